@@ -1,0 +1,227 @@
+/*
+ * manta_hip.h -- C ABI of the MI355X (gfx950) hot-path library `libmanta_hip.so`.
+ *
+ * The reference (zoharl3/mantaflow, /root/reference) has NO C ABI for this path: its boundary is the
+ * CPython module "manta" compiled into the executable (source/pwrapper/registry.cpp:21,488) and every
+ * plugin is reached through a generated `_W_n(self,args,kwds)` wrapper (preprocessor/codegen_python.cpp:32-58).
+ * What a maintainer would bind instead is therefore the set of KERNEL()/PYTHON() functions below; each
+ * entry point cites the reference function it replaces.  INTEGRATION.md shows the binding stub.
+ *
+ * The same signatures are implemented three times:
+ *   libmanta_hip.so     (mantaflow_amd/csrc)  the product: HIP kernels, every pointer is a DEVICE pointer
+ *   libmanta_oracle.so  (oracle/)             plain-C restatement, HOST pointers, test infrastructure only
+ *   libmanta_ref.so     (oracle/_ref)         the reference's own C++ behind a shim, HOST pointers, tests only
+ *
+ * Conventions
+ *   - all functions return 0 on success, non-zero on error; mf_last_error() gives the message
+ *     (reference: Manta::Error thrown by errMsg/assertMsg, general.h:42-77, surfaced as RuntimeError).
+ *   - pointers are BORROWED; nothing is allocated that the caller must free, except through mf_ws_*.
+ *   - `stream` is a hipStream_t (NULL = default stream); CPU libraries ignore it.  Calls are asynchronous
+ *     on the stream unless they return a scalar through a host pointer (those synchronise the stream).
+ *   - grids are dense, x fastest: idx = i + sx*(j + sy*k)  (reference grid.h:77).  2-D grids have sz == 1.
+ *   - Real grids: float[N]; FlagGrid/IntGrid: int32[N]  (N = sx*sy*sz).
+ *   - Vec3 / MAC grids are STRUCTURE-OF-ARRAYS: float[3][N] (x plane, y plane, z plane).  The reference
+ *     stores AoS Vec3 (vectorbase.h:69); the AoS view only exists at the numpy bridge (python side).
+ *   - particle positions / Vec3 pdata are SoA as well: float[3][cap]; component stride `pstride` (>= np)
+ *     is passed explicitly.  particle flags: int32[np] (particle.h:34-43: PNEW=1, PDELETE=1<<10 ...).
+ */
+#ifndef MANTA_HIP_H
+#define MANTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* FlagGrid::CellType, grid.h:306-320 */
+enum { MF_FLUID = 1, MF_OBSTACLE = 2, MF_EMPTY = 4, MF_INFLOW = 8, MF_OUTFLOW = 16, MF_OPEN = 32, MF_STICK = 64 };
+/* ParticleBase::SystemType status bits, particle.h:34-43 */
+enum { MF_PNEW = 1, MF_PDELETE = 1 << 10 };
+/* IntegrationMode, util/integrator.h:22 */
+enum { MF_INT_EULER = 0, MF_INT_RK2 = 1, MF_INT_RK4 = 2 };
+/* GridCgInterface::PreconditionType, conjugategrad.h:27 */
+enum { MF_PC_NONE = 0, MF_PC_ICP = 1, MF_PC_MICP = 2, MF_PC_MGP = 3 };
+
+const char* mf_last_error(void);
+/* "hip" | "oracle" | "reference" -- which implementation answered (tests assert on this) */
+const char* mf_backend(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise grid ops used inside the CG loop and by scenes
+ * ---------------------------------------------------------------------------------------------- */
+/* Grid<T>::clear / setConst, grid.cpp:95-97,279 */
+int mf_fill_f32(int64_t n, float* a, float value, void* stream);
+int mf_fill_i32(int64_t n, int32_t* a, int32_t value, void* stream);
+/* Grid<T>::copyFrom, grid.cpp:228-233 (n in elements of 4 bytes) */
+int mf_copy_f32(int64_t n, float* dst, const float* src, void* stream);
+/* gridScaledAdd<Real,Real>: me += factor*other, grid.h:514 */
+int mf_grid_scaled_add(int64_t n, float* me, const float* other, float factor, void* stream);
+/* UpdateSearchVec: dst = src + factor*dst, conjugategrad.cpp:193-196 */
+int mf_update_search_vec(int64_t n, float* dst, const float* src, float factor, void* stream);
+/* GridDotProduct: sum of fp32 products accumulated in fp64, conjugategrad.cpp:175-178 */
+int mf_grid_dot(int64_t n, const float* a, const float* b, double* result_host, void* stream);
+/* GridSumSqr, commonkernels.h:32-35 */
+int mf_grid_sum_sqr(int64_t n, const float* a, double* result_host, void* stream);
+/* Grid<Real>::getMaxAbs = max(|CompMinReal|,|CompMaxReal|), grid.cpp:185-196,356-360 */
+int mf_grid_max_abs(int64_t n, const float* a, float* result_host, void* stream);
+/* Grid<Real>::getMin / getMax */
+int mf_grid_min_max(int64_t n, const float* a, float* min_host, float* max_host, void* stream);
+/* Grid<Vec3>::getMaxAbs = sqrt(max normSquare), grid.cpp:198-224,367-369 (SoA input) */
+int mf_grid_max_abs_vec3(int64_t n, const float* a, float* result_host, void* stream);
+/* knGridStomp<Vec3>: v[c] < th ? 0 : v[c], grid.cpp:247-249 (applied to all 3n scalars) */
+int mf_grid_stomp(int64_t n, float* a, float threshold, void* stream);
+/* knGridSafeDiv: me = other ? me/other : me, grid.cpp:242, general.h:150 */
+int mf_grid_safe_divide(int64_t n, float* me, const float* other, void* stream);
+/* knGridAddConstReal / knGridMultConst / knGridClamp, grid.cpp:239-245 */
+int mf_grid_add_const(int64_t n, float* me, float v, void* stream);
+int mf_grid_mult_const(int64_t n, float* me, float v, void* stream);
+int mf_grid_clamp(int64_t n, float* me, float lo, float hi, void* stream);
+/* gridAdd / gridSub / gridMult, grid.h:508-512 */
+int mf_grid_add(int64_t n, float* me, const float* other, void* stream);
+int mf_grid_sub(int64_t n, float* me, const float* other, void* stream);
+int mf_grid_mult(int64_t n, float* me, const float* other, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pressure projection
+ * ---------------------------------------------------------------------------------------------- */
+/* ApplyMatrix / ApplyMatrix2D (sz==1), conjugategrad.h:118-151.  28 B/cell algorithmic traffic. */
+int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src,
+                    const float* A0, const float* Ai, const float* Aj, const float* Ak, void* stream);
+/* MakeLaplaceMatrix, conjugategrad.h:154-187.  A0..Ak must be zeroed by the caller (fresh temp grids).
+ * fractions: nullable SoA MAC grid. */
+int mf_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj,
+                           float* Ak, const float* fractions, void* stream);
+/* MakeRhs, plugin/pressure.cpp:32-84.  rhs border cells are left untouched (bnd=1 kernel).
+ * perCellCorr/fractions/obvel/phi/curv nullable.  cnt/sum returned through host pointers (nullable). */
+int mf_make_rhs(int sx, int sy, int sz, const int32_t* flags, float* rhs, const float* vel,
+                const float* perCellCorr, const float* fractions, const float* obvel,
+                const float* phi, const float* curv, float surfTens, float gfClamp,
+                int32_t* cnt_host, double* sum_host, void* stream);
+/* ApplyGhostFluidDiagonal, plugin/pressure.cpp:136-151 */
+int mf_apply_ghost_fluid_diagonal(int sx, int sy, int sz, float* A0, const int32_t* flags, const float* phi,
+                                  float gfClamp, void* stream);
+/* knCorrectVelocity, plugin/pressure.cpp:87-109 */
+int mf_correct_velocity(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* pressure,
+                        void* stream);
+/* knCorrectVelocityGhostFluid, plugin/pressure.cpp:154-187 (curv nullable) */
+int mf_correct_velocity_ghost_fluid(int sx, int sy, int sz, float* vel, const int32_t* flags,
+                                    const float* pressure, const float* phi, float gfClamp,
+                                    const float* curv, float surfTens, void* stream);
+/* knReplaceClampedGhostFluidVels, plugin/pressure.cpp:198-214 */
+int mf_replace_clamped_ghost_fluid_vels(int sx, int sy, int sz, float* vel, const int32_t* flags,
+                                        const float* pressure, const float* phi, float gfClamp, void* stream);
+/* CountEmptyCells, plugin/pressure.cpp:217-220 */
+int mf_count_empty_cells(int64_t n, const int32_t* flags, int32_t* result_host, void* stream);
+/* fixPressure, plugin/pressure.cpp:226-246 */
+int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float* rhs, float* A0, float* Ai,
+                    float* Aj, float* Ak, void* stream);
+
+/* InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97 (3-D only) */
+int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0,
+                const float* Ai, const float* Aj, const float* Ak, void* stream);
+/* ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159 (3-D only).
+ * dst keeps its previous content in non-fluid cells, exactly like the reference. */
+int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1,
+                 const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, void* stream);
+
+/* GridCg<ApplyMatrix>::doInit + iterate loop, conjugategrad.cpp:210-307, driven like
+ * solvePressureSystem's loop (plugin/pressure.cpp:438-441).
+ *   dst(pressure), residual, search, tmp : work grids, overwritten (dst = solution)
+ *   pc = MF_PC_NONE | MF_PC_MICP; Aprecond: grid for the MIC factor (pca0), unused for PC_NONE
+ *   out_host[0] = iterations done, out_host[1] = final residual norm (mResNorm), out_host[2] = mSigma
+ * returns non-zero with message "The CG solver diverged" when resNorm !< 1e35 (conjugategrad.cpp:288-295). */
+int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual,
+                float* search, float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak,
+                float* Aprecond, int pc, float accuracy, int maxIter, int useL2Norm,
+                float* out_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Advection (plugin/advection.cpp)
+ * ---------------------------------------------------------------------------------------------- */
+/* SemiLagrange<Real>, advection.cpp:25-42 (orderSpace must be 1; orderTrace 1|2).  bnd=1: border untouched */
+int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
+                          int orderTrace, void* stream);
+/* SemiLagrange<Vec3> (cell-centred Vec3 grid, SoA) */
+int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
+                          int orderTrace, void* stream);
+/* SemiLagrangeMAC, advection.cpp:45-78 */
+int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
+                         int orderTrace, void* stream);
+/* MacCormackCorrect<Real|Vec3> KERNEL(idx), advection.cpp:82-92; ncomp = 1 (Real) or 3 (Vec3 SoA) */
+int mf_maccormack_correct(int sx, int sy, int sz, int ncomp, const int32_t* flags, float* dst, const float* old,
+                          const float* fwd, const float* bwd, float strength, void* stream);
+/* MacCormackCorrectMAC<Vec3>(isMAC=true), advection.cpp:95-116 */
+int mf_maccormack_correct_mac(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* old,
+                              const float* fwd, const float* bwd, float strength, void* stream);
+/* MacCormackClamp<Real|Vec3>, advection.cpp:242-268 + doClampComponent :145-187 */
+int mf_maccormack_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags, const float* vel, float* dst,
+                        const float* orig, const float* fwd, float dt, int clampMode, void* stream);
+/* MacCormackClampMAC, advection.cpp:271-288 + doClampComponentMAC :192-236 */
+int mf_maccormack_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* dst,
+                            const float* orig, const float* fwd, float dt, int clampMode, void* stream);
+/* applyOutflowBC = extrapolateVelConvectiveBC + copyChangedVels, advection.cpp:347-392.
+ * velDst is a zeroed MAC scratch grid supplied by the caller. timeStep is the solver dt. */
+int mf_apply_outflow_bc(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* velPrev,
+                        float* velDst, float timeStep, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FLIP particle <-> grid transfers (plugin/flip.cpp, particle.h, util/interpol.h, util/integrator.h)
+ * ptype nullable; a particle is skipped when (ptype[idx] & exclude).
+ * ---------------------------------------------------------------------------------------------- */
+/* mapPartsToMAC, flip.cpp:637-661: clears vel+weight, scatters (knMapLinearVec3ToMACGrid :619-633 ->
+ * setInterpolMAC interpol.h:166-213), weight.stomp(1e-6), vel.safeDivide(weight), velOld.copyFrom(vel).
+ * deterministic != 0 : contributions are summed in particle-index order per cell (bit-identical to the
+ * reference's single-threaded scatter); 0 : fp32 atomics (order-dependent last bits). */
+int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight,
+                        int64_t np, int64_t pstride, const float* pos, const int32_t* pflag, const float* pvel,
+                        const int32_t* ptype, int exclude, int deterministic, void* stream);
+/* mapMACToParts -> knMapLinearMACGridToVec3_PIC, flip.cpp:709-721 */
+int mf_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t pstride, const float* pos,
+                        const int32_t* pflag, float* pvel, const int32_t* ptype, int exclude, void* stream);
+/* flipVelocityUpdate -> knMapLinearMACGridToVec3_FLIP, flip.cpp:724-742 */
+int mf_flip_velocity_update(int sx, int sy, int sz, const float* vel, const float* velOld, int64_t np,
+                            int64_t pstride, const float* pos, const int32_t* pflag, float* pvel,
+                            float flipRatio, const int32_t* ptype, int exclude, void* stream);
+/* mapPartsToGrid / mapPartsToGridVec3, flip.cpp:663-687 (+ setInterpol interpol.h:96-113, knSafeDivReal
+ * :607-615).  ncomp 1|3; target SoA; wtmp = zeroed Real scratch grid. */
+int mf_map_parts_to_grid(int sx, int sy, int sz, int ncomp, float* target, float* wtmp, int64_t np,
+                         int64_t pstride, const float* pos, const int32_t* pflag, const float* psrc,
+                         int deterministic, void* stream);
+/* mapGridToParts / mapGridToPartsVec3, flip.cpp:693-704 */
+int mf_map_grid_to_parts(int sx, int sy, int sz, int ncomp, const float* source, int64_t np, int64_t pstride,
+                         const float* pos, const int32_t* pflag, float* ptarget, void* stream);
+/* ParticleSystem::advectInGrid, particle.h:526-550 (GridAdvectKernel :458-481, integratePointSet
+ * integrator.h:26-78 incl. the fork's RK4 accumulation line 55, KnClampPositions :507-523,
+ * KnDeleteInObstacle :485-491).  scratch: float[3*3*pstride] (x0, u, uTotal). pos/pflag updated in place. */
+int mf_advect_in_grid(int sx, int sy, int sz, const int32_t* flags, const float* vel, int64_t np, int64_t pstride,
+                      float* pos, int32_t* pflag, float dt, int integrationMode, int deleteInObstacle,
+                      int stopInObstacle, int skipNew, const int32_t* ptype, int exclude, float* scratch,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * "next" rows: glue between advect and solve so a smoke step stays on the device
+ * ---------------------------------------------------------------------------------------------- */
+/* KnSetWallBcs (no fractions / obvel), plugin/extforces.cpp:187-237 */
+int mf_set_wall_bcs(int sx, int sy, int sz, const int32_t* flags, float* vel, void* stream);
+/* KnAddBuoyancy, plugin/extforces.cpp:73-88: strength = -gravity*dt/dx*coefficient computed by the caller */
+int mf_add_buoyancy(int sx, int sy, int sz, const int32_t* flags, const float* density, float* vel,
+                    float fx, float fy, float fz, void* stream);
+/* KnApplyForce (addGravity), plugin/extforces.cpp:46-66 */
+int mf_apply_force(int sx, int sy, int sz, const int32_t* flags, float* vel, float fx, float fy, float fz,
+                   int additive, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HIP-only helpers (return an error in the CPU libraries)
+ * ---------------------------------------------------------------------------------------------- */
+/* average duration in microseconds of `reps` back-to-back launches of the named kernel on `stream`,
+ * measured with hipEvents on that stream (used by bench.py for the roofline object). */
+int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src,
+                         const float* A0, const float* Ai, const float* Aj, const float* Ak, int reps,
+                         double* avg_us_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MANTA_HIP_H */

@@ -1,0 +1,513 @@
+/*
+ * oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never linked or loaded by the product path).
+ *
+ * A C ABI over the reference's own C++ classes (zoharl3/mantaflow, compiled from /root/reference by
+ * oracle/ref.mk in its NOPYTHON packaging).  This file is OUR code: it only constructs the reference's
+ * FluidSolver / Grid / BasicParticleSystem objects around caller-owned arrays and calls the reference's
+ * own plugins and kernels.  It pins the plain-C restatement (oracle/manta_oracle.c) and generates the
+ * golden vectors under tests/golden/.
+ *
+ * Array conventions are those of include/manta_hip.h (Vec3/MAC grids and particle vectors are SoA here and
+ * converted to the reference's AoS inside the shim).
+ */
+#include "manta.h"
+#include "grid.h"
+#include "particle.h"
+#include "conjugategrad.h"
+#include "commonkernels.h"
+#include "levelset.h"
+#include <cstring>
+#include <string>
+#include <vector>
+#include <memory>
+
+namespace Manta {
+// free functions with external linkage defined in the reference's .cpp files (no header declares them)
+void InitPreconditionModifiedIncompCholesky2(const FlagGrid& flags, Grid<Real>& Aprecond, Grid<Real>& A0,
+                                             Grid<Real>& Ai, Grid<Real>& Aj, Grid<Real>& Ak);  // conjugategrad.cpp:66
+void ApplyPreconditionModifiedIncompCholesky2(Grid<Real>& dst, Grid<Real>& Var1, const FlagGrid& flags,
+                                              Grid<Real>& Aprecond, Grid<Real>& A0, Grid<Real>& Ai,
+                                              Grid<Real>& Aj, Grid<Real>& Ak);                  // conjugategrad.cpp:135
+// PYTHON() plugins (plain functions in the NOPYTHON packaging)
+void advectSemiLagrange(const FlagGrid* flags, const MACGrid* vel, GridBase* grid, int order, Real strength,
+                        int orderSpace, bool openBounds, int boundaryWidth, int clampMode, int orderTrace);  // advection.cpp:443
+void computePressureRhs(Grid<Real>& rhs, const MACGrid& vel, const Grid<Real>& pressure, const FlagGrid& flags,
+                        Real cgAccuracy, const Grid<Real>* phi, const Grid<Real>* perCellCorr,
+                        const MACGrid* fractions, const MACGrid* obvel, Real gfClamp, Real cgMaxIterFac,
+                        bool precondition, int preconditioner, bool enforceCompatibility, bool useL2Norm,
+                        bool zeroPressureFixing, const Grid<Real>* curv, const Real surfTens);  // pressure.cpp:277
+void solvePressure(MACGrid& vel, Grid<Real>& pressure, const FlagGrid& flags, Real cgAccuracy,
+                   const Grid<Real>* phi, const Grid<Real>* perCellCorr, const MACGrid* fractions,
+                   const MACGrid* obvel, Real gfClamp, Real cgMaxIterFac, bool precondition, int preconditioner,
+                   bool enforceCompatibility, bool useL2Norm, bool zeroPressureFixing, const Grid<Real>* curv,
+                   const Real surfTens, Grid<Real>* retRhs);                                     // pressure.cpp:482
+void correctVelocity(MACGrid& vel, Grid<Real>& pressure, const FlagGrid& flags, Real cgAccuracy,
+                     const Grid<Real>* phi, const Grid<Real>* perCellCorr, const MACGrid* fractions, Real gfClamp,
+                     Real cgMaxIterFac, bool precondition, int preconditioner, bool enforceCompatibility,
+                     bool useL2Norm, bool zeroPressureFixing, const Grid<Real>* curv, const Real surfTens);  // pressure.cpp:457
+void mapPartsToMAC(const FlagGrid& flags, MACGrid& vel, MACGrid& velOld, const BasicParticleSystem& parts,
+                   const ParticleDataImpl<Vec3>& partVel, Grid<Vec3>* weight, const ParticleDataImpl<int>* ptype,
+                   const int exclude);                                                           // flip.cpp:637
+void mapMACToParts(const FlagGrid& flags, const MACGrid& vel, const BasicParticleSystem& parts,
+                   ParticleDataImpl<Vec3>& partVel, const ParticleDataImpl<int>* ptype, const int exclude);  // flip.cpp:717
+void flipVelocityUpdate(const FlagGrid& flags, const MACGrid& vel, const MACGrid& velOld,
+                        const BasicParticleSystem& parts, ParticleDataImpl<Vec3>& partVel, const Real flipRatio,
+                        const ParticleDataImpl<int>* ptype, const int exclude);                  // flip.cpp:738
+void mapPartsToGrid(const FlagGrid& flags, Grid<Real>& target, const BasicParticleSystem& parts,
+                    const ParticleDataImpl<Real>& source);                                       // flip.cpp:682
+void mapPartsToGridVec3(const FlagGrid& flags, Grid<Vec3>& target, const BasicParticleSystem& parts,
+                        const ParticleDataImpl<Vec3>& source);                                   // flip.cpp:685
+void mapGridToParts(const Grid<Real>& source, const BasicParticleSystem& parts, ParticleDataImpl<Real>& target);  // flip.cpp:699
+void mapGridToPartsVec3(const Grid<Vec3>& source, const BasicParticleSystem& parts,
+                        ParticleDataImpl<Vec3>& target);                                         // flip.cpp:702
+void setWallBcs(const FlagGrid& flags, MACGrid& vel, const MACGrid* obvel, const MACGrid* fractions,
+                const Grid<Real>* phiObs, int boundaryWidth);                                    // extforces.cpp:327
+void addBuoyancy(const FlagGrid& flags, const Grid<Real>& density, MACGrid& vel, Vec3 gravity, Real coefficient,
+                 bool scale);                                                                    // extforces.cpp:84
+void addGravity(const FlagGrid& flags, MACGrid& vel, Vec3 gravity, const Grid<Real>* exclude, bool scale);  // extforces.cpp:62
+}  // namespace Manta
+
+using namespace Manta;
+
+static thread_local std::string g_err;
+#define SHIM_TRY try {
+#define SHIM_CATCH                  \
+	}                               \
+	catch (std::exception & e) {    \
+		g_err = e.what();           \
+		return 1;                   \
+	}                               \
+	return 0;
+
+namespace {
+struct Ctx {
+	FluidSolver solver;
+	int64_t n;
+	Ctx(int sx, int sy, int sz, float dt) : solver(Vec3i(sx, sy, sz), sz > 1 ? 3 : 2), n((int64_t)sx * sy * sz) {
+		solver.mDt = dt;
+	}
+};
+// reference AoS Vec3 grid filled from / written back to a SoA float[3][n] array
+template <class G>
+struct VecIO {
+	G g;
+	float* soa;
+	int64_t n;
+	bool wb;
+	VecIO(Ctx& c, const float* s, bool writeback) : g(&c.solver), soa(const_cast<float*>(s)), n(c.n), wb(writeback) {
+		if (soa)
+			for (int64_t i = 0; i < n; i++) g[i] = Vec3(soa[i], soa[n + i], soa[2 * n + i]);
+	}
+	void store() {
+		if (soa)
+			for (int64_t i = 0; i < n; i++) {
+				soa[i] = g[i].x;
+				soa[n + i] = g[i].y;
+				soa[2 * n + i] = g[i].z;
+			}
+	}
+	~VecIO() {
+		if (wb) store();
+	}
+	G* ptr() { return soa ? &g : nullptr; }
+};
+typedef VecIO<MACGrid> MacIO;
+typedef VecIO<Grid<Vec3> > Vec3IO;
+
+struct RealRef {  // zero-copy Real grid over caller memory (Grid(FluidSolver*, T* data) ctor, grid.cpp:63-73)
+	std::unique_ptr<Grid<Real> > g;
+	RealRef(Ctx& c, const float* p) {
+		if (p) g.reset(new Grid<Real>(&c.solver, const_cast<float*>(p)));
+	}
+	Grid<Real>* ptr() { return g.get(); }
+	Grid<Real>& ref() { return *g; }
+};
+struct LevelRef {
+	std::unique_ptr<LevelsetGrid> g;
+	LevelRef(Ctx& c, const float* p) {
+		if (p) g.reset(new LevelsetGrid(&c.solver, const_cast<float*>(p)));
+	}
+};
+struct Parts {
+	BasicParticleSystem sys;
+	int64_t np, stride;
+	float* pos;
+	int32_t* pflag;
+	Parts(Ctx& c, int64_t np_, int64_t stride_, const float* pos_, const int32_t* pflag_)
+	    : sys(&c.solver), np(np_), stride(stride_), pos(const_cast<float*>(pos_)), pflag(const_cast<int32_t*>(pflag_)) {
+		sys.resizeAll(np);
+		for (int64_t i = 0; i < np; i++) {
+			sys[i].pos = Vec3(pos[i], pos[stride + i], pos[2 * stride + i]);
+			sys[i].flag = pflag ? pflag[i] : 0;
+		}
+	}
+	void store() {
+		for (int64_t i = 0; i < np; i++) {
+			pos[i] = sys[i].pos.x;
+			pos[stride + i] = sys[i].pos.y;
+			pos[2 * stride + i] = sys[i].pos.z;
+			if (pflag) pflag[i] = sys[i].flag;
+		}
+	}
+};
+template <class T>
+struct Pdata {
+	ParticleDataImpl<T> pd;
+	Pdata(Ctx& c, Parts& p) : pd(&c.solver) {
+		p.sys.registerPdata(&pd);
+		pd.resize(p.np);
+	}
+};
+static void loadVec3(ParticleDataImpl<Vec3>& pd, const float* s, int64_t np, int64_t stride) {
+	for (int64_t i = 0; i < np; i++) pd[i] = Vec3(s[i], s[stride + i], s[2 * stride + i]);
+}
+static void storeVec3(ParticleDataImpl<Vec3>& pd, float* s, int64_t np, int64_t stride) {
+	for (int64_t i = 0; i < np; i++) {
+		s[i] = pd[i].x;
+		s[stride + i] = pd[i].y;
+		s[2 * stride + i] = pd[i].z;
+	}
+}
+}  // namespace
+
+extern "C" {
+
+const char* mf_last_error(void) { return g_err.c_str(); }
+const char* mf_backend(void) { return "reference"; }
+
+/* ApplyMatrix / ApplyMatrix2D, conjugategrad.h:118-151 */
+int ref_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                     const float* Ai, const float* Aj, const float* Ak) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef d(c, dst), s(c, src), a0(c, A0), ai(c, Ai), aj(c, Aj), ak(c, Ak);
+	if (sz > 1)
+		ApplyMatrix(fl, d.ref(), s.ref(), a0.ref(), ai.ref(), aj.ref(), ak.ref());
+	else
+		ApplyMatrix2D(fl, d.ref(), s.ref(), a0.ref(), ai.ref(), aj.ref(), ak.ref());
+	SHIM_CATCH
+}
+
+/* MakeLaplaceMatrix, conjugategrad.h:154-187 */
+int ref_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak,
+                            const float* fractions) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef a0(c, A0), ai(c, Ai), aj(c, Aj), ak(c, Ak);
+	MacIO fr(c, fractions, false);
+	MakeLaplaceMatrix(fl, a0.ref(), ai.ref(), aj.ref(), ak.ref(), fr.ptr());
+	SHIM_CATCH
+}
+
+/* InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97 */
+int ref_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0, const float* Ai,
+                 const float* Aj, const float* Ak) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef ap(c, Aprecond), a0(c, A0), ai(c, Ai), aj(c, Aj), ak(c, Ak);
+	InitPreconditionModifiedIncompCholesky2(fl, ap.ref(), a0.ref(), ai.ref(), aj.ref(), ak.ref());
+	SHIM_CATCH
+}
+
+/* ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159 */
+int ref_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
+                  const float* A0, const float* Ai, const float* Aj, const float* Ak) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef d(c, dst), v(c, var1), ap(c, Aprecond), a0(c, A0), ai(c, Ai), aj(c, Aj), ak(c, Ak);
+	ApplyPreconditionModifiedIncompCholesky2(d.ref(), v.ref(), fl, ap.ref(), a0.ref(), ai.ref(), aj.ref(), ak.ref());
+	SHIM_CATCH
+}
+
+/* GridCg<ApplyMatrix>, conjugategrad.cpp:198-326, driven like solvePressureSystem (pressure.cpp:396-442) */
+int ref_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual,
+                 float* search, float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak,
+                 float* Aprecond, int pc, float accuracy, int maxIter, int useL2Norm, float* out) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef d(c, dst), r(c, rhs), res(c, residual), se(c, search), t(c, tmp), a0(c, A0), ai(c, Ai), aj(c, Aj), ak(c, Ak);
+	RealRef ap(c, Aprecond);
+	Grid<Real> p1(&c.solver), p2(&c.solver), p3(&c.solver);
+	std::unique_ptr<GridCgInterface> gcg;
+	if (sz > 1)
+		gcg.reset(new GridCg<ApplyMatrix>(d.ref(), r.ref(), res.ref(), se.ref(), fl, t.ref(), a0.ptr(), ai.ptr(), aj.ptr(), ak.ptr()));
+	else
+		gcg.reset(new GridCg<ApplyMatrix2D>(d.ref(), r.ref(), res.ref(), se.ref(), fl, t.ref(), a0.ptr(), ai.ptr(), aj.ptr(), ak.ptr()));
+	gcg->setAccuracy(accuracy);
+	gcg->setUseL2Norm(useL2Norm != 0);
+	if (pc == 2) gcg->setICPreconditioner(GridCgInterface::PC_mICP, ap.ptr(), &p1, &p2, &p3);
+	for (int iter = 0; iter < maxIter; iter++)
+		if (!gcg->iterate()) iter = maxIter;
+	out[0] = gcg->getIterations();
+	out[1] = gcg->getResNorm();
+	out[2] = gcg->getSigma();
+	SHIM_CATCH
+}
+
+/* computePressureRhs, pressure.cpp:277-299 */
+int ref_compute_pressure_rhs(int sx, int sy, int sz, const int32_t* flags, float* rhs, const float* vel,
+                             const float* phi, const float* perCellCorr, const float* fractions, const float* obvel,
+                             float gfClamp, int enforceCompatibility, const float* curv, float surfTens) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef r(c, rhs), ph(c, phi), pcc(c, perCellCorr), cv(c, curv);
+	Grid<Real> pressure(&c.solver);
+	MacIO v(c, vel, false), fr(c, fractions, false), ov(c, obvel, false);
+	computePressureRhs(r.ref(), v.g, pressure, fl, 1e-3, ph.ptr(), pcc.ptr(), fr.ptr(), ov.ptr(), gfClamp, 1.5, true, 1,
+	                   enforceCompatibility != 0, false, false, cv.ptr(), surfTens);
+	SHIM_CATCH
+}
+
+/* solvePressure, pressure.cpp:482-523 */
+int ref_solve_pressure(int sx, int sy, int sz, float* vel, float* pressure, const int32_t* flags, float cgAccuracy,
+                       const float* phi, const float* perCellCorr, const float* fractions, const float* obvel,
+                       float gfClamp, float cgMaxIterFac, int precondition, int preconditioner,
+                       int enforceCompatibility, int useL2Norm, int zeroPressureFixing, const float* curv,
+                       float surfTens, float* retRhs) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef p(c, pressure), ph(c, phi), pcc(c, perCellCorr), cv(c, curv), rr(c, retRhs);
+	MacIO v(c, vel, true), fr(c, fractions, false), ov(c, obvel, false);
+	solvePressure(v.g, p.ref(), fl, cgAccuracy, ph.ptr(), pcc.ptr(), fr.ptr(), ov.ptr(), gfClamp, cgMaxIterFac,
+	              precondition != 0, preconditioner, enforceCompatibility != 0, useL2Norm != 0, zeroPressureFixing != 0,
+	              cv.ptr(), surfTens, rr.ptr());
+	SHIM_CATCH
+}
+
+/* correctVelocity, pressure.cpp:457-478 */
+int ref_correct_velocity(int sx, int sy, int sz, float* vel, const float* pressure, const int32_t* flags,
+                         const float* phi, float gfClamp, const float* curv, float surfTens) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef p(c, pressure), ph(c, phi), cv(c, curv);
+	MacIO v(c, vel, true);
+	correctVelocity(v.g, p.ref(), fl, 1e-3, ph.ptr(), nullptr, nullptr, gfClamp, 1.5, true, 1, false, false, false,
+	                cv.ptr(), surfTens);
+	SHIM_CATCH
+}
+
+/* advectSemiLagrange, advection.cpp:443-461.  kind: 0 Real, 1 Vec3 (centred), 2 MAC, 3 Levelset(Real) */
+int ref_advect_semi_lagrange(int sx, int sy, int sz, float dt, const int32_t* flags, const float* vel, float* grid,
+                             int kind, int order, float strength, int orderSpace, int clampMode, int orderTrace) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, dt);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, false);
+	if (kind == 0) {
+		// the plugin swaps data pointers with a pool grid (grid.cpp:100-111): use a pool grid and copy back
+		Grid<Real> g(&c.solver);
+		memcpy(&g[0], grid, sizeof(float) * c.n);
+		advectSemiLagrange(&fl, &v.g, &g, order, strength, orderSpace, false, -1, clampMode, orderTrace);
+		memcpy(grid, &g[0], sizeof(float) * c.n);
+	} else if (kind == 3) {
+		LevelsetGrid g(&c.solver);
+		memcpy(&g[0], grid, sizeof(float) * c.n);
+		advectSemiLagrange(&fl, &v.g, &g, order, strength, orderSpace, false, -1, clampMode, orderTrace);
+		memcpy(grid, &g[0], sizeof(float) * c.n);
+	} else if (kind == 1) {
+		Vec3IO g(c, grid, false);
+		advectSemiLagrange(&fl, &v.g, &g.g, order, strength, orderSpace, false, -1, clampMode, orderTrace);
+		g.store();
+	} else {
+		MacIO g(c, grid, false);
+		advectSemiLagrange(&fl, &v.g, &g.g, order, strength, orderSpace, false, -1, clampMode, orderTrace);
+		g.store();
+	}
+	SHIM_CATCH
+}
+
+/* mapPartsToMAC, flip.cpp:637-661 */
+int ref_map_parts_to_mac(int sx, int sy, int sz, const int32_t* flags, float* vel, float* velOld, float* weight,
+                         int64_t np, int64_t pstride, const float* pos, const int32_t* pflag, const float* pvel,
+                         const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, true), vo(c, velOld, true);
+	Vec3IO w(c, weight, true);
+	Parts P(c, np, pstride, pos, pflag);
+	Pdata<Vec3> pv(c, P);
+	loadVec3(pv.pd, pvel, np, pstride);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	mapPartsToMAC(fl, v.g, vo.g, P.sys, pv.pd, w.ptr(), pt ? &pt->pd : nullptr, exclude);
+	SHIM_CATCH
+}
+
+/* mapMACToParts, flip.cpp:717-721 */
+int ref_map_mac_to_parts(int sx, int sy, int sz, const int32_t* flags, const float* vel, int64_t np, int64_t pstride,
+                         const float* pos, const int32_t* pflag, float* pvel, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, false);
+	Parts P(c, np, pstride, pos, pflag);
+	Pdata<Vec3> pv(c, P);
+	loadVec3(pv.pd, pvel, np, pstride);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	mapMACToParts(fl, v.g, P.sys, pv.pd, pt ? &pt->pd : nullptr, exclude);
+	storeVec3(pv.pd, pvel, np, pstride);
+	SHIM_CATCH
+}
+
+/* flipVelocityUpdate, flip.cpp:738-742 */
+int ref_flip_velocity_update(int sx, int sy, int sz, const int32_t* flags, const float* vel, const float* velOld,
+                             int64_t np, int64_t pstride, const float* pos, const int32_t* pflag, float* pvel,
+                             float flipRatio, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, false), vo(c, velOld, false);
+	Parts P(c, np, pstride, pos, pflag);
+	Pdata<Vec3> pv(c, P);
+	loadVec3(pv.pd, pvel, np, pstride);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	flipVelocityUpdate(fl, v.g, vo.g, P.sys, pv.pd, flipRatio, pt ? &pt->pd : nullptr, exclude);
+	storeVec3(pv.pd, pvel, np, pstride);
+	SHIM_CATCH
+}
+
+/* mapPartsToGrid / mapPartsToGridVec3, flip.cpp:682-687 */
+int ref_map_parts_to_grid(int sx, int sy, int sz, int ncomp, const int32_t* flags, float* target, int64_t np,
+                          int64_t pstride, const float* pos, const int32_t* pflag, const float* psrc) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	Parts P(c, np, pstride, pos, pflag);
+	if (ncomp == 1) {
+		RealRef t(c, target);
+		Pdata<Real> ps(c, P);
+		for (int64_t i = 0; i < np; i++) ps.pd[i] = psrc[i];
+		mapPartsToGrid(fl, t.ref(), P.sys, ps.pd);
+	} else {
+		Vec3IO t(c, target, true);
+		Pdata<Vec3> ps(c, P);
+		loadVec3(ps.pd, psrc, np, pstride);
+		mapPartsToGridVec3(fl, t.g, P.sys, ps.pd);
+	}
+	SHIM_CATCH
+}
+
+/* mapGridToParts / mapGridToPartsVec3, flip.cpp:699-704 */
+int ref_map_grid_to_parts(int sx, int sy, int sz, int ncomp, const float* source, int64_t np, int64_t pstride,
+                          const float* pos, const int32_t* pflag, float* ptarget) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	Parts P(c, np, pstride, pos, pflag);
+	if (ncomp == 1) {
+		RealRef s(c, source);
+		Pdata<Real> pt(c, P);
+		for (int64_t i = 0; i < np; i++) pt.pd[i] = ptarget[i];
+		mapGridToParts(s.ref(), P.sys, pt.pd);
+		for (int64_t i = 0; i < np; i++) ptarget[i] = pt.pd[i];
+	} else {
+		Vec3IO s(c, source, false);
+		Pdata<Vec3> pt(c, P);
+		loadVec3(pt.pd, ptarget, np, pstride);
+		mapGridToPartsVec3(s.g, P.sys, pt.pd);
+		storeVec3(pt.pd, ptarget, np, pstride);
+	}
+	SHIM_CATCH
+}
+
+/* ParticleSystem::advectInGrid, particle.h:526-550 */
+int ref_advect_in_grid(int sx, int sy, int sz, const int32_t* flags, const float* vel, int64_t np, int64_t pstride,
+                       float* pos, int32_t* pflag, float dt, int integrationMode, int deleteInObstacle,
+                       int stopInObstacle, int skipNew, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, dt);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, false);
+	Parts P(c, np, pstride, pos, pflag);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	P.sys.advectInGrid(fl, v.g, integrationMode, deleteInObstacle != 0, stopInObstacle != 0, skipNew != 0,
+	                   pt ? &pt->pd : nullptr, exclude);
+	P.store();
+	SHIM_CATCH
+}
+
+/* setWallBcs (no fractions), extforces.cpp:327-335 */
+int ref_set_wall_bcs(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* obvel) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, true), ov(c, obvel, false);
+	setWallBcs(fl, v.g, ov.ptr(), nullptr, nullptr, 0);
+	SHIM_CATCH
+}
+
+/* addBuoyancy, extforces.cpp:84-88 */
+int ref_add_buoyancy(int sx, int sy, int sz, float dt, const int32_t* flags, const float* density, float* vel,
+                     float gx, float gy, float gz, float coefficient, int scale) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, dt);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef d(c, density);
+	MacIO v(c, vel, true);
+	addBuoyancy(fl, d.ref(), v.g, Vec3(gx, gy, gz), coefficient, scale != 0);
+	SHIM_CATCH
+}
+
+/* addGravity, extforces.cpp:62-66 */
+int ref_add_gravity(int sx, int sy, int sz, float dt, const int32_t* flags, float* vel, float gx, float gy, float gz,
+                    const float* exclude, int scale) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, dt);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef e(c, exclude);
+	MacIO v(c, vel, true);
+	addGravity(fl, v.g, Vec3(gx, gy, gz), e.ptr(), scale != 0);
+	SHIM_CATCH
+}
+
+/* Grid<Real>::getMaxAbs (grid.cpp:356-360) and GridSumSqr (commonkernels.h:32-35) */
+int ref_grid_max_abs(int64_t n, const float* a, float* out) {
+	SHIM_TRY
+	Ctx c((int)n, 1, 1, 1.f);
+	RealRef g(c, a);
+	*out = g.ref().getMaxAbs();
+	SHIM_CATCH
+}
+int ref_grid_sum_sqr(int64_t n, const float* a, double* out) {
+	SHIM_TRY
+	Ctx c((int)n, 1, 1, 1.f);
+	RealRef g(c, a);
+	*out = GridSumSqr(g.ref()).sum;
+	SHIM_CATCH
+}
+
+/* FlagGrid::initDomain + fillGrid (grid.cpp:798-927) -- reference flag patterns for fixtures */
+int ref_init_domain(int sx, int sy, int sz, int32_t* flags, int boundaryWidth, const char* wall, const char* open,
+                    const char* inflow, const char* outflow, int fillType) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, flags);
+	fl.initDomain(boundaryWidth, wall, open, inflow, outflow, nullptr);
+	if (fillType) fl.fillGrid(fillType);
+	SHIM_CATCH
+}
+
+}  // extern "C"
