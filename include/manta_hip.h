@@ -203,14 +203,14 @@ int mf_advect_in_grid(int sx, int sy, int sz, const int32_t* flags, const float*
 /* ------------------------------------------------------------------------------------------------
  * "next" rows: glue between advect and solve so a smoke step stays on the device
  * ---------------------------------------------------------------------------------------------- */
-/* KnSetWallBcs (no fractions / obvel), plugin/extforces.cpp:187-237 */
-int mf_set_wall_bcs(int sx, int sy, int sz, const int32_t* flags, float* vel, void* stream);
+/* KnSetWallBcs (setWallBcs without fractions/phiObs), plugin/extforces.cpp:187-237,327-335; obvel nullable */
+int mf_set_wall_bcs(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* obvel, void* stream);
 /* KnAddBuoyancy, plugin/extforces.cpp:73-88: strength = -gravity*dt/dx*coefficient computed by the caller */
 int mf_add_buoyancy(int sx, int sy, int sz, const int32_t* flags, const float* density, float* vel,
                     float fx, float fy, float fz, void* stream);
-/* KnApplyForce (addGravity), plugin/extforces.cpp:46-66 */
+/* KnApplyForce (addGravity), plugin/extforces.cpp:46-66; exclude: nullable Real grid (skip where < 0) */
 int mf_apply_force(int sx, int sy, int sz, const int32_t* flags, float* vel, float fx, float fy, float fz,
-                   int additive, void* stream);
+                   const float* exclude, int additive, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HIP-only helpers (return an error in the CPU libraries)

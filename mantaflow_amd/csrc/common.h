@@ -1,0 +1,240 @@
+// common.h -- shared host/device helpers of libmanta_hip.so (gfx950 only).
+//
+// Numerics contract: every kernel keeps the reference's evaluation order and its float/double promotion
+// points (cited per kernel), and the library is compiled with -ffp-contract=off so that no FMA is formed
+// where the reference (gcc, x86-64, no -march) rounds twice.  IEEE fp32 divide/sqrt are hipcc's defaults.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/manta_hip.h"
+
+namespace mf {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+extern thread_local char g_err[512];
+int fail(const char* fmt, ...);
+#define MF_HIP(call)                                                                                  \
+	do {                                                                                              \
+		hipError_t e_ = (call);                                                                       \
+		if (e_ != hipSuccess) return mf::fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+#define MF_LAUNCH_CHECK() MF_HIP(hipGetLastError())
+#define MF_TRY(expr)           \
+	do {                       \
+		int r_ = (expr);       \
+		if (r_) return r_;     \
+	} while (0)
+
+// ---- per-device workspace (reduction partials, device scalars, pinned readback) ---------------------
+struct Workspace {
+	double* partials;   // [MAX_BLOCKS * 4]
+	float* fpartials;   // [MAX_BLOCKS * 4]
+	void* scalars;      // device scalar block (CgScalars etc.), 4 KiB
+	void* host;         // pinned host mirror, 4 KiB
+	int* tilework;      // counters for work-queue kernels
+};
+constexpr int MAX_BLOCKS = 16384;
+int get_workspace(Workspace** ws);
+
+// ---- grid geometry ---------------------------------------------------------------------------------
+struct Dim {
+	int sx, sy, sz;
+	int is3d;
+	int64_t Y, Z, n;  // strides (X == 1); Z == 0 in 2-D (reference grid.cpp:56)
+};
+static inline Dim mkdim(int sx, int sy, int sz) {
+	Dim d;
+	d.sx = sx;
+	d.sy = sy;
+	d.sz = sz;
+	d.is3d = sz > 1;
+	d.Y = sx;
+	d.Z = d.is3d ? (int64_t)sx * sy : 0;
+	d.n = (int64_t)sx * sy * sz;
+	return d;
+}
+static inline int check_dim(int sx, int sy, int sz) {
+	if (sx < 2 || sy < 2 || sz < 1) return fail("invalid grid size %dx%dx%d", sx, sy, sz);
+	if ((int64_t)sx * sy * sz >= (int64_t)1 << 31) return fail("grid too large for 32-bit cell indices");
+	return 0;
+}
+
+constexpr int BLOCK = 256;
+static inline int blocks_for(int64_t n, int per_block, int cap = MAX_BLOCKS) {
+	int64_t b = (n + per_block - 1) / per_block;
+	if (b < 1) b = 1;
+	if (b > cap) b = cap;
+	return (int)b;
+}
+
+// XCD-aware block remap: blocks are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so give
+// each XCD one contiguous range of work items; speed only, never correctness.
+__device__ __forceinline__ int xcd_swizzle(int b, int nb) {
+	if (nb & 7) return b;
+	return (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ---------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+	return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	return v;
+}
+// block-wide sum for blockDim.x == BLOCK (4 waves); result valid in thread 0
+__device__ __forceinline__ double block_sum(double v) {
+	__shared__ double sh[BLOCK / 64];
+	v = wave_sum(v);
+	const int w = threadIdx.x >> 6;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sh[w] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		v = sh[0];
+		for (int i = 1; i < (int)(blockDim.x >> 6); i++) v += sh[i];
+	}
+	return v;
+}
+__device__ __forceinline__ void block_minmax(float& lo, float& hi) {
+	__shared__ float shl[BLOCK / 64], shh[BLOCK / 64];
+	lo = wave_min(lo);
+	hi = wave_max(hi);
+	const int w = threadIdx.x >> 6;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) {
+		shl[w] = lo;
+		shh[w] = hi;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		lo = shl[0];
+		hi = shh[0];
+		for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
+			lo = fminf(lo, shl[i]);
+			hi = fmaxf(hi, shh[i]);
+		}
+	}
+}
+
+// ---- interpolation primitives, reference util/interpol.h -------------------------------------------------
+struct Bi {
+	int xi, yi, zi;
+	float s0, s1, t0, t1, f0, f1;
+};
+// BUILD_INDEX, interpol.h:52-69.  `1.-s1` is an fp64 subtraction rounded to fp32 in the reference; for
+// s1 in [0,1) that equals the fp32 subtraction (exact in fp64 when s1 >= 2^-29, both give 1 below), and
+// outside that range the clamps overwrite the weights.  The fork clamps the upper side on px, not xi.
+__device__ __forceinline__ Bi build_index(const Dim& d, float x, float y, float z) {
+	Bi b;
+	const float px = x - 0.5f, py = y - 0.5f, pz = z - 0.5f;
+	b.xi = (int)px;
+	b.yi = (int)py;
+	b.zi = (int)pz;
+	b.s1 = px - (float)b.xi;
+	b.s0 = (float)(1. - (double)b.s1);
+	b.t1 = py - (float)b.yi;
+	b.t0 = (float)(1. - (double)b.t1);
+	b.f1 = pz - (float)b.zi;
+	b.f0 = (float)(1. - (double)b.f1);
+	if (px < 0.f) { b.xi = 0; b.s0 = 1.f; b.s1 = 0.f; }
+	if (py < 0.f) { b.yi = 0; b.t0 = 1.f; b.t1 = 0.f; }
+	if (pz < 0.f) { b.zi = 0; b.f0 = 1.f; b.f1 = 0.f; }
+	if (px >= (float)(d.sx - 1)) { b.xi = d.sx - 2; b.s0 = 0.f; b.s1 = 1.f; }
+	if (py >= (float)(d.sy - 1)) { b.yi = d.sy - 2; b.t0 = 0.f; b.t1 = 1.f; }
+	if (d.sz > 1) { if (pz >= (float)(d.sz - 1)) { b.zi = d.sz - 2; b.f0 = 0.f; b.f1 = 1.f; } }
+	return b;
+}
+// shifted half of BUILD_INDEX_SHIFT, interpol.h:116-129 (upper clamp on the integer index)
+__device__ __forceinline__ Bi build_index_shift(const Dim& d, float x, float y, float z) {
+	Bi b;
+	b.xi = (int)x;
+	b.yi = (int)y;
+	b.zi = (int)z;
+	b.s1 = x - (float)b.xi;
+	b.s0 = (float)(1. - (double)b.s1);
+	b.t1 = y - (float)b.yi;
+	b.t0 = (float)(1. - (double)b.t1);
+	b.f1 = z - (float)b.zi;
+	b.f0 = (float)(1. - (double)b.f1);
+	if (x < 0.f) { b.xi = 0; b.s0 = 1.f; b.s1 = 0.f; }
+	if (y < 0.f) { b.yi = 0; b.t0 = 1.f; b.t1 = 0.f; }
+	if (z < 0.f) { b.zi = 0; b.f0 = 1.f; b.f1 = 0.f; }
+	if (b.xi >= d.sx - 1) { b.xi = d.sx - 2; b.s0 = 0.f; b.s1 = 1.f; }
+	if (b.yi >= d.sy - 1) { b.yi = d.sy - 2; b.t0 = 0.f; b.t1 = 1.f; }
+	if (d.sz > 1) { if (b.zi >= d.sz - 1) { b.zi = d.sz - 2; b.f0 = 0.f; b.f1 = 1.f; } }
+	return b;
+}
+// 8-corner gather with the reference's association order, interpol.h:77-80 / 90-93
+__device__ __forceinline__ float tri8(const float* __restrict__ r, int64_t Y, int64_t Z, float t0, float t1, float s0,
+                                      float s1, float f0, float f1) {
+	const float a = (r[0] * t0 + r[Y] * t1) * s0 + (r[1] * t0 + r[1 + Y] * t1) * s1;
+	const float b = (r[Z] * t0 + r[Y + Z] * t1) * s0 + (r[1 + Z] * t0 + r[1 + Y + Z] * t1) * s1;
+	return a * f0 + b * f1;
+}
+// interpol<T> / interpolComponent<c> on one scalar plane
+__device__ __forceinline__ float interpol1(const Dim& d, const float* __restrict__ data, float x, float y, float z) {
+	const Bi b = build_index(d, x, y, z);
+	const int64_t idx = (int64_t)b.xi + d.Y * b.yi + d.Z * b.zi;
+	return tri8(data + idx, d.Y, d.Z, b.t0, b.t1, b.s0, b.s1, b.f0, b.f1);
+}
+// interpolMAC, interpol.h:131-164 (vel is SoA: x plane, y plane, z plane)
+__device__ __forceinline__ void interpol_mac(const Dim& d, const float* __restrict__ vel, float x, float y, float z,
+                                             float& ox, float& oy, float& oz) {
+	const Bi b = build_index(d, x, y, z), s = build_index_shift(d, x, y, z);
+	ox = tri8(vel + (((int64_t)b.zi * d.sy + b.yi) * d.sx + s.xi), d.Y, d.Z, b.t0, b.t1, s.s0, s.s1, b.f0, b.f1);
+	oy = tri8(vel + d.n + (((int64_t)b.zi * d.sy + s.yi) * d.sx + b.xi), d.Y, d.Z, s.t0, s.t1, b.s0, b.s1, b.f0, b.f1);
+	oz = tri8(vel + 2 * d.n + (((int64_t)s.zi * d.sy + b.yi) * d.sx + b.xi), d.Y, d.Z, b.t0, b.t1, b.s0, b.s1, s.f0, s.f1);
+}
+// MACGrid samplers, grid.h:460-506.  0.5*/0.25* of an fp32 sum is exact, so fp32 arithmetic matches the
+// reference's double-literal products.
+__device__ __forceinline__ void get_centered(const Dim& d, const float* __restrict__ vel, int64_t idx, float& vx,
+                                             float& vy, float& vz) {
+	vx = 0.5f * (vel[idx] + vel[idx + 1]);
+	vy = 0.5f * (vel[d.n + idx] + vel[d.n + idx + d.sx]);
+	vz = 0.f;
+	if (d.is3d) vz = 0.5f * (vel[2 * d.n + idx] + vel[2 * d.n + idx + d.Z]);
+}
+__device__ __forceinline__ void get_at_mac_x(const Dim& d, const float* __restrict__ vel, int64_t idx, float& vx,
+                                             float& vy, float& vz) {
+	const float* y = vel + d.n;
+	const float* z = vel + 2 * d.n;
+	vx = vel[idx];
+	vy = 0.25f * (y[idx] + y[idx - 1] + y[idx + d.sx] + y[idx + d.sx - 1]);
+	vz = 0.f;
+	if (d.is3d) vz = 0.25f * (z[idx] + z[idx - 1] + z[idx + d.Z] + z[idx + d.Z - 1]);
+}
+__device__ __forceinline__ void get_at_mac_y(const Dim& d, const float* __restrict__ vel, int64_t idx, float& vx,
+                                             float& vy, float& vz) {
+	const float* x = vel;
+	const float* z = vel + 2 * d.n;
+	vx = 0.25f * (x[idx] + x[idx - d.sx] + x[idx + 1] + x[idx + 1 - d.sx]);
+	vy = vel[d.n + idx];
+	vz = 0.f;
+	if (d.is3d) vz = 0.25f * (z[idx] + z[idx - d.sx] + z[idx + d.Z] + z[idx + d.Z - d.sx]);
+}
+__device__ __forceinline__ void get_at_mac_z(const Dim& d, const float* __restrict__ vel, int64_t idx, float& vx,
+                                             float& vy, float& vz) {
+	const float* x = vel;
+	const float* y = vel + d.n;
+	vx = 0.25f * (x[idx] + x[idx - d.Z] + x[idx + 1] + x[idx + 1 - d.Z]);
+	vy = 0.25f * (y[idx] + y[idx - d.Z] + y[idx + d.sx] + y[idx + d.sx - d.Z]);
+	vz = vel[2 * d.n + idx];
+}
+
+}  // namespace mf

@@ -1,0 +1,991 @@
+// pressure.hip -- pressure projection on gfx950: 7-point ApplyMatrix stencil, Laplace matrix / rhs assembly,
+// velocity correction (+ ghost fluid), MIC(0) preconditioner as tile wavefronts, and the device-resident PCG loop.
+// Reference: source/conjugategrad.{h,cpp}, source/plugin/pressure.cpp (cited per kernel).
+#include "common.h"
+#include <float.h>
+
+using namespace mf;
+
+// =========================================================================================================
+// ApplyMatrix, conjugategrad.h:118-151
+//   non-fluid: dst = src ; fluid: left-to-right fp32 sum of the 7 products.  28 B/cell of compulsory traffic
+//   (flags, src, A0, Ai, Aj, Ak read once + dst written); the +-X/+-Y/+-Z neighbours of src and the -X/-Y/-Z
+//   entries of Ai/Aj/Ak are re-reads served by L1/L2 (each XCD owns a contiguous z-range of the grid).
+//   Optional fusion: per-block fp64 partial sums of dst*src (GridDotProduct(tmp, search)).
+// =========================================================================================================
+struct CgScalars {
+	float sigma, alpha, nalpha, beta, resNorm, dp, sigmaNew, accuracy;
+	int iterations, done, diverged, useL2;
+};
+
+template <bool DOT, bool IS3D>
+__global__ void __launch_bounds__(BLOCK)
+k_apply_matrix_v4(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
+                  const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
+                  const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int qpt) {
+	if (DOT && sc->done) return;
+	const int64_t nq = d.n >> 2;
+	const int qx = d.sx >> 2;  // quads per row (sx % 4 == 0)
+	double acc = 0.0;
+	// each block owns a contiguous run of qpt*BLOCK quads; with the XCD remap every XCD sweeps one contiguous
+	// z-slab front to back, so the +-Z neighbour planes are still in that XCD's L2 when they are re-read
+	const int vb = xcd_swizzle(blockIdx.x, gridDim.x);
+	const int64_t base = (int64_t)vb * BLOCK * qpt + threadIdx.x;
+	for (int t = 0; t < qpt; t++) {
+		const int64_t q = base + (int64_t)t * BLOCK;
+		if (q >= nq) break;
+		const int64_t idx = q << 2;
+		const int4 f = ((const int4*)flags)[q];
+		const float4 s = ((const float4*)src)[q];
+		float4 r = s;
+		if ((f.x | f.y | f.z | f.w) & MF_FLUID) {
+			const int64_t row = q / qx;
+			const int i0 = (int)(q - row * qx) << 2;
+			const int j = (int)(row % d.sy);
+			const int k = (int)(row / d.sy);
+			const float4 a0 = ((const float4*)A0)[q];
+			const float4 ai = ((const float4*)Ai)[q];
+			const float4 aj = ((const float4*)Aj)[q];
+			const float sl = (idx > 0) ? src[idx - 1] : 0.f;
+			const float al = (idx > 0) ? Ai[idx - 1] : 0.f;
+			const float sr = (idx + 4 < d.n) ? src[idx + 4] : 0.f;
+			const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+			const float4 sym = (j > 0) ? *(const float4*)(src + idx - d.Y) : z4;
+			const float4 ajm = (j > 0) ? *(const float4*)(Aj + idx - d.Y) : z4;
+			const float4 syp = (j < d.sy - 1) ? *(const float4*)(src + idx + d.Y) : z4;
+			float4 szm = z4, akm = z4, szp = z4, ak = z4;
+			if (IS3D) {
+				ak = ((const float4*)Ak)[q];
+				if (k > 0) {
+					szm = *(const float4*)(src + idx - d.Z);
+					akm = *(const float4*)(Ak + idx - d.Z);
+				}
+				if (k < d.sz - 1) szp = *(const float4*)(src + idx + d.Z);
+			}
+			(void)i0;
+#define CELL(c, SL, AL, SR)                                                                       \
+	if (f.c & MF_FLUID) {                                                                         \
+		float v = s.c * a0.c;                                                                     \
+		v = v + (SL) * (AL);                                                                      \
+		v = v + (SR) * ai.c;                                                                      \
+		v = v + sym.c * ajm.c;                                                                    \
+		v = v + syp.c * aj.c;                                                                     \
+		if (IS3D) {                                                                               \
+			v = v + szm.c * akm.c;                                                                \
+			v = v + szp.c * ak.c;                                                                 \
+		}                                                                                         \
+		r.c = v;                                                                                  \
+	}
+			CELL(x, sl, al, s.y)
+			CELL(y, s.x, ai.x, s.z)
+			CELL(z, s.y, ai.y, s.w)
+			CELL(w, s.z, ai.z, sr)
+#undef CELL
+		}
+		((float4*)dst)[q] = r;
+		if (DOT) {
+			const float p0 = r.x * s.x, p1 = r.y * s.y, p2 = r.z * s.z, p3 = r.w * s.w;
+			acc += (double)p0;
+			acc += (double)p1;
+			acc += (double)p2;
+			acc += (double)p3;
+		}
+	}
+	if (DOT) {
+		acc = block_sum(acc);
+		if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+	}
+}
+
+// generic fallback (sx % 4 != 0 or unaligned views): one cell per thread
+template <bool DOT>
+__global__ void __launch_bounds__(BLOCK)
+k_apply_matrix_scalar(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
+                      const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
+                      const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc) {
+	if (DOT && sc->done) return;
+	double acc = 0.0;
+	for (int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x; idx < d.n; idx += (int64_t)gridDim.x * BLOCK) {
+		const float s = src[idx];
+		float v = s;
+		if (flags[idx] & MF_FLUID) {
+			const int64_t Y = d.Y, Z = d.Z;
+			v = s * A0[idx];
+			v = v + ((idx >= 1) ? src[idx - 1] * Ai[idx - 1] : 0.f);
+			v = v + ((idx + 1 < d.n) ? src[idx + 1] : 0.f) * Ai[idx];
+			v = v + ((idx >= Y) ? src[idx - Y] * Aj[idx - Y] : 0.f);
+			v = v + ((idx + Y < d.n) ? src[idx + Y] : 0.f) * Aj[idx];
+			if (d.is3d) {
+				v = v + ((idx >= Z) ? src[idx - Z] * Ak[idx - Z] : 0.f);
+				v = v + ((idx + Z < d.n) ? src[idx + Z] : 0.f) * Ak[idx];
+			}
+		}
+		dst[idx] = v;
+		if (DOT) {
+			const float p = v * s;
+			acc += (double)p;
+		}
+	}
+	if (DOT) {
+		acc = block_sum(acc);
+		if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+	}
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// returns the number of blocks launched (== number of partials written when DOT)
+template <bool DOT>
+static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, const float* src, const float* A0,
+                               const float* Ai, const float* Aj, const float* Ak, double* partials,
+                               const CgScalars* sc, hipStream_t st, int* nblocks) {
+	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
+	int nb;
+	if (vec) {
+		const int64_t nq = d.n >> 2;
+		const int qpt = (int)((nq + (int64_t)BLOCK * MAX_BLOCKS - 1) / ((int64_t)BLOCK * MAX_BLOCKS));
+		nb = (int)((nq + (int64_t)BLOCK * qpt - 1) / ((int64_t)BLOCK * qpt));
+		if (nb < 1) nb = 1;
+		if (d.is3d)
+			hipLaunchKernelGGL((k_apply_matrix_v4<DOT, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, qpt);
+		else
+			hipLaunchKernelGGL((k_apply_matrix_v4<DOT, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, qpt);
+	} else {
+		nb = blocks_for(d.n, BLOCK, 2048);
+		hipLaunchKernelGGL((k_apply_matrix_scalar<DOT>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc);
+	}
+	MF_LAUNCH_CHECK();
+	if (nblocks) *nblocks = nb;
+	return 0;
+}
+
+// =========================================================================================================
+// assembly kernels (one thread per cell, bnd = 1 unless noted)
+// =========================================================================================================
+#define CELL_IJK(d)                                                               \
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;                \
+	if (idx >= (d).n) return;                                                     \
+	const int i = (int)(idx % (d).sx);                                            \
+	const int j = (int)((idx / (d).sx) % (d).sy);                                 \
+	const int k = (int)(idx / ((int64_t)(d).sx * (d).sy));                        \
+	(void)i; (void)j; (void)k;
+#define INTERIOR(d) (i >= 1 && i < (d).sx - 1 && j >= 1 && j < (d).sy - 1 && (!(d).is3d || (k >= 1 && k < (d).sz - 1)))
+
+// MakeLaplaceMatrix, conjugategrad.h:154-187
+__global__ void __launch_bounds__(BLOCK)
+k_make_laplace(Dim d, const int32_t* __restrict__ flags, float* __restrict__ A0, float* __restrict__ Ai,
+               float* __restrict__ Aj, float* __restrict__ Ak, const float* __restrict__ fr) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (!(flags[idx] & MF_FLUID)) return;
+	const int64_t Y = d.Y, Z = d.Z;
+	float a0 = A0[idx];
+	if (!fr) {
+		// `A0 += 1.` : fp32 value + double literal, rounded back; exact for these magnitudes
+		if (!(flags[idx - 1] & MF_OBSTACLE)) a0 = (float)((double)a0 + 1.);
+		if (!(flags[idx + 1] & MF_OBSTACLE)) a0 = (float)((double)a0 + 1.);
+		if (!(flags[idx - Y] & MF_OBSTACLE)) a0 = (float)((double)a0 + 1.);
+		if (!(flags[idx + Y] & MF_OBSTACLE)) a0 = (float)((double)a0 + 1.);
+		if (d.is3d && !(flags[idx - Z] & MF_OBSTACLE)) a0 = (float)((double)a0 + 1.);
+		if (d.is3d && !(flags[idx + Z] & MF_OBSTACLE)) a0 = (float)((double)a0 + 1.);
+		if (flags[idx + 1] & MF_FLUID) Ai[idx] = -1.f;
+		if (flags[idx + Y] & MF_FLUID) Aj[idx] = -1.f;
+		if (d.is3d && (flags[idx + Z] & MF_FLUID)) Ak[idx] = -1.f;
+	} else {
+		const float *fx = fr, *fy = fr + d.n, *fz = fr + 2 * d.n;
+		a0 += fx[idx];
+		a0 += fx[idx + 1];
+		a0 += fy[idx];
+		a0 += fy[idx + Y];
+		if (d.is3d) a0 += fz[idx];
+		if (d.is3d) a0 += fz[idx + Z];
+		if (flags[idx + 1] & MF_FLUID) Ai[idx] = -fx[idx + 1];
+		if (flags[idx + Y] & MF_FLUID) Aj[idx] = -fy[idx + Y];
+		if (d.is3d && (flags[idx + Z] & MF_FLUID)) Ak[idx] = -fz[idx + Z];
+	}
+	A0[idx] = a0;
+}
+
+// ghost-fluid helpers, plugin/pressure.cpp:115-133, 191-196
+__device__ __forceinline__ float thetaHelper(float inside, float outside) {
+	const float denom = inside - outside;
+	if ((double)denom > -1e-04) return 0.5f;
+	const float q = inside / denom;
+	const float m = q < 1.f ? q : 1.f;
+	return 0.f < m ? m : 0.f;
+}
+__device__ __forceinline__ float ghostFluidHelper(int64_t idx, int64_t offset, const float* __restrict__ phi, float gfClamp) {
+	const float alpha = thetaHelper(phi[idx], phi[idx + offset]);
+	if (alpha < gfClamp) return gfClamp;
+	return (float)(1. - (1. / (double)alpha));
+}
+__device__ __forceinline__ float surfTensHelper(int64_t idx, int64_t offset, const float* __restrict__ phi,
+                                                const float* __restrict__ curv, float surfTens, float gfClamp) {
+	return surfTens * (curv[idx + offset] - ghostFluidHelper(idx, offset, phi, gfClamp) * curv[idx]);
+}
+__device__ __forceinline__ bool ghostFluidWasClamped(int64_t idx, int64_t offset, const float* __restrict__ phi, float gfClamp) {
+	return thetaHelper(phi[idx], phi[idx + offset]) < gfClamp;
+}
+
+// MakeRhs, plugin/pressure.cpp:32-84 ; partials[b] = fp64 sum of `set`, partials[MAX_BLOCKS + b] = count
+__global__ void __launch_bounds__(BLOCK)
+k_make_rhs(Dim d, const int32_t* __restrict__ flags, float* __restrict__ rhs, const float* __restrict__ vel,
+           const float* __restrict__ pcc, const float* __restrict__ fr, const float* __restrict__ ob,
+           const float* __restrict__ phi, const float* __restrict__ curv, float surfTens, float gfClamp,
+           double* __restrict__ partials) {
+	double mysum = 0.0, mycnt = 0.0;
+	const int64_t X = 1, Y = d.Y, Z = d.Z, n = d.n;
+	const float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+	for (int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * BLOCK) {
+		const int i = (int)(idx % d.sx);
+		const int j = (int)((idx / d.sx) % d.sy);
+		const int k = (int)(idx / ((int64_t)d.sx * d.sy));
+		if (!INTERIOR(d)) continue;
+		if (!(flags[idx] & MF_FLUID)) {
+			rhs[idx] = 0.f;
+			continue;
+		}
+		float set;
+		if (!fr) {
+			set = vx[idx] - vx[idx + X] + vy[idx] - vy[idx + Y];
+			if (d.is3d) set += vz[idx] - vz[idx + Z];
+		} else {
+			const float *fx = fr, *fy = fr + n, *fz = fr + 2 * n;
+			set = fx[idx] * vx[idx] - fx[idx + X] * vx[idx + X] + fy[idx] * vy[idx] - fy[idx + Y] * vy[idx + Y];
+			if (d.is3d) set += fz[idx] * vz[idx] - fz[idx + Z] * vz[idx + Z];
+			if (ob) {
+				const float *ox = ob, *oy = ob + n, *oz = ob + 2 * n;
+				set += (1 - fx[idx]) * ox[idx] - (1 - fx[idx + X]) * ox[idx + X] + (1 - fy[idx]) * oy[idx] -
+				       (1 - fy[idx + Y]) * oy[idx + Y];
+				if (d.is3d) set += (1 - fz[idx]) * oz[idx] - (1 - fz[idx + Z]) * oz[idx + Z];
+			}
+		}
+		if (phi && curv) {
+			if (flags[idx - X] & MF_EMPTY) set += surfTensHelper(idx, -X, phi, curv, surfTens, gfClamp);
+			if (flags[idx + X] & MF_EMPTY) set += surfTensHelper(idx, +X, phi, curv, surfTens, gfClamp);
+			if (flags[idx - Y] & MF_EMPTY) set += surfTensHelper(idx, -Y, phi, curv, surfTens, gfClamp);
+			if (flags[idx + Y] & MF_EMPTY) set += surfTensHelper(idx, +Y, phi, curv, surfTens, gfClamp);
+			if (d.is3d) {
+				if (flags[idx - Z] & MF_EMPTY) set += surfTensHelper(idx, -Z, phi, curv, surfTens, gfClamp);
+				if (flags[idx + Z] & MF_EMPTY) set += surfTensHelper(idx, +Z, phi, curv, surfTens, gfClamp);
+			}
+		}
+		if (pcc) set += pcc[idx];
+		mysum += (double)set;
+		mycnt += 1.0;
+		rhs[idx] = set;
+	}
+	mysum = block_sum(mysum);
+	__syncthreads();
+	mycnt = block_sum(mycnt);
+	if (threadIdx.x == 0) {
+		partials[blockIdx.x] = mysum;
+		partials[MAX_BLOCKS + blockIdx.x] = mycnt;
+	}
+}
+// second-level reduction for grids with more blocks than one finishing block can hold in `partials`
+__global__ void __launch_bounds__(BLOCK) k_sum2_finish(int nb, const double* __restrict__ p0, const double* __restrict__ p1, double* __restrict__ out) {
+	double a = 0.0, b = 0.0;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+		a += p0[i];
+		b += p1[i];
+	}
+	a = block_sum(a);
+	__syncthreads();
+	b = block_sum(b);
+	if (threadIdx.x == 0) {
+		out[0] = a;
+		out[1] = b;
+	}
+}
+
+// ApplyGhostFluidDiagonal, plugin/pressure.cpp:136-151
+__global__ void __launch_bounds__(BLOCK)
+k_ghost_fluid_diag(Dim d, float* __restrict__ A0, const int32_t* __restrict__ flags, const float* __restrict__ phi, float gfClamp) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (!(flags[idx] & MF_FLUID)) return;
+	const int64_t X = 1, Y = d.Y, Z = d.Z;
+	float a = A0[idx];
+	if (flags[idx - X] & MF_EMPTY) a -= ghostFluidHelper(idx, -X, phi, gfClamp);
+	if (flags[idx + X] & MF_EMPTY) a -= ghostFluidHelper(idx, +X, phi, gfClamp);
+	if (flags[idx - Y] & MF_EMPTY) a -= ghostFluidHelper(idx, -Y, phi, gfClamp);
+	if (flags[idx + Y] & MF_EMPTY) a -= ghostFluidHelper(idx, +Y, phi, gfClamp);
+	if (d.is3d) {
+		if (flags[idx - Z] & MF_EMPTY) a -= ghostFluidHelper(idx, -Z, phi, gfClamp);
+		if (flags[idx + Z] & MF_EMPTY) a -= ghostFluidHelper(idx, +Z, phi, gfClamp);
+	}
+	A0[idx] = a;
+}
+
+// knCorrectVelocity, plugin/pressure.cpp:87-109
+__global__ void __launch_bounds__(BLOCK)
+k_correct_velocity(Dim d, const int32_t* __restrict__ flags, float* __restrict__ vel, const float* __restrict__ p) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	const int64_t X = 1, Y = d.Y, Z = d.Z, n = d.n;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+	const int f = flags[idx];
+	if (f & MF_FLUID) {
+		const float pc = p[idx];
+		float x = vx[idx], y = vy[idx], z = d.is3d ? vz[idx] : 0.f;
+		const int fxm = flags[idx - X], fym = flags[idx - Y], fzm = d.is3d ? flags[idx - Z] : 0;
+		if (fxm & MF_FLUID) x -= (pc - p[idx - X]);
+		if (fym & MF_FLUID) y -= (pc - p[idx - Y]);
+		if (d.is3d && (fzm & MF_FLUID)) z -= (pc - p[idx - Z]);
+		if (fxm & MF_EMPTY) x -= pc;
+		if (fym & MF_EMPTY) y -= pc;
+		if (d.is3d && (fzm & MF_EMPTY)) z -= pc;
+		vx[idx] = x;
+		vy[idx] = y;
+		if (d.is3d) vz[idx] = z;
+	} else if ((f & MF_EMPTY) && !(f & MF_OUTFLOW)) {
+		if (flags[idx - X] & MF_FLUID) vx[idx] += p[idx - X]; else vx[idx] = 0.f;
+		if (flags[idx - Y] & MF_FLUID) vy[idx] += p[idx - Y]; else vy[idx] = 0.f;
+		if (d.is3d) {
+			if (flags[idx - Z] & MF_FLUID) vz[idx] += p[idx - Z]; else vz[idx] = 0.f;
+		}
+	}
+}
+
+// knCorrectVelocityGhostFluid, plugin/pressure.cpp:154-187
+__global__ void __launch_bounds__(BLOCK)
+k_correct_velocity_gf(Dim d, float* __restrict__ vel, const int32_t* __restrict__ flags, const float* __restrict__ p,
+                      const float* __restrict__ phi, float gfClamp, const float* __restrict__ curv, float surfTens) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	const int64_t X = 1, Y = d.Y, Z = d.Z, n = d.n;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+	const int f = flags[idx];
+	const bool fl = (f & MF_FLUID) != 0, emp = (f & MF_EMPTY) && !(f & MF_OUTFLOW);
+	if (fl) {
+		if (flags[idx - X] & MF_EMPTY) vx[idx] += p[idx] * ghostFluidHelper(idx, -X, phi, gfClamp);
+		if (flags[idx - Y] & MF_EMPTY) vy[idx] += p[idx] * ghostFluidHelper(idx, -Y, phi, gfClamp);
+		if (d.is3d && (flags[idx - Z] & MF_EMPTY)) vz[idx] += p[idx] * ghostFluidHelper(idx, -Z, phi, gfClamp);
+	} else if (emp) {
+		if (flags[idx - X] & MF_FLUID) vx[idx] -= p[idx - X] * ghostFluidHelper(idx - X, +X, phi, gfClamp); else vx[idx] = 0.f;
+		if (flags[idx - Y] & MF_FLUID) vy[idx] -= p[idx - Y] * ghostFluidHelper(idx - Y, +Y, phi, gfClamp); else vy[idx] = 0.f;
+		if (d.is3d) {
+			if (flags[idx - Z] & MF_FLUID) vz[idx] -= p[idx - Z] * ghostFluidHelper(idx - Z, +Z, phi, gfClamp); else vz[idx] = 0.f;
+		}
+	}
+	if (curv) {
+		if (fl) {
+			if (flags[idx - X] & MF_EMPTY) vx[idx] += surfTensHelper(idx, -X, phi, curv, surfTens, gfClamp);
+			if (flags[idx - Y] & MF_EMPTY) vy[idx] += surfTensHelper(idx, -Y, phi, curv, surfTens, gfClamp);
+			if (d.is3d && (flags[idx - Z] & MF_EMPTY)) vz[idx] += surfTensHelper(idx, -Z, phi, curv, surfTens, gfClamp);
+		} else if (emp) {
+			vx[idx] -= (flags[idx - X] & MF_FLUID) ? surfTensHelper(idx - X, +X, phi, curv, surfTens, gfClamp) : 0.f;
+			vy[idx] -= (flags[idx - Y] & MF_FLUID) ? surfTensHelper(idx - Y, +Y, phi, curv, surfTens, gfClamp) : 0.f;
+			if (d.is3d) vz[idx] -= (flags[idx - Z] & MF_FLUID) ? surfTensHelper(idx - Z, +Z, phi, curv, surfTens, gfClamp) : 0.f;
+		}
+	}
+}
+
+// knReplaceClampedGhostFluidVels, plugin/pressure.cpp:198-214.  Writes touch empty cells' components, reads
+// touch fluid cells' components of the same grid: disjoint, so in-place is race free.
+__global__ void __launch_bounds__(BLOCK)
+k_replace_clamped_gf(Dim d, float* __restrict__ vel, const int32_t* __restrict__ flags, const float* __restrict__ phi, float gfClamp) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (!(flags[idx] & MF_EMPTY)) return;
+	const int64_t X = 1, Y = d.Y, Z = d.Z, n = d.n;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+	if ((flags[idx - X] & MF_FLUID) && ghostFluidWasClamped(idx - X, +X, phi, gfClamp)) vx[idx] = vx[idx - X];
+	if ((flags[idx - Y] & MF_FLUID) && ghostFluidWasClamped(idx - Y, +Y, phi, gfClamp)) vy[idx] = vy[idx - Y];
+	if (d.is3d && (flags[idx - Z] & MF_FLUID) && ghostFluidWasClamped(idx - Z, +Z, phi, gfClamp)) vz[idx] = vz[idx - Z];
+	if ((flags[idx + X] & MF_FLUID) && ghostFluidWasClamped(idx + X, -X, phi, gfClamp)) vx[idx] = vx[idx + X];
+	if ((flags[idx + Y] & MF_FLUID) && ghostFluidWasClamped(idx + Y, -Y, phi, gfClamp)) vy[idx] = vy[idx + Y];
+	if (d.is3d && (flags[idx + Z] & MF_FLUID) && ghostFluidWasClamped(idx + Z, -Z, phi, gfClamp)) vz[idx] = vz[idx + Z];
+}
+
+// fixPressure, plugin/pressure.cpp:226-246 (a handful of scalar updates: one thread)
+__global__ void k_fix_pressure(Dim d, int64_t p, float value, float* rhs, float* A0, float* Ai, float* Aj, float* Ak) {
+	const int64_t X = 1, Y = d.Y, Z = d.Z;
+	rhs[p + X] -= Ai[p] * value;
+	rhs[p + Y] -= Aj[p] * value;
+	rhs[p - X] -= Ai[p - X] * value;
+	rhs[p - Y] -= Aj[p - Y] * value;
+	if (d.is3d) {
+		rhs[p + Z] -= Ak[p] * value;
+		rhs[p - Z] -= Ak[p - Z] * value;
+	}
+	rhs[p] = value;
+	A0[p] = 1.f;
+	Ai[p] = Aj[p] = Ak[p] = 0.f;
+	Ai[p - X] = 0.f;
+	Aj[p - Y] = 0.f;
+	if (d.is3d) Ak[p - Z] = 0.f;
+}
+
+// =========================================================================================================
+// MIC(0) preconditioner, conjugategrad.cpp:66-97 (init) and :135-159 (apply).
+//
+// The reference runs these as single-threaded lexicographic sweeps with a (i-1, j-1, k-1) dependency
+// (forward) / (i+1, j+1, k+1) (backward).  Here the grid is cut into 8x8x8 tiles; tiles on one hyperplane
+// ti+tj+tk = L are independent and run as one launch (one 64-lane wave per tile); inside a tile the wave
+// walks the 22 cell hyperplanes, lane = one x-row (lj,lk), neighbour values move by wave shuffles and the
+// per-cell coefficients are staged in LDS.  Per-cell arithmetic is exactly the reference's expression, so the
+// result is bit-identical to the serial sweep.
+//   MODE 0: init   dst := Aprecond,  var1 := A0
+//   MODE 1: forward substitution     dst := tmp, var1 := residual
+//   MODE 2: backward substitution (tile and in-tile coordinates mirrored)
+// =========================================================================================================
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restrict__ flags, float* __restrict__ dst,
+            const float* __restrict__ var1, const float* __restrict__ Ap, const float* __restrict__ Ai,
+            const float* __restrict__ Aj, const float* __restrict__ Ak, const CgScalars* __restrict__ sc) {
+	constexpr bool REV = (MODE == 2);
+	constexpr int NC = (MODE == 0) ? 2 : 1;  // values handed to each neighbour
+	const int tjl = blockIdx.x, tkl = blockIdx.y;
+	const int til = level - tjl - tkl;
+	if (til < 0 || til >= nti) return;
+	if (sc && sc->done) return;
+	const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
+	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
+	const int x0 = ti * 8, j = tj * 8 + lj, k = tk * 8 + lk;
+	const bool row_in = (j < d.sy) && (k < d.sz);
+	const int64_t rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
+	const int back = REV ? 1 : -1;  // physical offset of the logical predecessor
+
+	__shared__ float sV[512], sAi[512], sAj[512], sAk[512], sP[512], sD[512];
+	__shared__ int sF[512];
+	__shared__ float sHj[NC][64], sHk[NC][64];
+
+	// ---- stage my row (logical order a = 0..7 <-> physical li) ----
+#pragma unroll
+	for (int a = 0; a < 8; a++) {
+		const int li = REV ? 7 - a : a;
+		const bool in = row_in && (x0 + li < d.sx);
+		const int64_t idx = rowbase + li;
+		const int fl = in ? (flags[idx] & MF_FLUID) : 0;
+		const int s = lane * 8 + a;
+		sF[s] = in ? (fl ? 1 : 2) : 0;  // 1 fluid, 2 in-domain non-fluid, 0 outside
+		sV[s] = fl ? var1[idx] : 0.f;
+		sAi[s] = in ? Ai[idx] : 0.f;
+		sAj[s] = in ? Aj[idx] : 0.f;
+		sAk[s] = in ? Ak[idx] : 0.f;
+		if (MODE == 0) {
+			sP[s] = 0.f;
+			sD[s] = 0.f;  // Aprecond.clear(): non-fluid cells stay 0
+		} else {
+			sP[s] = in ? Ap[idx] : 0.f;
+			sD[s] = (MODE == 2) ? (in ? dst[idx] : 0.f) : ((in && !fl) ? dst[idx] : 0.f);
+		}
+	}
+
+	// value(s) a finished neighbour cell hands to its logical successor in direction dir (0 i, 1 j, 2 k)
+	auto halo = [&](int64_t nidx, bool in, int dir, float& h0, float& h1) {
+		h0 = 0.f;
+		h1 = 0.f;
+		if (!in) return;
+		const float ai = Ai[nidx], aj = Aj[nidx], ak = Ak[nidx];
+		const float adir = dir == 0 ? ai : (dir == 1 ? aj : ak);
+		if (MODE == 1) {
+			h0 = (dst[nidx] * adir) * Ap[nidx];
+		} else if (MODE == 2) {
+			h0 = dst[nidx];
+		} else {
+			const float ap = dst[nidx];  // Aprecond being built
+			const float o = dir == 0 ? (aj + ak) : (dir == 1 ? (ai + ak) : (ai + aj));
+			const float t = adir * ap;
+			h0 = t * t;
+			h1 = adir * o * (ap * ap);
+		}
+	};
+	// i-halo: one cell per lane
+	float hi0, hi1;
+	{
+		const int gi = x0 + (REV ? 8 : -1);
+		halo(rowbase + (REV ? 8 : -1), row_in && gi >= 0 && gi < d.sx, 0, hi0, hi1);
+	}
+	// j-halo: rows of the lanes with b == 0 ; k-halo: rows of the lanes with c == 0
+	if (b == 0) {
+		const int jn = j + back;
+		const bool rin = (jn >= 0) && (jn < d.sy) && (k < d.sz);
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			const int li = REV ? 7 - a : a;
+			float h0, h1;
+			halo(rowbase + (int64_t)back * d.Y + li, rin && (x0 + li < d.sx), 1, h0, h1);
+			sHj[0][c * 8 + a] = h0;
+			if (NC == 2) sHj[NC - 1][c * 8 + a] = h1;
+		}
+	}
+	if (c == 0) {
+		const int kn = k + back;
+		const bool rin = (kn >= 0) && (kn < d.sz) && (j < d.sy);
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			const int li = REV ? 7 - a : a;
+			float h0, h1;
+			halo(rowbase + (int64_t)back * d.Z + li, rin && (x0 + li < d.sx), 2, h0, h1);
+			sHk[0][b * 8 + a] = h0;
+			if (NC == 2) sHk[NC - 1][b * 8 + a] = h1;
+		}
+	}
+	__syncthreads();
+
+	// ---- 22 cell hyperplanes ----
+	float oi0 = 0.f, oi1 = 0.f, oj0 = 0.f, oj1 = 0.f, ok0 = 0.f, ok1 = 0.f;
+#pragma unroll 2
+	for (int h = 0; h < 22; h++) {
+		const int a = h - b - c;
+		const bool valid = (a >= 0) && (a < 8);
+		const int ac = a < 0 ? 0 : (a > 7 ? 7 : a);
+		float ij0 = __shfl_up(oj0, 1, 64), ik0 = __shfl_up(ok0, 8, 64);
+		float ij1 = 0.f, ik1 = 0.f;
+		if (NC == 2) {
+			ij1 = __shfl_up(oj1, 1, 64);
+			ik1 = __shfl_up(ok1, 8, 64);
+		}
+		if (b == 0) {
+			ij0 = sHj[0][c * 8 + ac];
+			if (NC == 2) ij1 = sHj[NC - 1][c * 8 + ac];
+		}
+		if (c == 0) {
+			ik0 = sHk[0][b * 8 + ac];
+			if (NC == 2) ik1 = sHk[NC - 1][b * 8 + ac];
+		}
+		const float ii0 = (a == 0) ? hi0 : oi0;
+		const float ii1 = (a == 0) ? hi1 : oi1;
+		if (valid) {
+			const int s = lane * 8 + ac;
+			const int fl = sF[s];
+			const float ai = sAi[s], aj = sAj[s], ak = sAk[s];
+			if (MODE == 0) {
+				float ap = 0.f;
+				if (fl == 1) {
+					const float a0 = sV[s];
+					float e = a0 - ii0 - ij0 - ik0;
+					const float s3 = ii1 + ij1 + ik1;
+					// e -= tau * ( ... + 0. ): fp64 product and subtraction, conjugategrad.cpp:84-88
+					const float tau = 0.97f;
+					e = (float)((double)e - (double)tau * ((double)s3 + 0.));
+					if (e < 0.25f * a0) e = a0;
+					ap = (float)(1. / (double)sqrtf(e));
+				}
+				sD[s] = ap;
+				const float ti_ = ai * ap, tj_ = aj * ap, tk_ = ak * ap;
+				const float ap2 = ap * ap;
+				oi0 = ti_ * ti_;
+				oj0 = tj_ * tj_;
+				ok0 = tk_ * tk_;
+				oi1 = ai * (aj + ak) * ap2;
+				oj1 = aj * (ai + ak) * ap2;
+				ok1 = ak * (ai + aj) * ap2;
+			} else if (MODE == 1) {
+				const float p = sP[s];
+				float val = sD[s];
+				if (fl == 1) {
+					val = p * (sV[s] - ii0 - ij0 - ik0);
+					sD[s] = val;
+				}
+				oi0 = (val * ai) * p;
+				oj0 = (val * aj) * p;
+				ok0 = (val * ak) * p;
+			} else {
+				const float p = sP[s];
+				float val = sD[s];
+				if (fl == 1) {
+					val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+					sD[s] = val;
+				}
+				oi0 = oj0 = ok0 = val;
+			}
+		}
+	}
+	__syncthreads();
+	// ---- write back my row ----
+#pragma unroll
+	for (int a = 0; a < 8; a++) {
+		const int li = REV ? 7 - a : a;
+		const int s = lane * 8 + a;
+		if (sF[s] == 1) dst[rowbase + li] = sD[s];
+	}
+}
+
+template <int MODE>
+static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+                      const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
+	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
+	const int levels = nti + ntj + ntk - 2;
+	for (int L = 0; L < levels; L++)
+		hipLaunchKernelGGL((k_mic_tiles<MODE>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+// =========================================================================================================
+// PCG scalar kernels (one block) -- scalars never leave the device inside an iteration
+// =========================================================================================================
+__global__ void __launch_bounds__(BLOCK) k_cg_begin(CgScalars* sc, int nb, const double* __restrict__ partials, float accuracy, int useL2) {
+	double acc = 0.0;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partials[i];
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) {
+		sc->sigma = (float)acc;  // mSigma = GridDotProduct(mTmp, mResidual), conjugategrad.cpp:234
+		sc->alpha = sc->nalpha = sc->beta = 0.f;
+		sc->resNorm = 1e20f;
+		sc->accuracy = accuracy;
+		sc->iterations = 0;
+		sc->done = 0;
+		sc->diverged = 0;
+		sc->useL2 = useL2;
+	}
+}
+// alpha = sigma / dp, conjugategrad.cpp:250-252
+__global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const double* __restrict__ partials) {
+	if (sc->done) return;
+	double acc = 0.0;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partials[i];
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) {
+		const float dp = (float)acc;
+		float alpha = 0.f;
+		if (fabs((double)dp) > 0.) alpha = sc->sigma / dp;
+		sc->dp = dp;
+		sc->alpha = alpha;
+		sc->nalpha = -alpha;
+		sc->iterations++;
+	}
+}
+// dst += alpha*search ; residual += (-alpha)*tmp ; [PC_NONE: tmp = residual] ; partial min/max (or sum of
+// squares) of the new residual.  conjugategrad.cpp:254-255, 265, 268-272
+template <bool COPY_TMP>
+__global__ void __launch_bounds__(BLOCK)
+k_cg_axpy2(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, const float* __restrict__ search,
+           float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart, double* __restrict__ dpart) {
+	if (sc->done) return;
+	const float alpha = sc->alpha, nalpha = sc->nalpha;
+	const bool l2 = sc->useL2 != 0;
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	double ss = 0.0;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		float4 x = ((float4*)dst)[q];
+		const float4 s = ((const float4*)search)[q];
+		float4 r = ((float4*)residual)[q];
+		const float4 t = ((const float4*)tmp)[q];
+		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
+		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
+		((float4*)dst)[q] = x;
+		((float4*)residual)[q] = r;
+		if (COPY_TMP) ((float4*)tmp)[q] = r;
+		if (l2) {
+			ss += (double)r.x * (double)r.x;
+			ss += (double)r.y * (double)r.y;
+			ss += (double)r.z * (double)r.z;
+			ss += (double)r.w * (double)r.w;
+		} else {
+			lo = fminf(fminf(lo, r.x), fminf(r.y, fminf(r.z, r.w)));
+			hi = fmaxf(fmaxf(hi, r.x), fmaxf(r.y, fmaxf(r.z, r.w)));
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		dst[i] = dst[i] + alpha * search[i];
+		const float r = residual[i] + nalpha * tmp[i];
+		residual[i] = r;
+		if (COPY_TMP) tmp[i] = r;
+		if (l2) ss += (double)r * (double)r;
+		lo = fminf(lo, r);
+		hi = fmaxf(hi, r);
+	}
+	if (l2) {
+		ss = block_sum(ss);
+		if (threadIdx.x == 0) dpart[blockIdx.x] = ss;
+	} else {
+		block_minmax(lo, hi);
+		if (threadIdx.x == 0) {
+			fpart[2 * blockIdx.x] = lo;
+			fpart[2 * blockIdx.x + 1] = hi;
+		}
+	}
+}
+// sigmaNew partials: GridDotProduct(tmp, residual), conjugategrad.cpp:279
+__global__ void __launch_bounds__(BLOCK)
+k_cg_dot(int64_t n, const CgScalars* __restrict__ sc, const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ partials) {
+	if (sc->done) return;
+	double acc = 0.0;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		const float4 x = ((const float4*)a)[q], y = ((const float4*)b)[q];
+		const float p0 = x.x * y.x, p1 = x.y * y.y, p2 = x.z * y.z, p3 = x.w * y.w;
+		acc += (double)p0;
+		acc += (double)p1;
+		acc += (double)p2;
+		acc += (double)p3;
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		const float p = a[i] * b[i];
+		acc += (double)p;
+	}
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+// residual norm, convergence test, beta.  conjugategrad.cpp:268-295
+__global__ void __launch_bounds__(BLOCK)
+k_cg_beta(CgScalars* sc, int nbr, const float* __restrict__ fpart, const double* __restrict__ dpart_res, int nbd,
+          const double* __restrict__ dpart_dot) {
+	if (sc->done) return;
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	double ss = 0.0, dd = 0.0;
+	const bool l2 = sc->useL2 != 0;
+	for (int i = threadIdx.x; i < nbr; i += blockDim.x) {
+		if (l2)
+			ss += dpart_res[i];
+		else {
+			lo = fminf(lo, fpart[2 * i]);
+			hi = fmaxf(hi, fpart[2 * i + 1]);
+		}
+	}
+	for (int i = threadIdx.x; i < nbd; i += blockDim.x) dd += dpart_dot[i];
+	block_minmax(lo, hi);
+	__syncthreads();
+	ss = block_sum(ss);
+	__syncthreads();
+	dd = block_sum(dd);
+	if (threadIdx.x == 0) {
+		float resNorm;
+		if (l2)
+			resNorm = (float)ss;
+		else {
+			const float alo = fabsf(lo), ahi = fabsf(hi);
+			resNorm = alo > ahi ? alo : ahi;
+		}
+		sc->resNorm = resNorm;
+		if (resNorm < sc->accuracy) {
+			sc->sigma = resNorm;
+			sc->done = 1;
+		} else {
+			const float sigmaNew = (float)dd;
+			sc->beta = sigmaNew / sc->sigma;
+			sc->sigmaNew = sigmaNew;
+			sc->sigma = sigmaNew;
+			if (!((double)resNorm < 1e35)) {
+				sc->diverged = 1;  // the host finishes this iteration's search update, then reports
+			}
+		}
+	}
+}
+// search = tmp + beta*search, conjugategrad.cpp:193-196, 283
+__global__ void __launch_bounds__(BLOCK)
+k_cg_update_search(int64_t n, CgScalars* __restrict__ sc, float* __restrict__ search, const float* __restrict__ tmp) {
+	if (sc->done) return;
+	const float beta = sc->beta;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		float4 s = ((float4*)search)[q];
+		const float4 t = ((const float4*)tmp)[q];
+		s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
+		((float4*)search)[q] = s;
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		search[i] = tmp[i] + beta * search[i];
+	}
+}
+__global__ void k_cg_latch_diverged(CgScalars* sc) {
+	if (sc->diverged) sc->done = 1;
+}
+
+extern "C" {
+
+int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                    const float* Ai, const float* Aj, const float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	return launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, (hipStream_t)stream, nullptr);
+}
+
+int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                         const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	hipEvent_t e0, e1;
+	MF_HIP(hipEventCreate(&e0));
+	MF_HIP(hipEventCreate(&e1));
+	for (int i = 0; i < 3; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr));
+	MF_HIP(hipEventRecord(e0, st));
+	for (int i = 0; i < reps; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr));
+	MF_HIP(hipEventRecord(e1, st));
+	MF_HIP(hipEventSynchronize(e1));
+	float ms = 0.f;
+	MF_HIP(hipEventElapsedTime(&ms, e0, e1));
+	*avg_us = (double)ms * 1000.0 / (reps > 0 ? reps : 1);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return 0;
+}
+
+int mf_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak,
+                           const float* fractions, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_make_laplace, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, A0, Ai, Aj, Ak, fractions);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_make_rhs(int sx, int sy, int sz, const int32_t* flags, float* rhs, const float* vel, const float* perCellCorr,
+                const float* fractions, const float* obvel, const float* phi, const float* curv, float surfTens,
+                float gfClamp, int32_t* cnt_host, double* sum_host, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	hipStream_t st = (hipStream_t)stream;
+	const int nb = blocks_for(d.n, BLOCK, 2048);
+	hipLaunchKernelGGL(k_make_rhs, dim3(nb), dim3(BLOCK), 0, st, d, flags, rhs, vel, perCellCorr, fractions, obvel, phi, curv, surfTens, gfClamp, ws->partials);
+	hipLaunchKernelGGL(k_sum2_finish, dim3(1), dim3(BLOCK), 0, st, nb, ws->partials, ws->partials + MAX_BLOCKS, (double*)ws->scalars);
+	MF_LAUNCH_CHECK();
+	if (cnt_host || sum_host) {
+		MF_HIP(hipMemcpyAsync(ws->host, ws->scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipStreamSynchronize(st));
+		const double* h = (const double*)ws->host;
+		if (sum_host) *sum_host = h[0];
+		if (cnt_host) *cnt_host = (int32_t)h[1];
+	}
+	return 0;
+}
+
+int mf_apply_ghost_fluid_diagonal(int sx, int sy, int sz, float* A0, const int32_t* flags, const float* phi, float gfClamp, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_ghost_fluid_diag, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d, A0, flags, phi, gfClamp);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_correct_velocity(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* pressure, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_correct_velocity, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, vel, pressure);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_correct_velocity_ghost_fluid(int sx, int sy, int sz, float* vel, const int32_t* flags, const float* pressure,
+                                    const float* phi, float gfClamp, const float* curv, float surfTens, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_correct_velocity_gf, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, flags, pressure, phi, gfClamp, curv, surfTens);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_replace_clamped_ghost_fluid_vels(int sx, int sy, int sz, float* vel, const int32_t* flags, const float* pressure,
+                                        const float* phi, float gfClamp, void* stream) {
+	(void)pressure;
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_replace_clamped_gf, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, flags, phi, gfClamp);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float* rhs, float* A0, float* Ai, float* Aj, float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (fixPidx - d.Y < 0 || fixPidx + d.Y >= d.n || fixPidx - d.Z < 0 || fixPidx + d.Z >= d.n) return fail("fixPressure: cell %lld on the domain border", (long long)fixPidx);
+	hipLaunchKernelGGL(k_fix_pressure, dim3(1), dim3(1), 0, (hipStream_t)stream, d, fixPidx, value, rhs, A0, Ai, Aj, Ak);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0, const float* Ai,
+                const float* Aj, const float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, (hipStream_t)stream));
+	return launch_mic<0>(d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
+}
+int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
+                 const float* Ai, const float* Aj, const float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	MF_TRY(launch_mic<1>(d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream));
+	return launch_mic<2>(d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
+}
+
+int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual, float* search,
+                float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak, float* Aprecond, int pc,
+                float accuracy, int maxIter, int useL2Norm, float* out_host, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	hipStream_t st = (hipStream_t)stream;
+	if (pc != MF_PC_NONE && pc != MF_PC_MICP) return fail("GridCg<APPLYMAT>::setICPreconditioner: Invalid method specified.");
+	if (pc == MF_PC_MICP && !d.is3d) pc = MF_PC_NONE;  // conjugategrad.cpp:315-321
+	if (!(al16(dst) && al16(rhs) && al16(residual) && al16(search) && al16(tmp))) return fail("mf_cg_solve: work grids must be 16-byte aligned");
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	CgScalars* sc = (CgScalars*)ws->scalars;
+	double* p_dot = ws->partials;                   // apply-matrix / sigma dot partials
+	double* p_res = ws->partials + MAX_BLOCKS;      // sum-of-squares partials of the residual
+	double* p_sig = ws->partials + 2 * MAX_BLOCKS;  // dot(tmp, residual) partials
+	float* p_mm = ws->fpartials;
+	const int nbs = blocks_for(n >> 2, BLOCK, 2048);
+
+	// ---- doInit, conjugategrad.cpp:210-235 ----
+	MF_HIP(hipMemsetAsync(dst, 0, sizeof(float) * n, st));
+	MF_HIP(hipMemcpyAsync(residual, rhs, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+	if (pc == MF_PC_MICP) {
+		MF_TRY(mf_mic_init(sx, sy, sz, flags, Aprecond, A0, Ai, Aj, Ak, stream));
+		MF_TRY(mf_mic_apply(sx, sy, sz, flags, tmp, residual, Aprecond, Ai, Aj, Ak, stream));
+	} else {
+		MF_HIP(hipMemcpyAsync(tmp, residual, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+	}
+	MF_HIP(hipMemcpyAsync(search, tmp, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+	MF_HIP(hipMemsetAsync(sc, 0, sizeof(CgScalars), st));
+	hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
+	hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_sig, accuracy, useL2Norm);
+	MF_LAUNCH_CHECK();
+
+	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done` ----
+	const int batch = (pc == MF_PC_MICP) ? 1 : 4;
+	CgScalars h;
+	memset(&h, 0, sizeof h);
+	h.resNorm = 1e20f;
+	int issued = 0;
+	while (issued < maxIter) {
+		const int todo = (maxIter - issued < batch) ? (maxIter - issued) : batch;
+		for (int it = 0; it < todo; it++) {
+			int nba = 0;
+			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba));
+			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
+			if (pc == MF_PC_MICP) {
+				hipLaunchKernelGGL((k_cg_axpy2<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
+				MF_TRY(launch_mic<1>(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
+				MF_TRY(launch_mic<2>(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
+			} else {
+				hipLaunchKernelGGL((k_cg_axpy2<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
+			}
+			hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
+			hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nbs, p_sig);
+			hipLaunchKernelGGL(k_cg_update_search, dim3(nbs), dim3(BLOCK), 0, st, n, sc, search, tmp);
+			hipLaunchKernelGGL(k_cg_latch_diverged, dim3(1), dim3(1), 0, st, sc);
+		}
+		MF_LAUNCH_CHECK();
+		issued += todo;
+		MF_HIP(hipMemcpyAsync(ws->host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipStreamSynchronize(st));
+		memcpy(&h, ws->host, sizeof h);
+		if (h.done) break;
+	}
+	if (maxIter <= 0) {
+		MF_HIP(hipMemcpyAsync(ws->host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipStreamSynchronize(st));
+		memcpy(&h, ws->host, sizeof h);
+	}
+	out_host[0] = (float)h.iterations;
+	out_host[1] = h.resNorm;
+	out_host[2] = h.sigma;
+	if (h.diverged) return fail("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.");
+	return 0;
+}
+
+}  // extern "C"

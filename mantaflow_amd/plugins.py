@@ -1,0 +1,375 @@
+"""Python-callable operators ("plugins") of the hot path, same names / parameter order / defaults as the reference's
+PYTHON() declarations; orchestration mirrors the reference function by function, arithmetic happens in the C ABI.
+
+  advectSemiLagrange                         source/plugin/advection.cpp:443-461
+  computePressureRhs / solvePressureSystem / correctVelocity / solvePressure   source/plugin/pressure.cpp:277-523
+  mapPartsToMAC / mapMACToParts / flipVelocityUpdate / mapPartsToGrid(+Vec3) / mapGridToParts(+Vec3)
+                                             source/plugin/flip.cpp:637-742
+  setWallBcs / addBuoyancy / addGravity      source/plugin/extforces.cpp (SURVEY 8f-1 glue)
+"""
+import ctypes
+import functools
+import time
+
+import numpy as np
+import torch
+
+from . import core
+from .core import (FlagGrid, Grid, GridBase, LevelsetGrid, MACGrid, VecGrid, _ptr, _to_vec3, vec3)
+
+PcNone, PcMIC, PcMGDynamic, PcMGStatic = 0, 1, 2, 3
+IntEuler, IntRK2, IntRK4 = 0, 1, 2
+
+_UNIVERSAL = ("notiming", "parent", "name", "nocheck", "solver")   # codegen_python.cpp:37, pconvert.cpp:461,477
+_timings = {}
+_last_cg = {}
+
+
+def plugin(fn):
+    """Wrapper every PYTHON() symbol gets in the reference (codegen_python.cpp:32-58): universal kwargs, per-plugin
+    wall timer (pclass.cpp:36-41), unknown arguments -> RuntimeError (pconvert.cpp:460-474)."""
+    @functools.wraps(fn)
+    def w(*args, **kw):
+        notiming = kw.pop("notiming", False)
+        for k in _UNIVERSAL[1:]:
+            kw.pop(k, None)
+        t0 = time.time()
+        try:
+            r = fn(*args, **kw)
+        except TypeError as e:
+            msg = str(e)
+            if "unexpected keyword argument" in msg:
+                raise RuntimeError("Argument %s unknown" % msg.split("argument")[-1].strip())
+            raise RuntimeError(msg)
+        if not notiming:
+            rec = _timings.setdefault(fn.__name__, [0, 0.0])
+            rec[0] += 1
+            rec[1] += time.time() - t0
+        return r
+    return w
+
+
+class Timings(object):
+    """TimingData, timing.{h,cpp}: per-plugin wall time (host clock; kernels are asynchronous on the stream)."""
+    def display(self):
+        for k, (n, t) in sorted(_timings.items(), key=lambda kv: -kv[1][1]):
+            print("[%8.3fs] %s (%d calls)" % (t, k, n))
+    def saveMean(self, filename):
+        with open(filename, "w") as f:
+            for k, (n, t) in _timings.items():
+                f.write("%s: %f\n" % (k, t / max(n, 1)))
+    def step(self): pass
+
+
+def _chk(obj, cls, what):
+    if not isinstance(obj, cls):
+        raise RuntimeError("can't convert argument to %s*" % what)
+    return obj
+
+
+def _opt(obj, cls, what):
+    if obj is None or (isinstance(obj, int) and obj == 0):   # None or int 0 is NULL (pclass.cpp:128-134)
+        return None
+    return _chk(obj, cls, what)
+
+
+# =========================================================================================================
+# advection
+# =========================================================================================================
+@plugin
+def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, openBounds=False, boundaryWidth=-1,
+                       clampMode=2, orderTrace=1):
+    _chk(flags, FlagGrid, "FlagGrid")
+    _chk(vel, MACGrid, "MACGrid")
+    _chk(grid, GridBase, "GridBase")
+    if order not in (1, 2):
+        raise RuntimeError("AdvectSemiLagrange: Only order 1 (regular SL) and 2 (MacCormack) supported")
+    if orderSpace != 1:
+        raise RuntimeError("advectSemiLagrange: orderSpace=2 (cubic interpolation, util/interpolHigh.h) is outside the "
+                           "MI355X hot path (SURVEY 2.4)")
+    s = flags.parent
+    lib, st = s.lib, s.stream
+    sx, sy, sz = flags.dims
+    dt = s.getDt()
+    t = grid.getType()
+    if t & GridBase.TypeMAC:
+        # fnAdvectSemiLagrange<MACGrid>, advection.cpp:407-437
+        fwd = MACGrid(s)
+        lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), st)
+        if order == 1:
+            _apply_outflow_bc(flags, fwd, grid, dt)
+            grid.swap(fwd)
+        else:
+            bwd, newg = MACGrid(s), MACGrid(s)
+            lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), st)
+            lib.call("mf_maccormack_correct_mac", sx, sy, sz, flags.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength), st)
+            lib.call("mf_maccormack_clamp_mac", sx, sy, sz, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, dt, int(clampMode), st)
+            _apply_outflow_bc(flags, newg, grid, dt)
+            grid.swap(newg)
+    elif t & (GridBase.TypeReal | GridBase.TypeVec3):
+        # fnAdvectSemiLagrange<GridType>, advection.cpp:293-322
+        ncomp = 1 if (t & GridBase.TypeReal) else 3
+        G = type(grid)
+        sl = "mf_semi_lagrange_real" if ncomp == 1 else "mf_semi_lagrange_vec3"
+        fwd = G(s)
+        lib.call(sl, sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), st)
+        if order == 1:
+            grid.swap(fwd)
+        else:
+            bwd, newg = G(s), G(s)
+            lib.call(sl, sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), st)
+            lib.call("mf_maccormack_correct", sx, sy, sz, ncomp, flags.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength), st)
+            lib.call("mf_maccormack_clamp", sx, sy, sz, ncomp, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, dt, int(clampMode), st)
+            grid.swap(newg)
+    else:
+        raise RuntimeError("AdvectSemiLagrange: Grid Type is not supported (only Real, Vec3, MAC, Levelset)")
+
+
+def _apply_outflow_bc(flags, vel, velPrev, dt):
+    """applyOutflowBC, advection.cpp:388-392 (temp MAC grid so vel is not overwritten while it is read)"""
+    s = flags.parent
+    if not getattr(flags, "_may_have_outflow", True):
+        return
+    velDst = MACGrid(s)
+    s.lib.call("mf_apply_outflow_bc", flags.sx, flags.sy, flags.sz, flags.ptr, vel.ptr, velPrev.ptr, velDst.ptr, float(dt), s.stream)
+
+
+# =========================================================================================================
+# pressure projection
+# =========================================================================================================
+@plugin
+def computePressureRhs(rhs, vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=None, fractions=None, obvel=None,
+                       gfClamp=1e-04, cgMaxIterFac=1.5, precondition=True, preconditioner=PcMIC,
+                       enforceCompatibility=False, useL2Norm=False, zeroPressureFixing=False, curv=None, surfTens=0.):
+    _chk(rhs, Grid, "Grid<Real>"); _chk(vel, MACGrid, "MACGrid"); _chk(flags, FlagGrid, "FlagGrid")
+    phi, perCellCorr, curv = _opt(phi, Grid, "Grid<Real>"), _opt(perCellCorr, Grid, "Grid<Real>"), _opt(curv, Grid, "Grid<Real>")
+    fractions, obvel = _opt(fractions, MACGrid, "MACGrid"), _opt(obvel, MACGrid, "MACGrid")
+    s = flags.parent
+    cnt, sm = ctypes.c_int32(0), ctypes.c_double(0.0)
+    need = bool(enforceCompatibility)
+    s.lib.call("mf_make_rhs", flags.sx, flags.sy, flags.sz, flags.ptr, rhs.ptr, vel.ptr,
+               None if perCellCorr is None else perCellCorr.ptr, None if fractions is None else fractions.ptr,
+               None if obvel is None else obvel.ptr, None if phi is None else phi.ptr, None if curv is None else curv.ptr,
+               float(surfTens), float(gfClamp), ctypes.byref(cnt) if need else None, ctypes.byref(sm) if need else None, s.stream)
+    if enforceCompatibility:
+        # rhs += (Real)(-kernMakeRhs.sum / (Real)kernMakeRhs.cnt), pressure.cpp:297-298
+        corr = np.float32(-sm.value / float(np.float32(cnt.value)))
+        rhs.addConst(float(corr))
+
+
+@plugin
+def solvePressureSystem(rhs, vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=None, fractions=None, gfClamp=1e-04,
+                        cgMaxIterFac=1.5, precondition=True, preconditioner=PcMIC, enforceCompatibility=False,
+                        useL2Norm=False, zeroPressureFixing=False, curv=None, surfTens=0.):
+    _chk(rhs, Grid, "Grid<Real>"); _chk(vel, MACGrid, "MACGrid"); _chk(pressure, Grid, "Grid<Real>"); _chk(flags, FlagGrid, "FlagGrid")
+    phi = _opt(phi, Grid, "Grid<Real>")
+    fractions = _opt(fractions, MACGrid, "MACGrid")
+    if precondition is False:
+        preconditioner = PcNone
+    s = flags.parent
+    lib, st = s.lib, s.stream
+    sx, sy, sz = flags.dims
+    # reserve temp grids, pressure.cpp:332-338
+    residual, search, A0, Ai, Aj, Ak, tmp = (Grid(s) for _ in range(7))
+    lib.call("mf_make_laplace_matrix", sx, sy, sz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr,
+             None if fractions is None else fractions.ptr, st)
+    if phi is not None:
+        lib.call("mf_apply_ghost_fluid_diagonal", sx, sy, sz, A0.ptr, flags.ptr, phi.ptr, float(gfClamp), st)
+    if zeroPressureFixing or cgAccuracy < 1e-07:
+        _fix_pressure(flags, rhs, A0, Ai, Aj, Ak)
+    if preconditioner in (PcNone, PcMIC):
+        gmax = max(sx, sy, sz)
+        maxIter = int(np.float32(cgMaxIterFac) * np.float32(gmax)) * (1 if flags.is3D() else 4)   # pressure.cpp:410
+        pca0 = Grid(s)
+        pca1, pca2, pca3 = Grid(s), Grid(s), Grid(s)   # allocated (and zeroed) by the reference as well, :412-415
+        if preconditioner == PcNone:
+            # setICPreconditioner(PC_None, ...) asserts in the reference (conjugategrad.cpp:312); keep the behaviour
+            raise RuntimeError("GridCg<APPLYMAT>::setICPreconditioner: Invalid method specified.")
+        pc = 2   # PC_mICP ; 2-D degrades to PC_None inside the solver (conjugategrad.cpp:315-321)
+    elif preconditioner in (PcMGDynamic, PcMGStatic):
+        raise RuntimeError("solvePressure: multigrid preconditioners (source/multigrid.cpp) are outside the MI355X hot path")
+    else:
+        maxIter, pc, pca0 = 0, 0, Grid(s)
+    out = (ctypes.c_float * 3)()
+    lib.call("mf_cg_solve", sx, sy, sz, flags.ptr, pressure.ptr, rhs.ptr, residual.ptr, search.ptr, tmp.ptr,
+             A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, pca0.ptr, pc, float(cgAccuracy), int(maxIter), int(bool(useL2Norm)), out, st)
+    _last_cg["iterations"], _last_cg["residual"] = int(out[0]), float(out[1])
+
+
+def _fix_pressure(flags, rhs, A0, Ai, Aj, Ak):
+    """zero-pressure fixing, pressure.cpp:349-390"""
+    s = flags.parent
+    ne = ctypes.c_int32(0)
+    s.lib.call("mf_count_empty_cells", flags.n, flags.ptr, ctypes.byref(ne), s.stream)
+    if ne.value != 0:
+        return
+    sx, sy, sz = flags.dims
+    f = flags.data.view(sz, sy, sx)
+    top = (sx // 2, sy - 1, sz // 2 if flags.is3D() else 0)
+    fix = -1
+    for dy in (0, 1, 2):
+        i, j, k = top[0], top[1] - dy, top[2]
+        if int(f[k, j, i].item()) & core.TypeFluid:
+            fix = i + sx * (j + sy * k)
+            break
+    if fix == -1:
+        inner = f[(slice(1, -1) if flags.is3D() else slice(None)), 1:-1, 1:-1]
+        nz = torch.nonzero((inner & core.TypeFluid) != 0)
+        if nz.numel():
+            k, j, i = (int(v) for v in nz[0])
+            k = k + 1 if flags.is3D() else 0
+            fix = (i + 1) + sx * ((j + 1) + sy * k)
+    if fix >= 0:
+        s.lib.call("mf_fix_pressure", sx, sy, sz, int(fix), 0.0, rhs.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+
+
+@plugin
+def correctVelocity(vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=None, fractions=None, gfClamp=1e-04,
+                    cgMaxIterFac=1.5, precondition=True, preconditioner=PcMIC, enforceCompatibility=False, useL2Norm=False,
+                    zeroPressureFixing=False, curv=None, surfTens=0.):
+    _chk(vel, MACGrid, "MACGrid"); _chk(pressure, Grid, "Grid<Real>"); _chk(flags, FlagGrid, "FlagGrid")
+    phi, curv = _opt(phi, Grid, "Grid<Real>"), _opt(curv, Grid, "Grid<Real>")
+    s = flags.parent
+    sx, sy, sz = flags.dims
+    s.lib.call("mf_correct_velocity", sx, sy, sz, flags.ptr, vel.ptr, pressure.ptr, s.stream)
+    if phi is not None:
+        s.lib.call("mf_correct_velocity_ghost_fluid", sx, sy, sz, vel.ptr, flags.ptr, pressure.ptr, phi.ptr, float(gfClamp),
+                   None if curv is None else curv.ptr, float(surfTens), s.stream)
+        s.lib.call("mf_replace_clamped_ghost_fluid_vels", sx, sy, sz, vel.ptr, flags.ptr, pressure.ptr, phi.ptr, float(gfClamp), s.stream)
+
+
+@plugin
+def solvePressure(vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=None, fractions=None, obvel=None, gfClamp=1e-04,
+                  cgMaxIterFac=1.5, precondition=True, preconditioner=PcMIC, enforceCompatibility=False, useL2Norm=False,
+                  zeroPressureFixing=False, curv=None, surfTens=0., retRhs=None):
+    _chk(vel, MACGrid, "MACGrid")
+    rhs = Grid(vel.parent)
+    common = dict(cgAccuracy=cgAccuracy, phi=phi, perCellCorr=perCellCorr, fractions=fractions, gfClamp=gfClamp,
+                  cgMaxIterFac=cgMaxIterFac, precondition=precondition, preconditioner=preconditioner,
+                  enforceCompatibility=enforceCompatibility, useL2Norm=useL2Norm, zeroPressureFixing=zeroPressureFixing,
+                  curv=curv, surfTens=surfTens, notiming=True)
+    computePressureRhs(rhs, vel, pressure, flags, obvel=obvel, **common)
+    solvePressureSystem(rhs, vel, pressure, flags, **common)
+    correctVelocity(vel, pressure, flags, **common)
+    if retRhs is not None and not (isinstance(retRhs, int) and retRhs == 0):
+        _chk(retRhs, Grid, "Grid<Real>").copyFrom(rhs)
+
+
+def lastCgStats():
+    """iterations / residual of the most recent solvePressureSystem (the reference prints them at debug level 2,
+    pressure.cpp:442)"""
+    return dict(_last_cg)
+
+
+# =========================================================================================================
+# FLIP transfers
+# =========================================================================================================
+_deterministic_p2g = False
+
+
+def setDeterministicP2G(on):
+    """parity switch: particle->grid sums in particle-index order (bit-identical to the reference's single-threaded
+    scatter, flip.cpp:619) instead of fp32 atomics"""
+    global _deterministic_p2g
+    _deterministic_p2g = bool(on)
+
+
+def _pargs(parts, ptype):
+    return (parts.np, parts.cap, _ptr(parts.pos), _ptr(parts.flag)), (None if ptype is None else ptype.ptr)
+
+
+@plugin
+def mapPartsToMAC(flags, vel, velOld, parts, partVel, weight=None, ptype=None, exclude=0):
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(vel, MACGrid, "MACGrid"); _chk(velOld, MACGrid, "MACGrid")
+    weight = _opt(weight, VecGrid, "Grid<Vec3>")
+    s = flags.parent
+    w = weight if weight is not None else VecGrid(s)
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_map_parts_to_mac", flags.sx, flags.sy, flags.sz, vel.ptr, velOld.ptr, w.ptr, np_, cap, pos, pfl,
+               partVel.ptr, pt, int(exclude), int(_deterministic_p2g), s.stream)
+
+
+@plugin
+def mapMACToParts(flags, vel, parts, partVel, ptype=None, exclude=0):
+    s = flags.parent
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_map_mac_to_parts", flags.sx, flags.sy, flags.sz, vel.ptr, np_, cap, pos, pfl, partVel.ptr, pt, int(exclude), s.stream)
+
+
+@plugin
+def flipVelocityUpdate(flags, vel, velOld, parts, partVel, flipRatio, ptype=None, exclude=0):
+    s = flags.parent
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_flip_velocity_update", flags.sx, flags.sy, flags.sz, vel.ptr, velOld.ptr, np_, cap, pos, pfl,
+               partVel.ptr, float(flipRatio), pt, int(exclude), s.stream)
+
+
+def _map_parts_to_grid(flags, target, parts, source, ncomp):
+    s = flags.parent
+    tmp = Grid(s)
+    (np_, cap, pos, pfl), _ = _pargs(parts, None)
+    s.lib.call("mf_map_parts_to_grid", flags.sx, flags.sy, flags.sz, ncomp, target.ptr, tmp.ptr, np_, cap, pos, pfl,
+               source.ptr, int(_deterministic_p2g), s.stream)
+
+
+@plugin
+def mapPartsToGrid(flags, target, parts, source): _map_parts_to_grid(flags, _chk(target, Grid, "Grid<Real>"), parts, source, 1)
+
+
+@plugin
+def mapPartsToGridVec3(flags, target, parts, source): _map_parts_to_grid(flags, _chk(target, VecGrid, "Grid<Vec3>"), parts, source, 3)
+
+
+@plugin
+def mapGridToParts(source, parts, target):
+    s = source.parent
+    (np_, cap, pos, pfl), _ = _pargs(parts, None)
+    s.lib.call("mf_map_grid_to_parts", source.sx, source.sy, source.sz, 1, source.ptr, np_, cap, pos, pfl, target.ptr, s.stream)
+
+
+@plugin
+def mapGridToPartsVec3(source, parts, target):
+    s = source.parent
+    (np_, cap, pos, pfl), _ = _pargs(parts, None)
+    s.lib.call("mf_map_grid_to_parts", source.sx, source.sy, source.sz, 3, source.ptr, np_, cap, pos, pfl, target.ptr, s.stream)
+
+
+# =========================================================================================================
+# glue
+# =========================================================================================================
+@plugin
+def setWallBcs(flags, vel, obvel=None, fractions=None, phiObs=None, boundaryWidth=0):
+    obvel = _opt(obvel, MACGrid, "MACGrid")
+    if phiObs is not None and fractions is not None:
+        raise RuntimeError("setWallBcs: the fill-fraction variant (KnSetWallBcsFrac, extforces.cpp:240-324) is outside the hot path")
+    s = flags.parent
+    s.lib.call("mf_set_wall_bcs", flags.sx, flags.sy, flags.sz, flags.ptr, vel.ptr, None if obvel is None else obvel.ptr, s.stream)
+
+
+def _f32(x): return np.float32(x)
+
+
+@plugin
+def addBuoyancy(flags, density, vel, gravity, coefficient=1., scale=True):
+    g = _to_vec3(gravity)
+    s = flags.parent
+    gridScale = _f32(flags.getDx()) if scale else _f32(1)     # float gridScale = scale ? flags.getDx() : 1
+    dt = _f32(s.getDt())
+    f = [_f32(_f32(_f32(-_f32(c)) * dt) / gridScale) * _f32(coefficient) for c in (g.x, g.y, g.z)]   # -gravity*dt/gridScale*coefficient
+    s.lib.call("mf_add_buoyancy", flags.sx, flags.sy, flags.sz, flags.ptr, density.ptr, vel.ptr, float(f[0]), float(f[1]), float(f[2]), s.stream)
+
+
+@plugin
+def addGravity(flags, vel, gravity, exclude=None, scale=True):
+    g = _to_vec3(gravity)
+    s = flags.parent
+    gridScale = _f32(flags.getDx()) if scale else _f32(1)
+    dt = _f32(s.getDt())
+    f = [_f32(_f32(_f32(c) * dt) / gridScale) for c in (g.x, g.y, g.z)]
+    exclude = _opt(exclude, Grid, "Grid<Real>")
+    s.lib.call("mf_apply_force", flags.sx, flags.sy, flags.sz, flags.ptr, vel.ptr, float(f[0]), float(f[1]), float(f[2]),
+               None if exclude is None else exclude.ptr, 1, s.stream)
+
+
+@plugin
+def addGravityNoScale(flags, vel, gravity, exclude=None): addGravity(flags, vel, gravity, exclude, False, notiming=True)

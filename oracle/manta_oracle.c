@@ -1,0 +1,1541 @@
+/*
+ * oracle/manta_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, CPU restatement of the hot path of zoharl3/mantaflow (semi-Lagrangian / MacCormack advection,
+ * GridCg pressure projection with the modified-incomplete-Cholesky preconditioner, FLIP particle<->grid
+ * transfers) behind the C ABI of include/manta_hip.h, with HOST pointers.  Every function cites the
+ * reference file:line it follows and keeps the reference's evaluation order and float/double promotion
+ * points, so that results are bit-identical to the reference compiled without FMA contraction
+ * (gcc, x86-64, -O3; the reference build uses no -march flag).  Compile with -ffp-contract=off.
+ *
+ * It is NOT the product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * It is pinned against the reference itself (oracle/_ref/libmanta_ref.so, built by oracle/ref.mk) in
+ * tests/test_oracle_vs_reference.py and against the committed golden vectors in tests/golden/.
+ *
+ * Layouts: see include/manta_hip.h (Vec3/MAC grids and particle vectors are structure-of-arrays).
+ * Loops that the reference runs under `#pragma omp for` (preprocessor/codegen_kernel.cpp:213-299) carry the
+ * same pragma here; kernels the reference runs single-threaded (MIC sweeps conjugategrad.cpp:135-159, the
+ * particle->grid scatter flip.cpp:619) are single-threaded here too.
+ */
+#include "../include/manta_hip.h"
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static _Thread_local char g_err[512];
+static int fail(const char* msg) {
+	snprintf(g_err, sizeof g_err, "%s", msg);
+	return 1;
+}
+const char* mf_last_error(void) { return g_err; }
+const char* mf_backend(void) { return "oracle"; }
+
+typedef struct {
+	int sx, sy, sz;
+	int is3d;
+	int64_t X, Y, Z, n; /* strides (Z == 0 in 2-D, grid.cpp:56) */
+} Dim;
+static Dim mkdim(int sx, int sy, int sz) {
+	Dim d;
+	d.sx = sx;
+	d.sy = sy;
+	d.sz = sz;
+	d.is3d = sz > 1;
+	d.X = 1;
+	d.Y = sx;
+	d.Z = d.is3d ? (int64_t)sx * sy : 0;
+	d.n = (int64_t)sx * sy * sz;
+	return d;
+}
+#define IDX(d, i, j, k) ((int64_t)(i) + (d).Y * (j) + (d).Z * (k))
+/* FOR_IJK_BND, kernel.h:39-42 */
+#define K0(d, b) ((d).is3d ? (b) : 0)
+#define K1(d, b) ((d).is3d ? (d).sz - (b) : 1)
+
+/* ================================================================================================
+ * element-wise ops
+ * ============================================================================================== */
+int mf_fill_f32(int64_t n, float* a, float v, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) a[i] = v;
+	return 0;
+}
+int mf_fill_i32(int64_t n, int32_t* a, int32_t v, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) a[i] = v;
+	return 0;
+}
+int mf_copy_f32(int64_t n, float* dst, const float* src, void* s) {
+	(void)s;
+	memcpy(dst, src, sizeof(float) * n); /* grid.cpp:230 */
+	return 0;
+}
+/* gridScaledAdd, grid.h:514: me[idx] += factor * other[idx] (all fp32) */
+int mf_grid_scaled_add(int64_t n, float* me, const float* other, float factor, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] += factor * other[i];
+	return 0;
+}
+/* UpdateSearchVec, conjugategrad.cpp:193-196 */
+int mf_update_search_vec(int64_t n, float* dst, const float* src, float factor, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) dst[i] = src[i] + factor * dst[i];
+	return 0;
+}
+/* GridDotProduct, conjugategrad.cpp:175-178: fp32 product added to an fp64 accumulator.  The reference
+ * combines thread-local sums under `omp critical`; here: fixed chunks of 4096 summed in index order. */
+static double dot64(int64_t n, const float* a, const float* b) {
+	const int64_t CH = 4096;
+	int64_t nch = (n + CH - 1) / CH;
+	double* part = (double*)malloc(sizeof(double) * (nch ? nch : 1));
+#pragma omp parallel for
+	for (int64_t c = 0; c < nch; c++) {
+		double acc = 0.0;
+		int64_t e = (c + 1) * CH < n ? (c + 1) * CH : n;
+		for (int64_t i = c * CH; i < e; i++) acc += (a[i] * b[i]);
+		part[c] = acc;
+	}
+	double r = 0.0;
+	for (int64_t c = 0; c < nch; c++) r += part[c];
+	free(part);
+	return r;
+}
+int mf_grid_dot(int64_t n, const float* a, const float* b, double* r, void* s) {
+	(void)s;
+	*r = dot64(n, a, b);
+	return 0;
+}
+/* GridSumSqr, commonkernels.h:32-35: square of the value converted to double */
+static double sumsqr64(int64_t n, const float* a) {
+	const int64_t CH = 4096;
+	int64_t nch = (n + CH - 1) / CH;
+	double* part = (double*)malloc(sizeof(double) * (nch ? nch : 1));
+#pragma omp parallel for
+	for (int64_t c = 0; c < nch; c++) {
+		double acc = 0.0;
+		int64_t e = (c + 1) * CH < n ? (c + 1) * CH : n;
+		for (int64_t i = c * CH; i < e; i++) acc += (double)a[i] * (double)a[i];
+		part[c] = acc;
+	}
+	double r = 0.0;
+	for (int64_t c = 0; c < nch; c++) r += part[c];
+	free(part);
+	return r;
+}
+int mf_grid_sum_sqr(int64_t n, const float* a, double* r, void* s) {
+	(void)s;
+	*r = sumsqr64(n, a);
+	return 0;
+}
+/* CompMinReal / CompMaxReal, grid.cpp:185-196 */
+static void minmax(int64_t n, const float* a, float* mn, float* mx) {
+	float lo = FLT_MAX, hi = -FLT_MAX;
+#pragma omp parallel for reduction(min : lo) reduction(max : hi)
+	for (int64_t i = 0; i < n; i++) {
+		if (a[i] < lo) lo = a[i];
+		if (a[i] > hi) hi = a[i];
+	}
+	*mn = lo;
+	*mx = hi;
+}
+int mf_grid_min_max(int64_t n, const float* a, float* mn, float* mx, void* s) {
+	(void)s;
+	minmax(n, a, mn, mx);
+	return 0;
+}
+/* Grid<Real>::getMaxAbs, grid.cpp:356-360 */
+static float maxabs(int64_t n, const float* a) {
+	float lo, hi;
+	minmax(n, a, &lo, &hi);
+	lo = fabsf(lo);
+	hi = fabsf(hi);
+	return lo > hi ? lo : hi;
+}
+int mf_grid_max_abs(int64_t n, const float* a, float* r, void* s) {
+	(void)s;
+	*r = maxabs(n, a);
+	return 0;
+}
+/* Grid<Vec3>::getMaxAbs = sqrt(CompMaxVec), grid.cpp:218-224,367-369; normSquare vectorbase.h:392-395 */
+int mf_grid_max_abs_vec3(int64_t n, const float* a, float* r, void* s) {
+	(void)s;
+	float hi = -FLT_MAX;
+#pragma omp parallel for reduction(max : hi)
+	for (int64_t i = 0; i < n; i++) {
+		float x = a[i], y = a[n + i], z = a[2 * n + i];
+		float q = x * x + y * y + z * z;
+		if (q > hi) hi = q;
+	}
+	*r = sqrtf(hi);
+	return 0;
+}
+int mf_grid_stomp(int64_t n, float* a, float th, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++)
+		if (a[i] < th) a[i] = 0;
+	return 0;
+}
+int mf_grid_safe_divide(int64_t n, float* me, const float* other, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] = (other[i]) ? (me[i] / other[i]) : me[i];
+	return 0;
+}
+int mf_grid_add_const(int64_t n, float* me, float v, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] += v;
+	return 0;
+}
+int mf_grid_mult_const(int64_t n, float* me, float v, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] *= v;
+	return 0;
+}
+int mf_grid_clamp(int64_t n, float* me, float lo, float hi, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) {
+		float v = me[i];
+		me[i] = v < lo ? lo : (v > hi ? hi : v);
+	}
+	return 0;
+}
+int mf_grid_add(int64_t n, float* me, const float* o, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] += o[i];
+	return 0;
+}
+int mf_grid_sub(int64_t n, float* me, const float* o, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] -= o[i];
+	return 0;
+}
+int mf_grid_mult(int64_t n, float* me, const float* o, void* s) {
+	(void)s;
+#pragma omp parallel for
+	for (int64_t i = 0; i < n; i++) me[i] *= o[i];
+	return 0;
+}
+
+/* ================================================================================================
+ * pressure projection
+ * ============================================================================================== */
+/* ApplyMatrix, conjugategrad.h:118-133; 2-D variant :136-151.  KERNEL(idx): every cell. */
+int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                    const float* Ai, const float* Aj, const float* Ak, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t X = d.X, Y = d.Y, Z = d.Z;
+#pragma omp parallel for
+	for (int64_t idx = 0; idx < d.n; idx++) {
+		if (!(flags[idx] & MF_FLUID)) {
+			dst[idx] = src[idx];
+			continue;
+		}
+		float r = src[idx] * A0[idx] + src[idx - X] * Ai[idx - X] + src[idx + X] * Ai[idx] + src[idx - Y] * Aj[idx - Y] +
+		          src[idx + Y] * Aj[idx];
+		if (d.is3d) r = r + src[idx - Z] * Ak[idx - Z] + src[idx + Z] * Ak[idx];
+		dst[idx] = r;
+	}
+	return 0;
+}
+
+/* MakeLaplaceMatrix, conjugategrad.h:154-187 (bnd=1) */
+int mf_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak,
+                           const float* fr, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				if (!fr) {
+					if (!(flags[idx - d.X] & MF_OBSTACLE)) A0[idx] += 1.;
+					if (!(flags[idx + d.X] & MF_OBSTACLE)) A0[idx] += 1.;
+					if (!(flags[idx - d.Y] & MF_OBSTACLE)) A0[idx] += 1.;
+					if (!(flags[idx + d.Y] & MF_OBSTACLE)) A0[idx] += 1.;
+					if (d.is3d && !(flags[idx - d.Z] & MF_OBSTACLE)) A0[idx] += 1.;
+					if (d.is3d && !(flags[idx + d.Z] & MF_OBSTACLE)) A0[idx] += 1.;
+					if (flags[idx + d.X] & MF_FLUID) Ai[idx] = -1.;
+					if (flags[idx + d.Y] & MF_FLUID) Aj[idx] = -1.;
+					if (d.is3d && (flags[idx + d.Z] & MF_FLUID)) Ak[idx] = -1.;
+				} else {
+					const float *fx = fr, *fy = fr + n, *fz = fr + 2 * n;
+					A0[idx] += fx[idx];
+					A0[idx] += fx[idx + d.X];
+					A0[idx] += fy[idx];
+					A0[idx] += fy[idx + d.Y];
+					if (d.is3d) A0[idx] += fz[idx];
+					if (d.is3d) A0[idx] += fz[idx + d.Z];
+					if (flags[idx + d.X] & MF_FLUID) Ai[idx] = -fx[idx + d.X];
+					if (flags[idx + d.Y] & MF_FLUID) Aj[idx] = -fy[idx + d.Y];
+					if (d.is3d && (flags[idx + d.Z] & MF_FLUID)) Ak[idx] = -fz[idx + d.Z];
+				}
+			}
+	return 0;
+}
+
+/* ghost-fluid helpers, plugin/pressure.cpp:115-133 */
+static inline float thetaHelper(float inside, float outside) {
+	const float denom = inside - outside;
+	if (denom > -1e-04) return 0.5;
+	float q = inside / denom;
+	float m = q < 1.f ? q : 1.f; /* std::min(Real(1), q) */
+	return 0.f < m ? m : 0.f;    /* std::max(Real(0), m) */
+}
+static inline float ghostFluidHelper(int64_t idx, int64_t offset, const float* phi, float gfClamp) {
+	float alpha = thetaHelper(phi[idx], phi[idx + offset]);
+	if (alpha < gfClamp) return gfClamp;
+	return (float)(1. - (1. / alpha));
+}
+static inline float surfTensHelper(int64_t idx, int64_t offset, const float* phi, const float* curv, float surfTens,
+                                   float gfClamp) {
+	return surfTens * (curv[idx + offset] - ghostFluidHelper(idx, offset, phi, gfClamp) * curv[idx]);
+}
+static inline int ghostFluidWasClamped(int64_t idx, int64_t offset, const float* phi, float gfClamp) {
+	const float alpha = thetaHelper(phi[idx], phi[idx + offset]);
+	return alpha < gfClamp;
+}
+
+/* MakeRhs, plugin/pressure.cpp:32-84 (bnd=1, reduce +) */
+int mf_make_rhs(int sx, int sy, int sz, const int32_t* flags, float* rhs, const float* vel, const float* perCellCorr,
+                const float* fr, const float* ob, const float* phi, const float* curv, float surfTens, float gfClamp,
+                int32_t* cnt_out, double* sum_out, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	const float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+	int nk = K1(d, 1) - K0(d, 1);
+	if (nk < 0) nk = 0;
+	double* psum = (double*)calloc(nk ? nk : 1, sizeof(double));
+	int* pcnt = (int*)calloc(nk ? nk : 1, sizeof(int));
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++) {
+		double sum = 0;
+		int cnt = 0;
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) {
+					rhs[idx] = 0;
+					continue;
+				}
+				float set = 0;
+				if (!fr) {
+					set = vx[idx] - vx[idx + X] + vy[idx] - vy[idx + Y];
+					if (d.is3d) set += vz[idx] - vz[idx + Z];
+				} else {
+					const float *fx = fr, *fy = fr + n, *fz = fr + 2 * n;
+					set = fx[idx] * vx[idx] - fx[idx + X] * vx[idx + X] + fy[idx] * vy[idx] - fy[idx + Y] * vy[idx + Y];
+					if (d.is3d) set += fz[idx] * vz[idx] - fz[idx + Z] * vz[idx + Z];
+					if (ob) {
+						const float *ox = ob, *oy = ob + n, *oz = ob + 2 * n;
+						set += (1 - fx[idx]) * ox[idx] - (1 - fx[idx + X]) * ox[idx + X] + (1 - fy[idx]) * oy[idx] -
+						       (1 - fy[idx + Y]) * oy[idx + Y];
+						if (d.is3d) set += (1 - fz[idx]) * oz[idx] - (1 - fz[idx + Z]) * oz[idx + Z];
+					}
+				}
+				if (phi && curv) {
+					if (flags[idx - X] & MF_EMPTY) set += surfTensHelper(idx, -X, phi, curv, surfTens, gfClamp);
+					if (flags[idx + X] & MF_EMPTY) set += surfTensHelper(idx, +X, phi, curv, surfTens, gfClamp);
+					if (flags[idx - Y] & MF_EMPTY) set += surfTensHelper(idx, -Y, phi, curv, surfTens, gfClamp);
+					if (flags[idx + Y] & MF_EMPTY) set += surfTensHelper(idx, +Y, phi, curv, surfTens, gfClamp);
+					if (d.is3d) {
+						if (flags[idx - Z] & MF_EMPTY) set += surfTensHelper(idx, -Z, phi, curv, surfTens, gfClamp);
+						if (flags[idx + Z] & MF_EMPTY) set += surfTensHelper(idx, +Z, phi, curv, surfTens, gfClamp);
+					}
+				}
+				if (perCellCorr) set += perCellCorr[idx];
+				sum += set;
+				cnt++;
+				rhs[idx] = set;
+			}
+		psum[k - K0(d, 1)] = sum;
+		pcnt[k - K0(d, 1)] = cnt;
+	}
+	double sum = 0;
+	int cnt = 0;
+	for (int k = 0; k < nk; k++) {
+		sum += psum[k];
+		cnt += pcnt[k];
+	}
+	free(psum);
+	free(pcnt);
+	if (cnt_out) *cnt_out = cnt;
+	if (sum_out) *sum_out = sum;
+	return 0;
+}
+
+/* ApplyGhostFluidDiagonal, plugin/pressure.cpp:136-151 */
+int mf_apply_ghost_fluid_diagonal(int sx, int sy, int sz, float* A0, const int32_t* flags, const float* phi,
+                                  float gfClamp, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t X = d.X, Y = d.Y, Z = d.Z;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				if (flags[idx - X] & MF_EMPTY) A0[idx] -= ghostFluidHelper(idx, -X, phi, gfClamp);
+				if (flags[idx + X] & MF_EMPTY) A0[idx] -= ghostFluidHelper(idx, +X, phi, gfClamp);
+				if (flags[idx - Y] & MF_EMPTY) A0[idx] -= ghostFluidHelper(idx, -Y, phi, gfClamp);
+				if (flags[idx + Y] & MF_EMPTY) A0[idx] -= ghostFluidHelper(idx, +Y, phi, gfClamp);
+				if (d.is3d) {
+					if (flags[idx - Z] & MF_EMPTY) A0[idx] -= ghostFluidHelper(idx, -Z, phi, gfClamp);
+					if (flags[idx + Z] & MF_EMPTY) A0[idx] -= ghostFluidHelper(idx, +Z, phi, gfClamp);
+				}
+			}
+	return 0;
+}
+
+/* knCorrectVelocity, plugin/pressure.cpp:87-109 */
+int mf_correct_velocity(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* p, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				int f = flags[idx];
+				if (f & MF_FLUID) {
+					if (flags[idx - X] & MF_FLUID) vx[idx] -= (p[idx] - p[idx - X]);
+					if (flags[idx - Y] & MF_FLUID) vy[idx] -= (p[idx] - p[idx - Y]);
+					if (d.is3d && (flags[idx - Z] & MF_FLUID)) vz[idx] -= (p[idx] - p[idx - Z]);
+					if (flags[idx - X] & MF_EMPTY) vx[idx] -= p[idx];
+					if (flags[idx - Y] & MF_EMPTY) vy[idx] -= p[idx];
+					if (d.is3d && (flags[idx - Z] & MF_EMPTY)) vz[idx] -= p[idx];
+				} else if ((f & MF_EMPTY) && !(f & MF_OUTFLOW)) {
+					if (flags[idx - X] & MF_FLUID)
+						vx[idx] += p[idx - X];
+					else
+						vx[idx] = 0.f;
+					if (flags[idx - Y] & MF_FLUID)
+						vy[idx] += p[idx - Y];
+					else
+						vy[idx] = 0.f;
+					if (d.is3d) {
+						if (flags[idx - Z] & MF_FLUID)
+							vz[idx] += p[idx - Z];
+						else
+							vz[idx] = 0.f;
+					}
+				}
+			}
+	return 0;
+}
+
+/* knCorrectVelocityGhostFluid, plugin/pressure.cpp:154-187 */
+int mf_correct_velocity_ghost_fluid(int sx, int sy, int sz, float* vel, const int32_t* flags, const float* p,
+                                    const float* phi, float gfClamp, const float* curv, float surfTens, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				int f = flags[idx];
+				int fl = (f & MF_FLUID) != 0, emp = (f & MF_EMPTY) && !(f & MF_OUTFLOW);
+				if (fl) {
+					if (flags[idx - X] & MF_EMPTY) vx[idx] += p[idx] * ghostFluidHelper(idx, -X, phi, gfClamp);
+					if (flags[idx - Y] & MF_EMPTY) vy[idx] += p[idx] * ghostFluidHelper(idx, -Y, phi, gfClamp);
+					if (d.is3d && (flags[idx - Z] & MF_EMPTY)) vz[idx] += p[idx] * ghostFluidHelper(idx, -Z, phi, gfClamp);
+				} else if (emp) {
+					if (flags[idx - X] & MF_FLUID)
+						vx[idx] -= p[idx - X] * ghostFluidHelper(idx - X, +X, phi, gfClamp);
+					else
+						vx[idx] = 0.f;
+					if (flags[idx - Y] & MF_FLUID)
+						vy[idx] -= p[idx - Y] * ghostFluidHelper(idx - Y, +Y, phi, gfClamp);
+					else
+						vy[idx] = 0.f;
+					if (d.is3d) {
+						if (flags[idx - Z] & MF_FLUID)
+							vz[idx] -= p[idx - Z] * ghostFluidHelper(idx - Z, +Z, phi, gfClamp);
+						else
+							vz[idx] = 0.f;
+					}
+				}
+				if (curv) {
+					if (fl) {
+						if (flags[idx - X] & MF_EMPTY) vx[idx] += surfTensHelper(idx, -X, phi, curv, surfTens, gfClamp);
+						if (flags[idx - Y] & MF_EMPTY) vy[idx] += surfTensHelper(idx, -Y, phi, curv, surfTens, gfClamp);
+						if (d.is3d && (flags[idx - Z] & MF_EMPTY))
+							vz[idx] += surfTensHelper(idx, -Z, phi, curv, surfTens, gfClamp);
+					} else if (emp) {
+						vx[idx] -= (flags[idx - X] & MF_FLUID) ? surfTensHelper(idx - X, +X, phi, curv, surfTens, gfClamp) : 0.f;
+						vy[idx] -= (flags[idx - Y] & MF_FLUID) ? surfTensHelper(idx - Y, +Y, phi, curv, surfTens, gfClamp) : 0.f;
+						if (d.is3d)
+							vz[idx] -= (flags[idx - Z] & MF_FLUID) ? surfTensHelper(idx - Z, +Z, phi, curv, surfTens, gfClamp) : 0.f;
+					}
+				}
+			}
+	return 0;
+}
+
+/* knReplaceClampedGhostFluidVels, plugin/pressure.cpp:198-214.  The reference reads vel[idx+-X] while other
+ * threads may write them; reads only touch fluid cells' entries, writes only empty cells' -> race free. */
+int mf_replace_clamped_ghost_fluid_vels(int sx, int sy, int sz, float* vel, const int32_t* flags, const float* p,
+                                        const float* phi, float gfClamp, void* st) {
+	(void)st;
+	(void)p;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_EMPTY)) continue;
+				if ((flags[idx - X] & MF_FLUID) && ghostFluidWasClamped(idx - X, +X, phi, gfClamp)) vx[idx] = vx[idx - X];
+				if ((flags[idx - Y] & MF_FLUID) && ghostFluidWasClamped(idx - Y, +Y, phi, gfClamp)) vy[idx] = vy[idx - Y];
+				if (d.is3d && (flags[idx - Z] & MF_FLUID) && ghostFluidWasClamped(idx - Z, +Z, phi, gfClamp))
+					vz[idx] = vz[idx - Z];
+				if ((flags[idx + X] & MF_FLUID) && ghostFluidWasClamped(idx + X, -X, phi, gfClamp)) vx[idx] = vx[idx + X];
+				if ((flags[idx + Y] & MF_FLUID) && ghostFluidWasClamped(idx + Y, -Y, phi, gfClamp)) vy[idx] = vy[idx + Y];
+				if (d.is3d && (flags[idx + Z] & MF_FLUID) && ghostFluidWasClamped(idx + Z, -Z, phi, gfClamp))
+					vz[idx] = vz[idx + Z];
+			}
+	return 0;
+}
+
+/* CountEmptyCells, plugin/pressure.cpp:217-220 */
+int mf_count_empty_cells(int64_t n, const int32_t* flags, int32_t* r, void* st) {
+	(void)st;
+	int c = 0;
+#pragma omp parallel for reduction(+ : c)
+	for (int64_t i = 0; i < n; i++)
+		if (flags[i] & MF_EMPTY) c++;
+	*r = c;
+	return 0;
+}
+
+/* fixPressure, plugin/pressure.cpp:226-246 */
+int mf_fix_pressure(int sx, int sy, int sz, int64_t p, float value, float* rhs, float* A0, float* Ai, float* Aj,
+                    float* Ak, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t X = d.X, Y = d.Y, Z = d.Z;
+	rhs[p + X] -= Ai[p] * value;
+	rhs[p + Y] -= Aj[p] * value;
+	rhs[p - X] -= Ai[p - X] * value;
+	rhs[p - Y] -= Aj[p - Y] * value;
+	if (d.is3d) {
+		rhs[p + Z] -= Ak[p] * value;
+		rhs[p - Z] -= Ak[p - Z] * value;
+	}
+	rhs[p] = value;
+	A0[p] = 1.f;
+	Ai[p] = Aj[p] = Ak[p] = 0.f;
+	Ai[p - X] = 0.f;
+	Aj[p - Y] = 0.f;
+	if (d.is3d) Ak[p - Z] = 0.f;
+	return 0;
+}
+
+/* InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97.  Serial FOR_IJK over ALL cells; only
+ * fluid cells are touched (fluid cells never sit on the outer layer in valid scenes, so i-1 etc. exist). */
+static inline float sq(float a) { return a * a; }
+int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Ap, const float* A0, const float* Ai,
+                const float* Aj, const float* Ak, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	const int64_t X = d.X, Y = d.Y, Z = d.Z;
+	memset(Ap, 0, sizeof(float) * d.n);
+	const float tau = 0.97;
+	const float sigma = 0.25;
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				float e = A0[idx] - sq(Ai[idx - X] * Ap[idx - X]) - sq(Aj[idx - Y] * Ap[idx - Y]) - sq(Ak[idx - Z] * Ap[idx - Z]);
+				/* `tau * ( a + b + c + 0. )` : the trailing double literal promotes the product and the
+				 * subtraction to fp64 (conjugategrad.cpp:84-88) */
+				float s3 = Ai[idx - X] * (Aj[idx - X] + Ak[idx - X]) * sq(Ap[idx - X]) +
+				           Aj[idx - Y] * (Ai[idx - Y] + Ak[idx - Y]) * sq(Ap[idx - Y]) +
+				           Ak[idx - Z] * (Ai[idx - Z] + Aj[idx - Z]) * sq(Ap[idx - Z]);
+				e = (float)((double)e - (double)tau * ((double)s3 + 0.));
+				if (e < sigma * A0[idx]) e = A0[idx];
+				Ap[idx] = (float)(1. / (double)sqrtf(e));
+			}
+	return 0;
+}
+
+/* ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159 (serial forward + backward sweep) */
+int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* v, const float* Ap,
+                 const float* Ai, const float* Aj, const float* Ak, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	const int64_t X = d.X, Y = d.Y, Z = d.Z;
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				const float p = Ap[idx];
+				dst[idx] = p * (v[idx] - dst[idx - X] * Ai[idx - X] * Ap[idx - X] - dst[idx - Y] * Aj[idx - Y] * Ap[idx - Y] -
+				                dst[idx - Z] * Ak[idx - Z] * Ap[idx - Z]);
+			}
+	for (int k = sz - 1; k >= 0; k--)
+		for (int j = sy - 1; j >= 0; j--)
+			for (int i = sx - 1; i >= 0; i--) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				const float p = Ap[idx];
+				dst[idx] = p * (dst[idx] - dst[idx + X] * Ai[idx] * p - dst[idx + Y] * Aj[idx] * p - dst[idx + Z] * Ak[idx] * p);
+			}
+	return 0;
+}
+
+/* GridCg<APPLYMAT>::doInit / iterate, conjugategrad.cpp:210-299; loop as in solvePressureSystem
+ * (plugin/pressure.cpp:438-441) */
+int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual,
+                float* search, float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak,
+                float* Ap, int pc, float accuracy, int maxIter, int useL2Norm, float* out, void* st) {
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	if (pc != MF_PC_NONE && pc != MF_PC_MICP) return fail("GridCg<APPLYMAT>::setICPreconditioner: Invalid method specified.");
+	if (pc == MF_PC_MICP && !d.is3d) pc = MF_PC_NONE; /* conjugategrad.cpp:315-321 */
+	int iterations = 0;
+	float resNorm = 1e20f, sigma = 0.f;
+	/* doInit */
+	memset(dst, 0, sizeof(float) * n);
+	memcpy(residual, rhs, sizeof(float) * n);
+	if (pc == MF_PC_MICP) {
+		mf_mic_init(sx, sy, sz, flags, Ap, A0, Ai, Aj, Ak, st);
+		mf_mic_apply(sx, sy, sz, flags, tmp, residual, Ap, Ai, Aj, Ak, st);
+	} else
+		memcpy(tmp, residual, sizeof(float) * n);
+	memcpy(search, tmp, sizeof(float) * n);
+	sigma = (float)dot64(n, tmp, residual);
+	for (int iter = 0; iter < maxIter; iter++) {
+		iterations++;
+		mf_apply_matrix(sx, sy, sz, flags, tmp, search, A0, Ai, Aj, Ak, st);
+		float dp = (float)dot64(n, tmp, search);
+		float alpha = 0.;
+		if (fabs(dp) > 0.) alpha = sigma / (float)dp;
+		mf_grid_scaled_add(n, dst, search, alpha, st);
+		mf_grid_scaled_add(n, residual, tmp, -alpha, st);
+		if (pc == MF_PC_MICP)
+			mf_mic_apply(sx, sy, sz, flags, tmp, residual, Ap, Ai, Aj, Ak, st);
+		else
+			memcpy(tmp, residual, sizeof(float) * n);
+		if (useL2Norm)
+			resNorm = (float)sumsqr64(n, residual);
+		else
+			resNorm = maxabs(n, residual);
+		if (resNorm < accuracy) {
+			sigma = resNorm;
+			break;
+		}
+		float sigmaNew = (float)dot64(n, tmp, residual);
+		float beta = sigmaNew / sigma;
+		mf_update_search_vec(n, search, tmp, beta, st);
+		sigma = sigmaNew;
+		if (!(resNorm < 1e35)) {
+			out[0] = (float)iterations;
+			out[1] = resNorm;
+			out[2] = sigma;
+			return fail("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.");
+		}
+	}
+	out[0] = (float)iterations;
+	out[1] = resNorm;
+	out[2] = sigma;
+	return 0;
+}
+
+/* ================================================================================================
+ * interpolation primitives, util/interpol.h
+ * ============================================================================================== */
+typedef struct {
+	int xi, yi, zi;
+	float s0, s1, t0, t1, f0, f1;
+} Bi;
+/* BUILD_INDEX, interpol.h:52-69 (note: the fork's upper clamp tests px, not xi) */
+static inline Bi build_index(const Dim* d, float x, float y, float z) {
+	Bi b;
+	float px = x - 0.5f, py = y - 0.5f, pz = z - 0.5f;
+	b.xi = (int)px;
+	b.yi = (int)py;
+	b.zi = (int)pz;
+	b.s1 = px - (float)b.xi;
+	b.s0 = 1. - b.s1;
+	b.t1 = py - (float)b.yi;
+	b.t0 = 1. - b.t1;
+	b.f1 = pz - (float)b.zi;
+	b.f0 = 1. - b.f1;
+	if (px < 0.) { b.xi = 0; b.s0 = 1.0; b.s1 = 0.0; }
+	if (py < 0.) { b.yi = 0; b.t0 = 1.0; b.t1 = 0.0; }
+	if (pz < 0.) { b.zi = 0; b.f0 = 1.0; b.f1 = 0.0; }
+	if (px >= d->sx - 1) { b.xi = d->sx - 2; b.s0 = 0.0; b.s1 = 1.0; }
+	if (py >= d->sy - 1) { b.yi = d->sy - 2; b.t0 = 0.0; b.t1 = 1.0; }
+	if (d->sz > 1) { if (pz >= d->sz - 1) { b.zi = d->sz - 2; b.f0 = 0.0; b.f1 = 1.0; } }
+	return b;
+}
+/* the shifted half of BUILD_INDEX_SHIFT, interpol.h:116-129 (upper clamp tests the integer index) */
+static inline Bi build_index_shift(const Dim* d, float x, float y, float z) {
+	Bi b;
+	b.xi = (int)x;
+	b.yi = (int)y;
+	b.zi = (int)z;
+	b.s1 = x - (float)b.xi;
+	b.s0 = 1. - b.s1;
+	b.t1 = y - (float)b.yi;
+	b.t0 = 1. - b.t1;
+	b.f1 = z - (float)b.zi;
+	b.f0 = 1. - b.f1;
+	if (x < 0) { b.xi = 0; b.s0 = 1.0; b.s1 = 0.0; }
+	if (y < 0) { b.yi = 0; b.t0 = 1.0; b.t1 = 0.0; }
+	if (z < 0) { b.zi = 0; b.f0 = 1.0; b.f1 = 0.0; }
+	if (b.xi >= d->sx - 1) { b.xi = d->sx - 2; b.s0 = 0.0; b.s1 = 1.0; }
+	if (b.yi >= d->sy - 1) { b.yi = d->sy - 2; b.t0 = 0.0; b.t1 = 1.0; }
+	if (d->sz > 1) { if (b.zi >= d->sz - 1) { b.zi = d->sz - 2; b.f0 = 0.0; b.f1 = 1.0; } }
+	return b;
+}
+/* interpol<T> / interpolComponent<c>, interpol.h:71-94 on one scalar plane */
+static inline float interpol1(const Dim* d, const float* data, float x, float y, float z) {
+	Bi b = build_index(d, x, y, z);
+	const int64_t X = 1, Y = d->Y, Z = d->Z;
+	int64_t idx = (int64_t)b.xi + Y * b.yi + Z * b.zi;
+	return ((data[idx] * b.t0 + data[idx + Y] * b.t1) * b.s0 + (data[idx + X] * b.t0 + data[idx + X + Y] * b.t1) * b.s1) * b.f0 +
+	       ((data[idx + Z] * b.t0 + data[idx + Y + Z] * b.t1) * b.s0 + (data[idx + X + Z] * b.t0 + data[idx + X + Y + Z] * b.t1) * b.s1) * b.f1;
+}
+/* interpolMAC, interpol.h:131-164 */
+static inline void interpol_mac(const Dim* d, const float* vel, float x, float y, float z, float out[3]) {
+	Bi b = build_index(d, x, y, z), s = build_index_shift(d, x, y, z);
+	const int64_t X = 1, Y = d->Y, Z = d->Z, n = d->n;
+	{
+		const float* r = vel + (((int64_t)b.zi * d->sy + b.yi) * d->sx + s.xi);
+		out[0] = b.f0 * ((r[0] * b.t0 + r[Y] * b.t1) * s.s0 + (r[X] * b.t0 + r[X + Y] * b.t1) * s.s1) +
+		         b.f1 * ((r[Z] * b.t0 + r[Z + Y] * b.t1) * s.s0 + (r[X + Z] * b.t0 + r[X + Y + Z] * b.t1) * s.s1);
+	}
+	{
+		const float* r = vel + n + (((int64_t)b.zi * d->sy + s.yi) * d->sx + b.xi);
+		out[1] = b.f0 * ((r[0] * s.t0 + r[Y] * s.t1) * b.s0 + (r[X] * s.t0 + r[X + Y] * s.t1) * b.s1) +
+		         b.f1 * ((r[Z] * s.t0 + r[Z + Y] * s.t1) * b.s0 + (r[X + Z] * s.t0 + r[X + Y + Z] * s.t1) * b.s1);
+	}
+	{
+		const float* r = vel + 2 * n + (((int64_t)s.zi * d->sy + b.yi) * d->sx + b.xi);
+		out[2] = s.f0 * ((r[0] * b.t0 + r[Y] * b.t1) * b.s0 + (r[X] * b.t0 + r[X + Y] * b.t1) * b.s1) +
+		         s.f1 * ((r[Z] * b.t0 + r[Z + Y] * b.t1) * b.s0 + (r[X + Z] * b.t0 + r[X + Y + Z] * b.t1) * b.s1);
+	}
+}
+/* MACGrid::getCentered / getAtMACX/Y/Z, grid.h:460-506 */
+static inline void get_centered(const Dim* d, const float* vel, int64_t idx, float v[3]) {
+	const int64_t n = d->n;
+	v[0] = 0.5 * (vel[idx] + vel[idx + 1]);
+	v[1] = 0.5 * (vel[n + idx] + vel[n + idx + d->sx]);
+	v[2] = 0.;
+	if (d->is3d) v[2] = 0.5 * (vel[2 * n + idx] + vel[2 * n + idx + d->Z]);
+}
+static inline void get_at_mac_x(const Dim* d, const float* vel, int64_t idx, float v[3]) {
+	const int64_t n = d->n, sx = d->sx, Z = d->Z;
+	const float *y = vel + n, *z = vel + 2 * n;
+	v[0] = vel[idx];
+	v[1] = 0.25 * (y[idx] + y[idx - 1] + y[idx + sx] + y[idx + sx - 1]);
+	v[2] = 0.;
+	if (d->is3d) v[2] = 0.25 * (z[idx] + z[idx - 1] + z[idx + Z] + z[idx + Z - 1]);
+}
+static inline void get_at_mac_y(const Dim* d, const float* vel, int64_t idx, float v[3]) {
+	const int64_t n = d->n, sx = d->sx, Z = d->Z;
+	const float *x = vel, *z = vel + 2 * n;
+	v[0] = 0.25 * (x[idx] + x[idx - sx] + x[idx + 1] + x[idx + 1 - sx]);
+	v[1] = vel[n + idx];
+	v[2] = 0.;
+	if (d->is3d) v[2] = 0.25 * (z[idx] + z[idx - sx] + z[idx + Z] + z[idx + Z - sx]);
+}
+static inline void get_at_mac_z(const Dim* d, const float* vel, int64_t idx, float v[3]) {
+	const int64_t n = d->n, sx = d->sx, Z = d->Z;
+	const float *x = vel, *y = vel + n;
+	v[0] = 0.25 * (x[idx] + x[idx - Z] + x[idx + 1] + x[idx + 1 - Z]);
+	v[1] = 0.25 * (y[idx] + y[idx - Z] + y[idx + sx] + y[idx + sx - Z]);
+	v[2] = vel[2 * n + idx];
+}
+
+/* ================================================================================================
+ * advection, plugin/advection.cpp
+ * ============================================================================================== */
+/* SemiLagrange<T>, advection.cpp:25-42; ncomp scalar planes of `src` (1 = Real, 3 = centred Vec3) */
+static int semi_lagrange(int sx, int sy, int sz, int ncomp, const float* vel, float* dst, const float* src, float dt,
+                         int orderTrace) {
+	Dim d = mkdim(sx, sy, sz);
+	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order");
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				float v[3], px, py, pz;
+				get_centered(&d, vel, idx, v);
+				if (orderTrace == 1) {
+					px = (i + 0.5f) - v[0] * dt;
+					py = (j + 0.5f) - v[1] * dt;
+					pz = (k + 0.5f) - v[2] * dt;
+				} else {
+					float p1x = (i + 0.5f) - (float)((v[0] * dt) * 0.5);
+					float p1y = (j + 0.5f) - (float)((v[1] * dt) * 0.5);
+					float p1z = (k + 0.5f) - (float)((v[2] * dt) * 0.5);
+					float u[3];
+					interpol_mac(&d, vel, p1x, p1y, p1z, u);
+					px = (i + 0.5f) - u[0] * dt;
+					py = (j + 0.5f) - u[1] * dt;
+					pz = (k + 0.5f) - u[2] * dt;
+				}
+				for (int c = 0; c < ncomp; c++) dst[c * d.n + idx] = interpol1(&d, src + c * d.n, px, py, pz);
+			}
+	return 0;
+}
+int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
+                          int orderTrace, void* st) {
+	(void)st;
+	return semi_lagrange(sx, sy, sz, 1, vel, dst, src, dt, orderTrace);
+}
+int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
+                          int orderTrace, void* st) {
+	(void)st;
+	return semi_lagrange(sx, sy, sz, 3, vel, dst, src, dt, orderTrace);
+}
+/* SemiLagrangeMAC, advection.cpp:45-78 */
+int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
+                         int orderTrace, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order");
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				float v[3], r[3];
+				if (orderTrace == 1) {
+					get_at_mac_x(&d, vel, idx, v);
+					r[0] = interpol1(&d, src, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (k + 0.5f) - v[2] * dt);
+					get_at_mac_y(&d, vel, idx, v);
+					r[1] = interpol1(&d, src + n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (k + 0.5f) - v[2] * dt);
+					get_at_mac_z(&d, vel, idx, v);
+					r[2] = interpol1(&d, src + 2 * n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (k + 0.5f) - v[2] * dt);
+				} else {
+					float u[3];
+					const float p0x = (float)(i + 0.5), p0y = (float)(j + 0.5), p0z = (float)(k + 0.5);
+					get_at_mac_x(&d, src, idx, v);
+					interpol_mac(&d, src, (float)i - (float)((v[0] * dt) * 0.5), (j + 0.5f) - (float)((v[1] * dt) * 0.5),
+					             (k + 0.5f) - (float)((v[2] * dt) * 0.5), u);
+					r[0] = interpol1(&d, src, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
+					get_at_mac_y(&d, src, idx, v);
+					interpol_mac(&d, src, (i + 0.5f) - (float)((v[0] * dt) * 0.5), (float)j - (float)((v[1] * dt) * 0.5),
+					             (k + 0.5f) - (float)((v[2] * dt) * 0.5), u);
+					r[1] = interpol1(&d, src + n, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
+					get_at_mac_z(&d, src, idx, v);
+					interpol_mac(&d, src, (i + 0.5f) - (float)((v[0] * dt) * 0.5), (j + 0.5f) - (float)((v[1] * dt) * 0.5),
+					             (float)k - (float)((v[2] * dt) * 0.5), u);
+					r[2] = interpol1(&d, src + 2 * n, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
+				}
+				dst[idx] = r[0];
+				dst[n + idx] = r[1];
+				dst[2 * n + idx] = r[2];
+			}
+	return 0;
+}
+
+/* MacCormackCorrect<T>, advection.cpp:82-92 (KERNEL(idx)).
+ * Real:  dst += strength*0.5*(old-bwd)  -> the compound assignment is evaluated in fp64 (0.5 is a double).
+ * Vec3:  S2*Vector3D rounds each product to fp32 first (vectorbase.h:282-284), then an fp32 add. */
+int mf_maccormack_correct(int sx, int sy, int sz, int ncomp, const int32_t* flags, float* dst, const float* old,
+                          const float* fwd, const float* bwd, float strength, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+#pragma omp parallel for
+	for (int64_t idx = 0; idx < n; idx++) {
+		int fl = flags[idx] & MF_FLUID;
+		for (int c = 0; c < ncomp; c++) {
+			int64_t q = c * n + idx;
+			float v = fwd[q];
+			if (fl) {
+				if (ncomp == 1)
+					v = (float)((double)v + strength * 0.5 * (old[q] - bwd[q]));
+				else
+					v = v + (float)(strength * 0.5 * (old[q] - bwd[q]));
+			}
+			dst[q] = v;
+		}
+	}
+	return 0;
+}
+/* MacCormackCorrectMAC<Vec3>(isMAC=true), advection.cpp:95-116 (KERNEL(): all cells) */
+int mf_maccormack_correct_mac(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* old,
+                              const float* fwd, const float* bwd, float strength, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+#pragma omp parallel for
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				int skip[3] = {0, 0, 0};
+				if (!(flags[idx] & MF_FLUID)) skip[0] = skip[1] = skip[2] = 1;
+				if ((i > 0) && !(flags[idx - d.X] & MF_FLUID)) skip[0] = 1;
+				if ((j > 0) && !(flags[idx - d.Y] & MF_FLUID)) skip[1] = 1;
+				if ((k > 0) && !(flags[idx - d.Z] & MF_FLUID)) skip[2] = 1;
+				for (int c = 0; c < 3; c++) {
+					int64_t q = c * n + idx;
+					if (skip[c])
+						dst[q] = fwd[q];
+					else
+						dst[q] = (float)(fwd[q] + strength * 0.5 * (old[q] - bwd[q]));
+				}
+			}
+	return 0;
+}
+
+#define CHECKFLAG(f) ((f) & (MF_FLUID | MF_EMPTY)) /* advection.cpp:140 */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* doClampComponent<T>, advection.cpp:145-187 (gridSize argument already holds size-1) */
+static void do_clamp_component(const Dim* d, int ncomp, const int32_t* flags, float* dval, const float* orig,
+                               const float* fwdv, float px, float py, float pz, const float vel[3], int clampMode) {
+	float minv[3], maxv[3];
+	for (int c = 0; c < ncomp; c++) {
+		minv[c] = FLT_MAX;
+		maxv[c] = -FLT_MAX;
+	}
+	int haveFl = 0;
+	int pos[2][3];
+	int numPos = 1;
+	pos[0][0] = (int)(px - vel[0]);
+	pos[0][1] = (int)(py - vel[1]);
+	pos[0][2] = (int)(pz - vel[2]);
+	if (clampMode == 1) {
+		numPos = 2;
+		pos[1][0] = (int)(px + vel[0]);
+		pos[1][1] = (int)(py + vel[1]);
+		pos[1][2] = (int)(pz + vel[2]);
+	}
+	const int gx = d->sx - 1, gy = d->sy - 1, gz = d->sz - 1;
+	for (int l = 0; l < numPos; l++) {
+		const int i0 = clampi(pos[l][0], 0, gx - 1);
+		const int j0 = clampi(pos[l][1], 0, gy - 1);
+		const int k0 = clampi(pos[l][2], 0, d->is3d ? (gz - 1) : 1);
+		const int i1 = i0 + 1, j1 = j0 + 1, k1 = d->is3d ? (k0 + 1) : k0;
+		const int ii[8] = {i0, i1, i0, i1, i0, i1, i0, i1};
+		const int jj[8] = {j0, j0, j1, j1, j0, j0, j1, j1};
+		const int kk[8] = {k0, k0, k0, k0, k1, k1, k1, k1};
+		int nc = d->is3d ? 8 : 4;
+		for (int q = 0; q < nc; q++) {
+			int64_t idx = IDX(*d, ii[q], jj[q], kk[q]);
+			if (CHECKFLAG(flags[idx])) {
+				for (int c = 0; c < ncomp; c++) {
+					float v = orig[c * d->n + idx];
+					if (v < minv[c]) minv[c] = v;
+					if (v > maxv[c]) maxv[c] = v;
+				}
+				haveFl = 1;
+			}
+		}
+	}
+	if (!haveFl) {
+		for (int c = 0; c < ncomp; c++) dval[c] = fwdv[c];
+		return;
+	}
+	if (clampMode == 1) {
+		for (int c = 0; c < ncomp; c++) {
+			float v = dval[c];
+			dval[c] = v < minv[c] ? minv[c] : (v > maxv[c] ? maxv[c] : v);
+		}
+	} else {
+		int outside = 0;
+		for (int c = 0; c < ncomp; c++) outside |= (dval[c] < minv[c]) | (dval[c] > maxv[c]);
+		if (outside)
+			for (int c = 0; c < ncomp; c++) dval[c] = fwdv[c];
+	}
+}
+/* MacCormackClamp<T>, advection.cpp:242-268 */
+int mf_maccormack_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags, const float* vel, float* dst,
+                        const float* orig, const float* fwd, float dt, int clampMode, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	const int gx = sx - 1, gy = sy - 1, gz = sz - 1;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				float dval[3], fw[3], v[3], vd[3];
+				for (int c = 0; c < ncomp; c++) {
+					dval[c] = dst[c * n + idx];
+					fw[c] = fwd[c * n + idx];
+				}
+				get_centered(&d, vel, idx, v);
+				vd[0] = v[0] * dt;
+				vd[1] = v[1] * dt;
+				vd[2] = v[2] * dt;
+				do_clamp_component(&d, ncomp, flags, dval, orig, fw, (float)i, (float)j, (float)k, vd, clampMode);
+				if (clampMode == 1) {
+					/* Vec3(i,j,k) + Vec3(0.5,0.5,0.5) -+ vel*dt, truncated */
+					int fx = (int)(((float)i + 0.5f) - vd[0]), fy = (int)(((float)j + 0.5f) - vd[1]), fz = (int)(((float)k + 0.5f) - vd[2]);
+					int bx = (int)(((float)i + 0.5f) + vd[0]), by = (int)(((float)j + 0.5f) + vd[1]), bz = (int)(((float)k + 0.5f) + vd[2]);
+					int bad = fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > gx || fy > gy ||
+					          ((fz > gz) && d.is3d) || bx > gx || by > gy || ((bz > gz) && d.is3d);
+					if (!bad) bad = (flags[IDX(d, fx, fy, fz)] & MF_OBSTACLE) || (flags[IDX(d, bx, by, bz)] & MF_OBSTACLE);
+					if (bad)
+						for (int c = 0; c < ncomp; c++) dval[c] = fw[c];
+				}
+				for (int c = 0; c < ncomp; c++) dst[c * n + idx] = dval[c];
+			}
+	return 0;
+}
+/* doClampComponentMAC<c>, advection.cpp:192-236 */
+static float do_clamp_component_mac(const Dim* d, int c, const int32_t* flags, float dst, const float* orig, float fwd,
+                                    int i, int j, int k, const float vel[3], int clampMode) {
+	float minv = FLT_MAX, maxv = -FLT_MAX;
+	const float px = (float)i, py = (float)j, pz = (float)k;
+	int pos[2][3];
+	int numPos = 1;
+	pos[0][0] = (int)(px - vel[0]);
+	pos[0][1] = (int)(py - vel[1]);
+	pos[0][2] = (int)(pz - vel[2]);
+	if (clampMode == 1) {
+		numPos = 2;
+		pos[1][0] = (int)(px + vel[0]);
+		pos[1][1] = (int)(py + vel[1]);
+		pos[1][2] = (int)(pz + vel[2]);
+	}
+	int o[3] = {i, j, k}, nb[3] = {i, j, k};
+	nb[c] -= 1;
+	if (clampMode == 2 && !(CHECKFLAG(flags[IDX(*d, o[0], o[1], o[2])]) && CHECKFLAG(flags[IDX(*d, nb[0], nb[1], nb[2])])))
+		return fwd;
+	const int gx = d->sx - 1, gy = d->sy - 1, gz = d->sz - 1;
+	const float* oc = orig + c * d->n;
+	for (int l = 0; l < numPos; l++) {
+		const int i0 = clampi(pos[l][0], 0, gx - 1);
+		const int j0 = clampi(pos[l][1], 0, gy - 1);
+		const int k0 = clampi(pos[l][2], 0, d->is3d ? (gz - 1) : 0);
+		const int i1 = i0 + 1, j1 = j0 + 1, k1 = d->is3d ? (k0 + 1) : k0;
+		const int ii[8] = {i0, i1, i0, i1, i0, i1, i0, i1};
+		const int jj[8] = {j0, j0, j1, j1, j0, j0, j1, j1};
+		const int kk[8] = {k0, k0, k0, k0, k1, k1, k1, k1};
+		int nc = d->is3d ? 8 : 4;
+		for (int q = 0; q < nc; q++) {
+			float v = oc[IDX(*d, ii[q], jj[q], kk[q])];
+			if (v < minv) minv = v;
+			if (v > maxv) maxv = v;
+		}
+	}
+	if (clampMode == 1)
+		dst = dst < minv ? minv : (dst > maxv ? maxv : dst);
+	else if ((dst < minv) | (dst > maxv))
+		dst = fwd;
+	return dst;
+}
+/* MacCormackClampMAC, advection.cpp:271-288 */
+int mf_maccormack_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* dst,
+                            const float* orig, const float* fwd, float dt, int clampMode, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				float v[3], vd[3];
+				get_at_mac_x(&d, vel, idx, v);
+				vd[0] = v[0] * dt; vd[1] = v[1] * dt; vd[2] = v[2] * dt;
+				float rx = do_clamp_component_mac(&d, 0, flags, dst[idx], orig, fwd[idx], i, j, k, vd, clampMode);
+				get_at_mac_y(&d, vel, idx, v);
+				vd[0] = v[0] * dt; vd[1] = v[1] * dt; vd[2] = v[2] * dt;
+				float ry = do_clamp_component_mac(&d, 1, flags, dst[n + idx], orig, fwd[n + idx], i, j, k, vd, clampMode);
+				float rz = dst[2 * n + idx];
+				if (d.is3d) {
+					get_at_mac_z(&d, vel, idx, v);
+					vd[0] = v[0] * dt; vd[1] = v[1] * dt; vd[2] = v[2] * dt;
+					rz = do_clamp_component_mac(&d, 2, flags, rz, orig, fwd[2 * n + idx], i, j, k, vd, clampMode);
+				}
+				dst[idx] = rx;
+				dst[n + idx] = ry;
+				dst[2 * n + idx] = rz;
+			}
+	return 0;
+}
+
+/* applyOutflowBC, advection.cpp:327-392 */
+static int in_bounds(const Dim* d, int i, int j, int k) { return i >= 0 && j >= 0 && k >= 0 && i < d->sx && j < d->sy && k < d->sz; }
+int mf_apply_outflow_bc(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* velPrev, float* velDst,
+                        float dtIn, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	/* applyOutflowBC takes double timeStep and passes max(1.0, timeStep*4) as Real */
+	const float timeStep = (float)((1.0 > (double)dtIn * 4) ? 1.0 : (double)dtIn * 4);
+#pragma omp parallel for
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_OUTFLOW)) continue;
+				/* getBulkVel, advection.cpp:327-344 */
+				float avg[3] = {0.f, 0.f, 0.f};
+				int count = 0;
+				int nmax = d.is3d ? 1 : 0;
+				for (int nn = -nmax; nn <= nmax; nn++)
+					for (int m = -1; m <= 1; m++)
+						for (int l = -1; l <= 1; l++)
+							if (in_bounds(&d, i + l, j + m, k + nn)) {
+								int64_t q = IDX(d, i + l, j + m, k + nn);
+								if (flags[q] & (MF_FLUID | MF_OUTFLOW)) {
+									avg[0] += vel[q];
+									avg[1] += vel[n + q];
+									avg[2] += vel[2 * n + q];
+									count++;
+								}
+							}
+				if (count > 0) {
+					avg[0] = avg[0] / count;
+					avg[1] = avg[1] / count;
+					avg[2] = avg[2] / count;
+				}
+				int dim = d.is3d ? 3 : 2;
+				int cnt = 0;
+				float acc[3] = {velDst[idx], velDst[n + idx], velDst[2 * n + idx]};
+				for (int c = 0; c < dim; c++) {
+					int low[3] = {i, j, k}, up[3] = {i, j, k}, flLow[3] = {i, j, k}, flUp[3] = {i, j, k};
+					float factor = timeStep * ((float)1.0 > avg[c] ? (float)1.0 : avg[c]);
+					low[c] = flLow[c] = low[c] - 1;
+					up[c] = flUp[c] = up[c] + 1;
+					for (int dd = 0; dd < 2; dd++) {
+						int eL = in_bounds(&d, flLow[0], flLow[1], flLow[2]) && (flags[IDX(d, flLow[0], flLow[1], flLow[2])] & MF_FLUID);
+						int eU = in_bounds(&d, flUp[0], flUp[1], flUp[2]) && (flags[IDX(d, flUp[0], flUp[1], flUp[2])] & MF_FLUID);
+						if (eL || eU) {
+							if (eL) {
+								int64_t q = IDX(d, low[0], low[1], low[2]);
+								for (int e = 0; e < 3; e++) acc[e] += ((vel[e * n + idx] - velPrev[e * n + idx]) / factor) + vel[e * n + q];
+								cnt++;
+							}
+							if (eU) {
+								int64_t q = IDX(d, up[0], up[1], up[2]);
+								for (int e = 0; e < 3; e++) acc[e] += ((vel[e * n + idx] - velPrev[e * n + idx]) / factor) + vel[e * n + q];
+								cnt++;
+							}
+							break;
+						}
+						flLow[c]--;
+						flUp[c]++;
+					}
+				}
+				if (cnt > 0) {
+					float fc = (float)cnt;
+					acc[0] /= fc;
+					acc[1] /= fc;
+					acc[2] /= fc;
+				}
+				velDst[idx] = acc[0];
+				velDst[n + idx] = acc[1];
+				velDst[2 * n + idx] = acc[2];
+			}
+	/* copyChangedVels, advection.cpp:385 */
+#pragma omp parallel for
+	for (int64_t idx = 0; idx < n; idx++)
+		if (flags[idx] & MF_OUTFLOW) {
+			vel[idx] = velDst[idx];
+			vel[n + idx] = velDst[n + idx];
+			vel[2 * n + idx] = velDst[2 * n + idx];
+		}
+	return 0;
+}
+
+/* ================================================================================================
+ * FLIP transfers
+ * ============================================================================================== */
+static inline int skip_particle(const int32_t* pflag, const int32_t* ptype, int exclude, int64_t p) {
+	/* !p.isActive(idx) || (ptype && ((*ptype)[idx] & exclude)), flip.cpp:630 */
+	return (pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude));
+}
+/* setInterpolMAC, interpol.h:166-213: one component plane with its own base index and weights */
+static inline void scatter8(float* ref, float* sum, int64_t Y, int64_t Z, float ta, float tb, float sa, float sb,
+                            float fa, float fb, float val, int zfirst) {
+	const int64_t X = 1;
+	float s0f0 = sa * fa, s1f0 = sb * fa, s0f1 = sa * fb, s1f1 = sb * fb;
+	float w0 = ta * s0f0, wx = ta * s1f0, wy = tb * s0f0, wxy = tb * s1f0;
+	float wz = ta * s0f1, wxz = ta * s1f1, wyz = tb * s0f1, wxyz = tb * s1f1;
+	if (zfirst) { /* X and Y components add the +Z corners first (matters when Z == 0 in 2-D) */
+		sum[Z] += wz; sum[X + Z] += wxz; sum[Y + Z] += wyz; sum[X + Y + Z] += wxyz;
+		ref[Z] += wz * val; ref[X + Z] += wxz * val; ref[Y + Z] += wyz * val; ref[X + Y + Z] += wxyz * val;
+		sum[0] += w0; sum[X] += wx; sum[Y] += wy; sum[X + Y] += wxy;
+		ref[0] += w0 * val; ref[X] += wx * val; ref[Y] += wy * val; ref[X + Y] += wxy * val;
+	} else {
+		sum[0] += w0; sum[X] += wx; sum[Y] += wy; sum[X + Y] += wxy;
+		sum[Z] += wz; sum[X + Z] += wxz; sum[Y + Z] += wyz; sum[X + Y + Z] += wxyz;
+		ref[0] += w0 * val; ref[X] += wx * val; ref[Y] += wy * val; ref[X + Y] += wxy * val;
+		ref[Z] += wz * val; ref[X + Z] += wxz * val; ref[Y + Z] += wyz * val; ref[X + Y + Z] += wxyz * val;
+	}
+}
+/* mapPartsToMAC, flip.cpp:637-661 */
+int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight, int64_t np, int64_t ps,
+                        const float* pos, const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude,
+                        int deterministic, void* st) {
+	(void)st;
+	(void)deterministic;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	memset(weight, 0, sizeof(float) * 3 * n);
+	memset(vel, 0, sizeof(float) * 3 * n);
+	for (int64_t p = 0; p < np; p++) { /* KERNEL(pts, single): particle order, one thread (flip.cpp:619) */
+		if (skip_particle(pflag, ptype, exclude, p)) continue;
+		float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+		Bi b = build_index(&d, x, y, z), s = build_index_shift(&d, x, y, z);
+		int64_t ix = ((int64_t)b.zi * sy + b.yi) * sx + s.xi;
+		scatter8(vel + ix, weight + ix, d.Y, d.Z, b.t0, b.t1, s.s0, s.s1, b.f0, b.f1, pvel[p], 1);
+		int64_t iy = ((int64_t)b.zi * sy + s.yi) * sx + b.xi;
+		scatter8(vel + n + iy, weight + n + iy, d.Y, d.Z, s.t0, s.t1, b.s0, b.s1, b.f0, b.f1, pvel[ps + p], 1);
+		int64_t iz = ((int64_t)s.zi * sy + b.yi) * sx + b.xi;
+		scatter8(vel + 2 * n + iz, weight + 2 * n + iz, d.Y, d.Z, b.t0, b.t1, b.s0, b.s1, s.f0, s.f1, pvel[2 * ps + p], 0);
+	}
+	mf_grid_stomp(3 * n, weight, 1e-6f, st);       /* weight->stomp(Vec3(VECTOR_EPSILON)) */
+	mf_grid_safe_divide(3 * n, vel, weight, st);   /* vel.safeDivide(*weight) */
+	memcpy(velOld, vel, sizeof(float) * 3 * n);    /* velOld.copyFrom(vel) */
+	return 0;
+}
+/* mapMACToParts, flip.cpp:709-721 */
+int mf_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t ps, const float* pos,
+                        const int32_t* pflag, float* pvel, const int32_t* ptype, int exclude, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+#pragma omp parallel for
+	for (int64_t p = 0; p < np; p++) {
+		if (skip_particle(pflag, ptype, exclude, p)) continue;
+		float v[3];
+		interpol_mac(&d, vel, pos[p], pos[ps + p], pos[2 * ps + p], v);
+		pvel[p] = v[0];
+		pvel[ps + p] = v[1];
+		pvel[2 * ps + p] = v[2];
+	}
+	return 0;
+}
+/* flipVelocityUpdate, flip.cpp:724-742: pvel = flipRatio*(v + delta) + (1.0 - flipRatio)*v2 ; the second
+ * scalar is a double, so that product is rounded from fp64 (vectorbase.h:282-284) */
+int mf_flip_velocity_update(int sx, int sy, int sz, const float* vel, const float* velOld, int64_t np, int64_t ps,
+                            const float* pos, const int32_t* pflag, float* pvel, float flipRatio, const int32_t* ptype,
+                            int exclude, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+#pragma omp parallel for
+	for (int64_t p = 0; p < np; p++) {
+		if (skip_particle(pflag, ptype, exclude, p)) continue;
+		float v1[3], v2[3];
+		interpol_mac(&d, velOld, pos[p], pos[ps + p], pos[2 * ps + p], v1);
+		interpol_mac(&d, vel, pos[p], pos[ps + p], pos[2 * ps + p], v2);
+		for (int c = 0; c < 3; c++) {
+			float v = pvel[c * ps + p];
+			float delta = v2[c] - v1[c];
+			float a = flipRatio * (v + delta);
+			float b = (float)((1.0 - flipRatio) * v2[c]);
+			pvel[c * ps + p] = a + b;
+		}
+	}
+	return 0;
+}
+/* mapPartsToGrid(+Vec3), flip.cpp:663-687; setInterpol interpol.h:96-113; knSafeDivReal flip.cpp:607-615 */
+int mf_map_parts_to_grid(int sx, int sy, int sz, int ncomp, float* target, float* wtmp, int64_t np, int64_t ps,
+                         const float* pos, const int32_t* pflag, const float* psrc, int deterministic, void* st) {
+	(void)st;
+	(void)deterministic;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = 1, Y = d.Y, Z = d.Z;
+	memset(target, 0, sizeof(float) * ncomp * n);
+	memset(wtmp, 0, sizeof(float) * n);
+	for (int64_t p = 0; p < np; p++) {
+		if (pflag[p] & MF_PDELETE) continue;
+		Bi b = build_index(&d, pos[p], pos[ps + p], pos[2 * ps + p]);
+		int64_t idx = (int64_t)b.xi + Y * b.yi + Z * b.zi;
+		float s0f0 = b.s0 * b.f0, s1f0 = b.s1 * b.f0, s0f1 = b.s0 * b.f1, s1f1 = b.s1 * b.f1;
+		float w0 = b.t0 * s0f0, wx = b.t0 * s1f0, wy = b.t1 * s0f0, wxy = b.t1 * s1f0;
+		float wz = b.t0 * s0f1, wxz = b.t0 * s1f1, wyz = b.t1 * s0f1, wxyz = b.t1 * s1f1;
+		float* sum = wtmp + idx;
+		sum[Z] += wz; sum[X + Z] += wxz; sum[Y + Z] += wyz; sum[X + Y + Z] += wxyz;
+		for (int c = 0; c < ncomp; c++) {
+			float* ref = target + c * n + idx;
+			float v = psrc[c * ps + p];
+			ref[Z] += wz * v; ref[X + Z] += wxz * v; ref[Y + Z] += wyz * v; ref[X + Y + Z] += wxyz * v;
+		}
+		sum[0] += w0; sum[X] += wx; sum[Y] += wy; sum[X + Y] += wxy;
+		for (int c = 0; c < ncomp; c++) {
+			float* ref = target + c * n + idx;
+			float v = psrc[c * ps + p];
+			ref[0] += w0 * v; ref[X] += wx * v; ref[Y] += wy * v; ref[X + Y] += wxy * v;
+		}
+	}
+#pragma omp parallel for
+	for (int64_t idx = 0; idx < n; idx++) {
+		if (wtmp[idx] < 1e-6f) {
+			for (int c = 0; c < ncomp; c++) target[c * n + idx] = 0.;
+		} else {
+			float dv = wtmp[idx];
+			for (int c = 0; c < ncomp; c++) target[c * n + idx] = (dv) ? (target[c * n + idx] / dv) : target[c * n + idx];
+		}
+	}
+	return 0;
+}
+/* mapGridToParts(+Vec3), flip.cpp:693-704 */
+int mf_map_grid_to_parts(int sx, int sy, int sz, int ncomp, const float* source, int64_t np, int64_t ps,
+                         const float* pos, const int32_t* pflag, float* ptarget, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+#pragma omp parallel for
+	for (int64_t p = 0; p < np; p++) {
+		if (pflag[p] & MF_PDELETE) continue;
+		for (int c = 0; c < ncomp; c++) ptarget[c * ps + p] = interpol1(&d, source + c * d.n, pos[p], pos[ps + p], pos[2 * ps + p]);
+	}
+	return 0;
+}
+
+/* GridBase::isInBounds(Vec3, bnd) -> toVec3i truncation, grid.h:65, 430-438 */
+static inline int in_bounds_pos(const Dim* d, float x, float y, float z, int bnd) {
+	int i = (int)x, j = (int)y, k = (int)z;
+	int r = i >= bnd && j >= bnd && i < d->sx - bnd && j < d->sy - bnd;
+	if (d->is3d)
+		r &= (k >= bnd && k < d->sz - bnd);
+	else
+		r &= (k == 0);
+	return r;
+}
+static inline int flag_at(const Dim* d, const int32_t* flags, float x, float y, float z) { /* FlagGrid::getAt, grid.h:324 */
+	return flags[IDX(*d, (int)x, (int)y, (int)z)];
+}
+/* GridAdvectKernel, particle.h:458-481 */
+static void grid_advect_kernel(const Dim* d, const int32_t* flags, const float* vel, int64_t np, int64_t ps,
+                               const float* pos, int32_t* pflag, float dt, int deleteInObstacle, int stopInObstacle,
+                               int skipNew, const int32_t* ptype, int exclude, float* u) {
+#pragma omp parallel for
+	for (int64_t p = 0; p < np; p++) {
+		if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude)) || (skipNew && (pflag[p] & MF_PNEW))) {
+			u[p] = u[ps + p] = u[2 * ps + p] = 0.;
+			continue;
+		}
+		float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+		if (deleteInObstacle || stopInObstacle) {
+			if (!in_bounds_pos(d, x, y, z, 1) || (flag_at(d, flags, x, y, z) & MF_OBSTACLE)) {
+				if (stopInObstacle) u[p] = u[ps + p] = u[2 * ps + p] = 0.;
+				if (deleteInObstacle) pflag[p] |= MF_PDELETE;
+				continue;
+			}
+		}
+		float v[3];
+		interpol_mac(d, vel, x, y, z, v);
+		u[p] = v[0] * dt;
+		u[ps + p] = v[1] * dt;
+		u[2 * ps + p] = v[2] * dt;
+	}
+}
+/* ParticleSystem::advectInGrid, particle.h:526-550 + integratePointSet, util/integrator.h:26-78 */
+int mf_advect_in_grid(int sx, int sy, int sz, const int32_t* flags, const float* vel, int64_t np, int64_t ps,
+                      float* pos, int32_t* pflag, float dt, int mode, int deleteInObstacle, int stopInObstacle,
+                      int skipNew, const int32_t* ptype, int exclude, float* scratch, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	float *x0 = scratch, *u = scratch + 3 * ps, *ut = scratch + 6 * ps;
+	for (int c = 0; c < 3; c++) memcpy(x0 + c * ps, pos + c * ps, sizeof(float) * np); /* posOld / PosType x0(x) */
+	for (int c = 0; c < 3; c++) memset(u + c * ps, 0, sizeof(float) * np);             /* returns(vector<Vec3> u(size)) */
+#define RUN() grid_advect_kernel(&d, flags, vel, np, ps, pos, pflag, dt, deleteInObstacle, stopInObstacle, skipNew, ptype, exclude, u)
+	RUN();
+	if (mode == MF_INT_EULER) {
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) pos[c * ps + p] += u[c * ps + p];
+	} else if (mode == MF_INT_RK2) {
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) pos[c * ps + p] = x0[c * ps + p] + (float)(0.5 * u[c * ps + p]);
+		RUN();
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) pos[c * ps + p] = x0[c * ps + p] + u[c * ps + p];
+	} else if (mode == MF_INT_RK4) {
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) {
+				int64_t q = c * ps + p;
+				ut[q] = u[q];
+				pos[q] = x0[q] + (float)(0.5 * u[q]);
+				ut[q] += u[q]; /* the fork's extra accumulation, integrator.h:55 */
+			}
+		RUN();
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) {
+				int64_t q = c * ps + p;
+				pos[q] = x0[q] + (float)(0.5 * u[q]);
+				ut[q] += 2 * u[q];
+			}
+		RUN();
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) {
+				int64_t q = c * ps + p;
+				pos[q] = x0[q] + u[q];
+				ut[q] += 2 * u[q];
+			}
+		RUN();
+		for (int c = 0; c < 3; c++)
+			for (int64_t p = 0; p < np; p++) {
+				int64_t q = c * ps + p;
+				pos[q] = x0[q] + (float)(1. / 6.) * (ut[q] + u[q]);
+			}
+	} else
+		return fail("unknown integration type");
+#undef RUN
+	if (!deleteInObstacle) {
+		/* KnClampPositions, particle.h:507-523 */
+		const float hi[3] = {(float)sx - 1.f, (float)sy - 1.f, (float)sz - 1.f};
+#pragma omp parallel for
+		for (int64_t p = 0; p < np; p++) {
+			if (pflag[p] & MF_PDELETE) continue;
+			if (ptype && (ptype[p] & exclude)) {
+				for (int c = 0; c < 3; c++) pos[c * ps + p] = x0[c * ps + p];
+				continue;
+			}
+			float q[3] = {pos[p], pos[ps + p], pos[2 * ps + p]};
+			if (!in_bounds_pos(&d, q[0], q[1], q[2], 0))
+				for (int c = 0; c < 3; c++) q[c] = q[c] < 0.f ? 0.f : (q[c] > hi[c] ? hi[c] : q[c]);
+			if (stopInObstacle && (flag_at(&d, flags, q[0], q[1], q[2]) & MF_OBSTACLE)) {
+				/* bisectBacktracePos, particle.h:494-504 */
+				const float o[3] = {x0[p], x0[ps + p], x0[2 * ps + p]};
+				float s = 0.;
+				for (int i = 1; i < 5; ++i) {
+					float ds = 1. / (float)(1 << i);
+					float a = (float)(1. - (s + ds)), b = s + ds;
+					float tx = (float)(o[0] * (1. - (s + ds))) + q[0] * b;
+					float ty = (float)(o[1] * (1. - (s + ds))) + q[1] * b;
+					float tz = (float)(o[2] * (1. - (s + ds))) + q[2] * b;
+					(void)a;
+					if (!(flag_at(&d, flags, tx, ty, tz) & MF_OBSTACLE)) s += ds;
+				}
+				for (int c = 0; c < 3; c++) q[c] = (float)(o[c] * (1. - (s))) + q[c] * (s);
+			}
+			pos[p] = q[0];
+			pos[ps + p] = q[1];
+			pos[2 * ps + p] = q[2];
+		}
+	} else {
+		/* KnDeleteInObstacle, particle.h:485-491 */
+#pragma omp parallel for
+		for (int64_t p = 0; p < np; p++) {
+			if (pflag[p] & MF_PDELETE) continue;
+			float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+			if (!in_bounds_pos(&d, x, y, z, 1) || (flag_at(&d, flags, x, y, z) & MF_OBSTACLE)) pflag[p] |= MF_PDELETE;
+		}
+	}
+	return 0;
+}
+
+/* ================================================================================================
+ * glue: setWallBcs / addBuoyancy / addGravity kernels, plugin/extforces.cpp
+ * ============================================================================================== */
+/* KnSetWallBcs, extforces.cpp:187-237 (KERNEL(): all cells) */
+int mf_set_wall_bcs(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* obvel, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+#pragma omp parallel for
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				int f = flags[idx];
+				int curFluid = f & MF_FLUID, curObs = f & MF_OBSTACLE;
+				float bx = 0.f, by = 0.f, bz = 0.f;
+				if (!curFluid && !curObs) continue;
+				if (obvel) {
+					bx = obvel[idx];
+					by = obvel[n + idx];
+					if (d.is3d) bz = obvel[2 * n + idx];
+				}
+				if (i > 0 && (flags[idx - X] & MF_OBSTACLE)) vx[idx] = bx;
+				if (i > 0 && curObs && (flags[idx - X] & MF_FLUID)) vx[idx] = bx;
+				if (j > 0 && (flags[idx - Y] & MF_OBSTACLE)) vy[idx] = by;
+				if (j > 0 && curObs && (flags[idx - Y] & MF_FLUID)) vy[idx] = by;
+				if (!d.is3d) {
+					vz[idx] = 0;
+				} else {
+					if (k > 0 && (flags[idx - Z] & MF_OBSTACLE)) vz[idx] = bz;
+					if (k > 0 && curObs && (flags[idx - Z] & MF_FLUID)) vz[idx] = bz;
+				}
+				if (curFluid) {
+					if ((i > 0 && (flags[idx - X] & MF_STICK)) || (i < sx - 1 && (flags[idx + X] & MF_STICK))) vy[idx] = vz[idx] = 0;
+					if ((j > 0 && (flags[idx - Y] & MF_STICK)) || (j < sy - 1 && (flags[idx + Y] & MF_STICK))) vx[idx] = vz[idx] = 0;
+					if (d.is3d && ((k > 0 && (flags[idx - Z] & MF_STICK)) || (k < sz - 1 && (flags[idx + Z] & MF_STICK))))
+						vx[idx] = vy[idx] = 0;
+				}
+			}
+	return 0;
+}
+/* KnAddBuoyancy, extforces.cpp:73-81: vel += (0.5*strength) * (f + f) evaluated in fp64 */
+int mf_add_buoyancy(int sx, int sy, int sz, const int32_t* flags, const float* fac, float* vel, float fx, float fy,
+                    float fz, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				if (flags[idx - X] & MF_FLUID) vx[idx] += (0.5 * fx) * (fac[idx] + fac[idx - X]);
+				if (flags[idx - Y] & MF_FLUID) vy[idx] += (0.5 * fy) * (fac[idx] + fac[idx - Y]);
+				if (d.is3d && (flags[idx - Z] & MF_FLUID)) vz[idx] += (0.5 * fz) * (fac[idx] + fac[idx - Z]);
+			}
+	return 0;
+}
+/* KnApplyForce, extforces.cpp:46-60 */
+int mf_apply_force(int sx, int sy, int sz, const int32_t* flags, float* vel, float fx, float fy, float fz,
+                   const float* exclude, int additive, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, X = d.X, Y = d.Y, Z = d.Z;
+	float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+#pragma omp parallel for
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				int curFluid = flags[idx] & MF_FLUID, curEmpty = flags[idx] & MF_EMPTY;
+				if (!curFluid && !curEmpty) continue;
+				if (exclude && (exclude[idx] < 0.)) continue;
+				if ((flags[idx - X] & MF_FLUID) || (curFluid && (flags[idx - X] & MF_EMPTY))) vx[idx] = additive ? vx[idx] + fx : fx;
+				if ((flags[idx - Y] & MF_FLUID) || (curFluid && (flags[idx - Y] & MF_EMPTY))) vy[idx] = additive ? vy[idx] + fy : fy;
+				if (d.is3d && ((flags[idx - Z] & MF_FLUID) || (curFluid && (flags[idx - Z] & MF_EMPTY))))
+					vz[idx] = additive ? vz[idx] + fz : fz;
+			}
+	return 0;
+}
+
+int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                         const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* st) {
+	(void)sx; (void)sy; (void)sz; (void)flags; (void)dst; (void)src; (void)A0; (void)Ai; (void)Aj; (void)Ak; (void)reps;
+	(void)avg_us; (void)st;
+	return fail("mf_time_apply_matrix: HIP only");
+}

@@ -1,0 +1,357 @@
+"""Parity cases: each case builds seeded inputs (numpy), runs them through
+   - `ref`  : the compiled reference behind oracle/ref_shim.cpp (host arrays), and
+   - `pkg`  : the package's host layer (mantaflow_amd.core/plugins) on whatever ABI library is active
+              (the oracle restatement in CPU tests, the HIP library in -m gpu tests), or a raw util.Impl,
+and returns dicts of numpy outputs that the tests compare bit for bit."""
+import ctypes
+
+import numpy as np
+import torch
+
+import util
+from util import P, refcall
+
+SIZES_3D = [(12, 10, 9), (16, 16, 16), (20, 13, 11)]
+SIZE_2D = (24, 18, 1)
+
+
+def soa_to_grid(g, arr):
+    """numpy SoA [ncomp][sz][sy][sx] (or [sz][sy][sx]) -> package grid storage"""
+    g.data.copy_(torch.from_numpy(np.ascontiguousarray(arr).reshape(-1)).to(g.data.device))
+    return g
+
+
+def grid_to_soa(g):
+    a = g.data.detach().cpu().numpy().copy()
+    return a.reshape((g._ncomp, g.sz, g.sy, g.sx)) if g._ncomp == 3 else a.reshape((g.sz, g.sy, g.sx))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# kernel-level cases (raw ABI through util.Impl)
+# ---------------------------------------------------------------------------------------------------------
+def laplace_inputs(dims, seed, fractions=False):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=(seed % 2 == 1))
+    fr = None
+    if fractions:
+        fr = np.random.default_rng(seed + 5).uniform(0, 1, (3, sz, sy, sx)).astype(np.float32)
+    return flags, fr
+
+
+def run_laplace_impl(impl, dims, flags, fr):
+    sx, sy, sz = dims
+    A = [impl.dev(np.zeros((sz, sy, sx), np.float32)) for _ in range(4)]
+    impl.call("mf_make_laplace_matrix", sx, sy, sz, impl.dev(flags), A[0], A[1], A[2], A[3], impl.dev(fr), None)
+    impl.sync()
+    return [impl.host(a) for a in A]
+
+
+def run_laplace_ref(dims, flags, fr):
+    sx, sy, sz = dims
+    A = [np.zeros((sz, sy, sx), np.float32) for _ in range(4)]
+    refcall("ref_make_laplace_matrix", sx, sy, sz, flags, A[0], A[1], A[2], A[3], fr)
+    return A
+
+
+def system_inputs(dims, seed):
+    """flags + Laplace matrix (built by the reference when available, else by the oracle) + random src"""
+    sx, sy, sz = dims
+    flags, _ = laplace_inputs(dims, seed)
+    if util.have_ref():
+        A = run_laplace_ref(dims, flags, None)
+    else:
+        A = run_laplace_impl(util.Impl("oracle"), dims, flags, None)
+    src = util.rand_real((sz, sy, sx), seed + 11)
+    return flags, A, src
+
+
+def run_apply_matrix_impl(impl, dims, flags, A, src):
+    sx, sy, sz = dims
+    dst = impl.dev(np.full((sz, sy, sx), 7.0, np.float32))
+    impl.call("mf_apply_matrix", sx, sy, sz, impl.dev(flags), dst, impl.dev(src), *[impl.dev(a) for a in A], None)
+    impl.sync()
+    return impl.host(dst)
+
+
+def run_apply_matrix_ref(dims, flags, A, src):
+    sx, sy, sz = dims
+    dst = np.full((sz, sy, sx), 7.0, np.float32)
+    refcall("ref_apply_matrix", sx, sy, sz, flags, dst, src, *A)
+    return dst
+
+
+def run_mic_impl(impl, dims, flags, A, var1):
+    sx, sy, sz = dims
+    ap = impl.dev(np.full((sz, sy, sx), 3.0, np.float32))
+    dA = [impl.dev(a) for a in A]
+    f = impl.dev(flags)
+    impl.call("mf_mic_init", sx, sy, sz, f, ap, dA[0], dA[1], dA[2], dA[3], None)
+    dst = impl.dev(np.zeros((sz, sy, sx), np.float32))
+    impl.call("mf_mic_apply", sx, sy, sz, f, dst, impl.dev(var1), ap, dA[1], dA[2], dA[3], None)
+    impl.sync()
+    return impl.host(ap), impl.host(dst)
+
+
+def run_mic_ref(dims, flags, A, var1):
+    sx, sy, sz = dims
+    ap = np.full((sz, sy, sx), 3.0, np.float32)
+    refcall("ref_mic_init", sx, sy, sz, flags, ap, *A)
+    dst = np.zeros((sz, sy, sx), np.float32)
+    refcall("ref_mic_apply", sx, sy, sz, flags, dst, var1, ap, *A)
+    return ap, dst
+
+
+def cg_rhs(dims, flags, seed):
+    sx, sy, sz = dims
+    rhs = util.rand_real((sz, sy, sx), seed + 23)
+    rhs[(flags & util.FLUID) == 0] = 0
+    return rhs
+
+
+def run_cg_impl(impl, dims, flags, A, rhs, pc, accuracy, maxIter, useL2=0):
+    sx, sy, sz = dims
+    z = lambda: impl.dev(np.zeros((sz, sy, sx), np.float32))
+    dst, residual, search, tmp, ap = z(), z(), z(), z(), z()
+    out = (ctypes.c_float * 3)()
+    impl.call("mf_cg_solve", sx, sy, sz, impl.dev(flags), dst, impl.dev(rhs), residual, search, tmp,
+              *[impl.dev(a) for a in A], ap, pc, accuracy, maxIter, useL2, out, None)
+    impl.sync()
+    return impl.host(dst), (int(out[0]), float(out[1]), float(out[2]))
+
+
+def run_cg_ref(dims, flags, A, rhs, pc, accuracy, maxIter, useL2=0):
+    sx, sy, sz = dims
+    z = lambda: np.zeros((sz, sy, sx), np.float32)
+    dst, residual, search, tmp, ap = z(), z(), z(), z(), z()
+    out = np.zeros(3, np.float32)
+    refcall("ref_cg_solve", sx, sy, sz, flags, dst, rhs, residual, search, tmp, *A, ap, pc, ctypes.c_float(accuracy), maxIter, useL2, out)
+    return dst, (int(out[0]), float(out[1]), float(out[2]))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# plugin-level cases (package host layer vs reference plugins)
+# ---------------------------------------------------------------------------------------------------------
+def _mk_solver(dims, dt=1.0):
+    from mantaflow_amd import core
+    sx, sy, sz = dims
+    s = core.Solver(gridSize=core.vec3(sx, sy, sz), dim=3 if sz > 1 else 2)
+    s.timestep = dt
+    return s
+
+
+def pressure_inputs(dims, seed, liquid=False):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=liquid)
+    vel = util.rand_vel(sx, sy, sz, seed + 3, 0.5)
+    phi = None
+    if liquid:
+        # a smooth level set that is negative in fluid cells and positive in empty ones
+        zz, yy, xx = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+        phi = (yy - (2 * sy) // 3 + 0.3 + 0.2 * np.sin(xx * 0.7)).astype(np.float32)
+    return flags, vel, phi
+
+
+def run_solve_pressure_pkg(dims, flags, vel, phi, **kw):
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims)
+    fl, v, p = core.FlagGrid(s), core.MACGrid(s), core.Grid(s)
+    soa_to_grid(fl, flags); soa_to_grid(v, vel)
+    ph = soa_to_grid(core.LevelsetGrid(s), phi) if phi is not None else None
+    rr = core.Grid(s)
+    plugins.solvePressure(v, p, fl, phi=ph, retRhs=rr, **kw)
+    s.sync()
+    return dict(vel=grid_to_soa(v), pressure=grid_to_soa(p), rhs=grid_to_soa(rr), stats=plugins.lastCgStats())
+
+
+def run_solve_pressure_ref(dims, flags, vel, phi, cgAccuracy=1e-3, cgMaxIterFac=1.5, enforceCompatibility=False,
+                           useL2Norm=False, zeroPressureFixing=False, gfClamp=1e-4):
+    sx, sy, sz = dims
+    v = vel.copy()
+    p = np.zeros((sz, sy, sx), np.float32)
+    rr = np.zeros((sz, sy, sx), np.float32)
+    refcall("ref_solve_pressure", sx, sy, sz, v, p, flags, ctypes.c_float(cgAccuracy), phi, None, None, None,
+            ctypes.c_float(gfClamp), ctypes.c_float(cgMaxIterFac), 1, 1, int(enforceCompatibility), int(useL2Norm),
+            int(zeroPressureFixing), None, ctypes.c_float(0.0), rr)
+    return dict(vel=v, pressure=p, rhs=rr)
+
+
+def advect_inputs(dims, seed, vmax=2.5, outflow=False):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=True, outflow=outflow)
+    vel = util.smooth_vel(sx, sy, sz, seed + 1, vmax)
+    return flags, vel
+
+
+def run_advect_pkg(dims, dt, flags, vel, field, kind, **kw):
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims, dt)
+    fl, v = core.FlagGrid(s), core.MACGrid(s)
+    soa_to_grid(fl, flags); soa_to_grid(v, vel)
+    G = {0: core.Grid, 1: core.VecGrid, 2: core.MACGrid, 3: core.LevelsetGrid}[kind]
+    g = soa_to_grid(G(s), field)
+    plugins.advectSemiLagrange(fl, v, g, **kw)
+    s.sync()
+    return grid_to_soa(g)
+
+
+def run_advect_ref(dims, dt, flags, vel, field, kind, order=1, strength=1.0, orderSpace=1, clampMode=2, orderTrace=1):
+    sx, sy, sz = dims
+    g = field.copy()
+    refcall("ref_advect_semi_lagrange", sx, sy, sz, ctypes.c_float(dt), flags, vel, g, kind, order, ctypes.c_float(strength),
+            orderSpace, clampMode, orderTrace)
+    return g
+
+
+def _mk_parts(s, pos, pflag):
+    from mantaflow_amd import core
+    pp = core.BasicParticleSystem(s)
+    pp.resizeAll(pos.shape[1])
+    for c in range(3):
+        pp.pos[c * pp.cap:c * pp.cap + pp.np] = torch.from_numpy(pos[c]).to(pp.pos.device)
+    pp.flag[:pp.np] = torch.from_numpy(pflag).to(pp.flag.device)
+    return pp
+
+
+def _pd_vec3(s, pp, arr):
+    from mantaflow_amd import core
+    pd = pp.create(core.PdataVec3)
+    for c in range(3):
+        pd.data[c * pd.cap:c * pd.cap + pp.np] = torch.from_numpy(arr[c]).to(pd.data.device)
+    return pd
+
+
+def _pd_get(pd, n):
+    a = pd.data.detach().cpu().numpy()
+    return np.stack([a[c * pd.cap:c * pd.cap + n] for c in range(pd._ncomp)], 0) if pd._ncomp == 3 else a[:n].copy()
+
+
+def run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype=None, exclude=0, deterministic=True):
+    """mapPartsToMAC -> (vel, velOld, weight); mapMACToParts; flipVelocityUpdate; mapPartsToGrid(+Vec3); mapGridToParts"""
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims)
+    plugins.setDeterministicP2G(deterministic)
+    fl = soa_to_grid(core.FlagGrid(s), flags)
+    pp = _mk_parts(s, pos, pflag)
+    pv = _pd_vec3(s, pp, pvel)
+    pt = None
+    if ptype is not None:
+        pt = pp.create(core.PdataInt)
+        pt.data[:pp.np] = torch.from_numpy(ptype).to(pt.data.device)
+    out = {}
+    v, vo, w = core.MACGrid(s), core.MACGrid(s), core.VecGrid(s)
+    soa_to_grid(v, util.rand_vel(*dims, 99)); soa_to_grid(w, util.rand_vel(*dims, 98))     # must be cleared by the plugin
+    plugins.mapPartsToMAC(fl, v, vo, pp, pv, w, ptype=pt, exclude=exclude)
+    out["p2g_vel"], out["p2g_velOld"], out["p2g_weight"] = grid_to_soa(v), grid_to_soa(vo), grid_to_soa(w)
+    gv, gvo = soa_to_grid(core.MACGrid(s), vel), soa_to_grid(core.MACGrid(s), velOld)
+    pv2 = _pd_vec3(s, pp, pvel)
+    plugins.mapMACToParts(fl, gv, pp, pv2, ptype=pt, exclude=exclude)
+    out["pic"] = _pd_get(pv2, pp.np)
+    pv3 = _pd_vec3(s, pp, pvel)
+    plugins.flipVelocityUpdate(fl, gv, gvo, pp, pv3, 0.97, ptype=pt, exclude=exclude)
+    out["flip"] = _pd_get(pv3, pp.np)
+    tgt = core.Grid(s)
+    ps = pp.create(core.PdataReal)
+    ps.data[:pp.np] = torch.from_numpy(pvel[0]).to(ps.data.device)
+    plugins.mapPartsToGrid(fl, tgt, pp, ps)
+    out["p2g_real"] = grid_to_soa(tgt)
+    tv = core.VecGrid(s)
+    plugins.mapPartsToGridVec3(fl, tv, pp, pv)
+    out["p2g_vec3"] = grid_to_soa(tv)
+    pr = pp.create(core.PdataReal)
+    plugins.mapGridToParts(soa_to_grid(core.Grid(s), vel[0]), pp, pr)
+    out["g2p_real"] = _pd_get(pr, pp.np)
+    pv4 = _pd_vec3(s, pp, pvel)
+    plugins.mapGridToPartsVec3(soa_to_grid(core.VecGrid(s), vel), pp, pv4)
+    out["g2p_vec3"] = _pd_get(pv4, pp.np)
+    s.sync()
+    plugins.setDeterministicP2G(False)
+    return out
+
+
+def run_flip_ref(dims, flags, vel, velOld, pos, pflag, pvel, ptype=None, exclude=0):
+    sx, sy, sz = dims
+    n = pos.shape[1]
+    out = {}
+    v, vo, w = util.rand_vel(*dims, 99), np.zeros((3, sz, sy, sx), np.float32), util.rand_vel(*dims, 98)
+    refcall("ref_map_parts_to_mac", sx, sy, sz, flags, v, vo, w, n, n, pos, pflag, pvel, ptype, exclude)
+    out["p2g_vel"], out["p2g_velOld"], out["p2g_weight"] = v, vo, w
+    pv2 = pvel.copy()
+    refcall("ref_map_mac_to_parts", sx, sy, sz, flags, vel, n, n, pos, pflag, pv2, ptype, exclude)
+    out["pic"] = pv2
+    pv3 = pvel.copy()
+    refcall("ref_flip_velocity_update", sx, sy, sz, flags, vel, velOld, n, n, pos, pflag, pv3, ctypes.c_float(0.97), ptype, exclude)
+    out["flip"] = pv3
+    tgt = np.zeros((sz, sy, sx), np.float32)
+    refcall("ref_map_parts_to_grid", sx, sy, sz, 1, flags, tgt, n, n, pos, pflag, np.ascontiguousarray(pvel[0]))
+    out["p2g_real"] = tgt
+    tv = np.zeros((3, sz, sy, sx), np.float32)
+    refcall("ref_map_parts_to_grid", sx, sy, sz, 3, flags, tv, n, n, pos, pflag, pvel)
+    out["p2g_vec3"] = tv
+    pr = np.zeros(n, np.float32)
+    refcall("ref_map_grid_to_parts", sx, sy, sz, 1, np.ascontiguousarray(vel[0]), n, n, pos, pflag, pr)
+    out["g2p_real"] = pr
+    pv4 = pvel.copy()
+    refcall("ref_map_grid_to_parts", sx, sy, sz, 3, vel, n, n, pos, pflag, pv4)
+    out["g2p_vec3"] = pv4
+    return out
+
+
+def run_advect_parts_pkg(dims, dt, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle=True, skipNew=False,
+                         ptype=None, exclude=0):
+    from mantaflow_amd import core
+    s = _mk_solver(dims, dt)
+    fl, v = soa_to_grid(core.FlagGrid(s), flags), soa_to_grid(core.MACGrid(s), vel)
+    pp = _mk_parts(s, pos, pflag)
+    pt = None
+    if ptype is not None:
+        pt = pp.create(core.PdataInt)
+        pt.data[:pp.np] = torch.from_numpy(ptype).to(pt.data.device)
+    pp.advectInGrid(fl, v, mode, deleteInObstacle=deleteInObstacle, stopInObstacle=stopInObstacle, skipNew=skipNew,
+                    ptype=pt, exclude=exclude)
+    s.sync()
+    a = pp.pos.detach().cpu().numpy()
+    return np.stack([a[c * pp.cap:c * pp.cap + pp.np] for c in range(3)], 0), pp.flag[:pp.np].cpu().numpy().copy()
+
+
+def run_advect_parts_ref(dims, dt, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle=True, skipNew=False,
+                         ptype=None, exclude=0):
+    sx, sy, sz = dims
+    p, f = pos.copy(), pflag.copy()
+    n = p.shape[1]
+    refcall("ref_advect_in_grid", sx, sy, sz, flags, vel, n, n, p, f, ctypes.c_float(dt), mode, int(deleteInObstacle),
+            int(stopInObstacle), int(skipNew), ptype, exclude)
+    return p, f
+
+
+def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims, dt)
+    fl = soa_to_grid(core.FlagGrid(s), flags)
+    out = {}
+    v = soa_to_grid(core.MACGrid(s), vel)
+    plugins.setWallBcs(fl, v, obvel=None if obvel is None else soa_to_grid(core.MACGrid(s), obvel))
+    out["wall"] = grid_to_soa(v)
+    v = soa_to_grid(core.MACGrid(s), vel)
+    plugins.addBuoyancy(fl, soa_to_grid(core.Grid(s), density), v, core.vec3(0.1, -4e-3, 0.02))
+    out["buoy"] = grid_to_soa(v)
+    v = soa_to_grid(core.MACGrid(s), vel)
+    plugins.addGravity(fl, v, core.vec3(0.0, -0.003, 0.001))
+    out["grav"] = grid_to_soa(v)
+    s.sync()
+    return out
+
+
+def run_glue_ref(dims, dt, flags, vel, density, obvel=None):
+    sx, sy, sz = dims
+    out = {}
+    v = vel.copy()
+    refcall("ref_set_wall_bcs", sx, sy, sz, flags, v, obvel)
+    out["wall"] = v
+    v = vel.copy()
+    cf = ctypes.c_float
+    refcall("ref_add_buoyancy", sx, sy, sz, cf(dt), flags, density, v, cf(0.1), cf(-4e-3), cf(0.02), cf(1.0), 1)
+    out["buoy"] = v
+    v = vel.copy()
+    refcall("ref_add_gravity", sx, sy, sz, cf(dt), flags, v, cf(0.0), cf(-0.003), cf(0.001), None, 1)
+    out["grav"] = v
+    return out

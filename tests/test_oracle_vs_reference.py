@@ -1,0 +1,201 @@
+"""Pins the plain-C oracle restatement (oracle/manta_oracle.c) and the package's host orchestration against the
+reference's own compiled C++ (oracle/_ref/libmanta_ref.so, built by oracle/ref.mk).  Bit-exact everywhere."""
+import numpy as np
+import pytest
+
+import cases
+import util
+from util import assert_bitexact
+
+pytestmark = pytest.mark.skipif(not util.have_ref(), reason="compiled reference (oracle/_ref) not present")
+
+DIMS = cases.SIZES_3D + [cases.SIZE_2D]
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("fractions", [False, True])
+def test_make_laplace_matrix(oracle, dims, fractions):
+    flags, fr = cases.laplace_inputs(dims, 3, fractions)
+    a = cases.run_laplace_impl(oracle, dims, flags, fr)
+    b = cases.run_laplace_ref(dims, flags, fr)
+    for x, y, nm in zip(a, b, ("A0", "Ai", "Aj", "Ak")):
+        assert_bitexact(x, y, nm)
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_apply_matrix(oracle, dims, seed):
+    flags, A, src = cases.system_inputs(dims, seed)
+    assert_bitexact(cases.run_apply_matrix_impl(oracle, dims, flags, A, src), cases.run_apply_matrix_ref(dims, flags, A, src), "ApplyMatrix")
+
+
+@pytest.mark.parametrize("dims", cases.SIZES_3D)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_mic(oracle, dims, seed):
+    flags, A, src = cases.system_inputs(dims, seed)
+    ap, dst = cases.run_mic_impl(oracle, dims, flags, A, src)
+    ap_r, dst_r = cases.run_mic_ref(dims, flags, A, src)
+    assert_bitexact(ap, ap_r, "Aprecond")
+    assert_bitexact(dst, dst_r, "mic apply")
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("pc,acc,iters", [(2, 1e-3, 60), (2, 1e-1, 60), (2, 1e-9, 3), (0, 1e-3, 80)])
+def test_cg_solve(oracle, dims, pc, acc, iters):
+    flags, A, _ = cases.system_inputs(dims, 5)   # odd seed: empty band on top -> SPD system, CG converges
+    rhs = cases.cg_rhs(dims, flags, 5)
+    x, st = cases.run_cg_impl(oracle, dims, flags, A, rhs, pc, acc, iters)
+    xr, str_ = cases.run_cg_ref(dims, flags, A, rhs, pc, acc, iters)
+    assert st[0] == str_[0], (st, str_)
+    assert_bitexact(x, xr, "cg solution")
+    assert_bitexact(np.float32(st[1:]), np.float32(str_[1:]), "resNorm/sigma")
+
+
+def test_cg_l2norm(oracle):
+    dims = (16, 16, 16)
+    flags, A, _ = cases.system_inputs(dims, 5)
+    rhs = cases.cg_rhs(dims, flags, 5)
+    x, st = cases.run_cg_impl(oracle, dims, flags, A, rhs, 2, 1e-4, 50, useL2=1)
+    xr, str_ = cases.run_cg_ref(dims, flags, A, rhs, 2, 1e-4, 50, useL2=1)
+    assert st[0] == str_[0]
+    assert_bitexact(x, xr, "cg solution (L2 norm)")
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("liquid", [False, True])
+def test_solve_pressure(oracle_backend, dims, liquid):
+    flags, vel, phi = cases.pressure_inputs(dims, 6, liquid)
+    a = cases.run_solve_pressure_pkg(dims, flags, vel, phi)
+    b = cases.run_solve_pressure_ref(dims, flags, vel, phi)
+    for k in ("rhs", "pressure", "vel"):
+        assert_bitexact(a[k], b[k], "solvePressure " + k)
+
+
+def test_solve_pressure_options(oracle_backend):
+    dims = (14, 12, 10)
+    flags, vel, phi = cases.pressure_inputs(dims, 8, False)
+    kw = dict(cgAccuracy=1e-5, cgMaxIterFac=3.0, enforceCompatibility=True, zeroPressureFixing=True)
+    a = cases.run_solve_pressure_pkg(dims, flags, vel, phi, **kw)
+    b = cases.run_solve_pressure_ref(dims, flags, vel, phi, **kw)
+    for k in ("rhs", "pressure", "vel"):
+        assert_bitexact(a[k], b[k], "solvePressure(options) " + k)
+
+
+def test_solve_pressure_pcnone_raises(oracle_backend):
+    """the reference asserts for PcNone / precondition=False (SURVEY intro item 1)"""
+    dims = (10, 10, 10)
+    flags, vel, phi = cases.pressure_inputs(dims, 8, False)
+    with pytest.raises(RuntimeError, match="Invalid method specified"):
+        cases.run_solve_pressure_pkg(dims, flags, vel, phi, preconditioner=0)
+    with pytest.raises(RuntimeError, match="Invalid method specified"):
+        cases.run_solve_pressure_pkg(dims, flags, vel, phi, precondition=False)
+
+
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("order,clampMode", [(1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("orderTrace", [1, 2])
+def test_advect(oracle_backend, dims, kind, order, clampMode, orderTrace):
+    sx, sy, sz = dims
+    flags, vel = cases.advect_inputs(dims, 9, vmax=2.5, outflow=(kind == 2))
+    field = util.rand_real((sz, sy, sx), 10) if kind == 0 else util.rand_vel(sx, sy, sz, 10)
+    if kind == 1 and sz == 1:
+        field[2] = util.rand_real((sz, sy, sx), 12)
+    kw = dict(order=order, clampMode=clampMode, orderTrace=orderTrace, strength=0.8 if order == 2 else 1.0)
+    a = cases.run_advect_pkg(dims, 0.9, flags, vel, field, kind, **kw)
+    b = cases.run_advect_ref(dims, 0.9, flags, vel, field, kind, **kw)
+    assert_bitexact(a, b, "advectSemiLagrange kind=%d" % kind)
+
+
+def test_advect_selfadvection_long_traces(oracle_backend):
+    """velocity advecting itself with traces leaving the domain (|v| dt up to 6 cells)"""
+    dims = (16, 14, 12)
+    flags, vel = cases.advect_inputs(dims, 13, vmax=6.0)
+    a = cases.run_advect_pkg(dims, 1.0, flags, vel, vel, 2, order=2)
+    b = cases.run_advect_ref(dims, 1.0, flags, vel, vel, 2, order=2)
+    assert_bitexact(a, b, "self advection")
+
+
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
+@pytest.mark.parametrize("with_ptype", [False, True])
+def test_flip_transfers(oracle_backend, dims, with_ptype):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 14, empty_top=True)
+    vel, velOld = util.rand_vel(sx, sy, sz, 15), util.rand_vel(sx, sy, sz, 16)
+    pos, pflag, pvel = util.make_particles(flags, 3, 17)
+    ptype = exclude = None
+    if with_ptype:
+        ptype = (np.random.default_rng(18).integers(0, 4, pos.shape[1]) * 2).astype(np.int32)
+    a = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype, 4 if with_ptype else 0)
+    b = cases.run_flip_ref(dims, flags, vel, velOld, pos, pflag, pvel, ptype, 4 if with_ptype else 0)
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("deleteInObstacle,stopInObstacle", [(False, True), (True, True), (False, False), (True, False)])
+def test_advect_in_grid(oracle_backend, dims, mode, deleteInObstacle, stopInObstacle):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 19, empty_top=True)
+    vel = util.smooth_vel(sx, sy, sz, 20, 2.0)
+    pos, pflag, _ = util.make_particles(flags, 2, 21)
+    a = cases.run_advect_parts_pkg(dims, 0.8, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle)
+    b = cases.run_advect_parts_ref(dims, 0.8, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle)
+    assert_bitexact(a[1], b[1], "particle flags")
+    assert_bitexact(a[0], b[0], "particle positions")
+
+
+def test_advect_in_grid_ptype_skipnew(oracle_backend):
+    dims = (12, 10, 9)
+    flags = util.make_flags(*dims, 22, empty_top=True)
+    vel = util.smooth_vel(*dims, 23, 1.5)
+    pos, pflag, _ = util.make_particles(flags, 2, 24)
+    ptype = (np.random.default_rng(25).integers(0, 2, pos.shape[1]) * 2).astype(np.int32)
+    a = cases.run_advect_parts_pkg(dims, 1.0, flags, vel, pos, pflag, 2, False, True, True, ptype, 2)
+    b = cases.run_advect_parts_ref(dims, 1.0, flags, vel, pos, pflag, 2, False, True, True, ptype, 2)
+    assert_bitexact(a[1], b[1], "particle flags")
+    assert_bitexact(a[0], b[0], "particle positions")
+
+
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
+def test_glue(oracle_backend, dims):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 26, empty_top=True)
+    flags[flags.shape[0] // 2, 3, 3] |= util.STICK
+    vel = util.rand_vel(sx, sy, sz, 27)
+    density = util.rand_real((sz, sy, sx), 28)
+    a = cases.run_glue_pkg(dims, 0.7, flags, vel, density)
+    b = cases.run_glue_ref(dims, 0.7, flags, vel, density)
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
+def test_init_domain_matches_reference(oracle_backend):
+    from mantaflow_amd import core
+    for dims, bw, kw in [((10, 9, 8), 0, {}), ((12, 10, 9), 1, dict(open="xY", outflow="z")), ((16, 12, 1), 0, dict(inflow="y"))]:
+        s = cases._mk_solver(dims)
+        fl = core.FlagGrid(s)
+        fl.initDomain(boundaryWidth=bw, **kw)
+        fl.fillGrid()
+        ref = np.zeros((dims[2], dims[1], dims[0]), np.int32)
+        pad = lambda x: (x + "      ").encode()
+        util.refcall("ref_init_domain", dims[0], dims[1], dims[2], ref, bw, b"xXyYzZ", pad(kw.get("open", "")),
+                     pad(kw.get("inflow", "")), pad(kw.get("outflow", "")), 1)
+        assert_bitexact(cases.grid_to_soa(fl), ref, "initDomain %s" % (dims,))
+
+
+def test_reductions(oracle):
+    n = 12345
+    a = util.rand_real((n,), 30, 3.0)
+    import ctypes
+    r = ctypes.c_float()
+    oracle.call("mf_grid_max_abs", n, oracle.dev(a), ctypes.byref(r), None)
+    rr = np.zeros(1, np.float32)
+    util.refcall("ref_grid_max_abs", n, a, rr)
+    assert r.value == rr[0]
+    d = ctypes.c_double()
+    oracle.call("mf_grid_sum_sqr", n, oracle.dev(a), ctypes.byref(d), None)
+    dd = np.zeros(1, np.float64)
+    util.refcall("ref_grid_sum_sqr", n, a, dd)
+    assert abs(d.value - dd[0]) <= 1e-12 * dd[0]
