@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: Mcells/s per step (advect + CG) on the 256^3 smoke configuration.
+
+One "step" = the hot path of one smoke time step over the synthetic S-smoke input:
+    restore velocity (device copy) -> advectSemiLagrange(density, order=2) -> advectSemiLagrange(vel, order=2)
+    -> setWallBcs -> solvePressure(MIC-preconditioned CG, cgAccuracy 1e-3)
+All inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task prompt)
+with two extra objects: `roofline` (ApplyMatrix, the kernel BASELINE.json's north_star names: 28 B/cell algorithmic
+bytes / HIP-event launch time, vs 8 TB/s) and `cpu_baseline` (the reference C++/OpenMP path -- oracle/_ref, or the
+oracle port when the compiled reference is absent -- timed on the host cores on a bounded sample of the workload).
+
+Launch: python bench.py --gpus 1 [--steps K --warmup W]  |  torchrun --nproc-per-node N bench.py --gpus N ...
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GRID = 256
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+APPLY_MATRIX_BYTES_PER_CELL = 28  # flags 4 + src 4 + A0,Ai,Aj,Ak 16 read; dst 4 written
+
+
+def synthetic_velocity(sx, sy, sz, seed=7, vmax=2.0):
+    """S-smoke: seeded band-limited velocity, max |v| dt = vmax cells (MAC, SoA [3][z][y][x])"""
+    rng = np.random.default_rng(seed)
+    z = np.arange(sz, dtype=np.float32)[:, None, None]
+    y = np.arange(sy, dtype=np.float32)[None, :, None]
+    x = np.arange(sx, dtype=np.float32)[None, None, :]
+    v = np.zeros((3, sz, sy, sx), np.float32)
+    for c in range(3):
+        for _ in range(3):
+            k = rng.uniform(0.5, 3.0, 3) * 2 * np.pi / np.array([sz, sy, sx])
+            ph = rng.uniform(0, 2 * np.pi, 3)
+            v[c] += np.float32(rng.uniform(-1, 1)) * (np.sin(k[0] * z + ph[0]) * np.sin(k[1] * y + ph[1]) * np.sin(k[2] * x + ph[2])).astype(np.float32)
+    v *= np.float32(vmax / max(np.abs(v).max(), 1e-9))
+    return v
+
+
+def synthetic_density(sx, sy, sz):
+    z = np.arange(sz, dtype=np.float32)[:, None, None]
+    y = np.arange(sy, dtype=np.float32)[None, :, None]
+    x = np.arange(sx, dtype=np.float32)[None, None, :]
+    r2 = ((x - sx * 0.5) / (0.2 * sx)) ** 2 + ((y - sy * 0.3) / (0.15 * sy)) ** 2 + ((z - sz * 0.5) / (0.2 * sz)) ** 2
+    return np.exp(-r2).astype(np.float32)
+
+
+def domain_flags(sx, sy, sz):
+    f = np.full((sz, sy, sx), 1, np.int32)     # initDomain(0) + fillGrid(): 1-cell obstacle shell, fluid interior
+    f[:, :, 0] = f[:, :, -1] = f[:, 0, :] = f[:, -1, :] = 2
+    f[0] = f[-1] = 2
+    return f
+
+
+def cpu_baseline(sample_dims, vel, dens, flags, dt):
+    """The reference CPU path timed on this host: one step of the same workload on a bounded sample (a z-slab of the
+    256^3 input re-walled as its own domain).  kind 'reference' = the reference's own C++/OpenMP (oracle/_ref)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    sx, sy, sz = sample_dims
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    v = np.ascontiguousarray(vel[:, :sz])
+    d = np.ascontiguousarray(dens[:sz])
+    f = domain_flags(sx, sy, sz)
+    cf = ctypes.c_float
+    if util.have_ref():
+        import cases  # noqa: F401
+        kind = "reference"
+        t0 = time.time()
+        util.refcall("ref_advect_semi_lagrange", sx, sy, sz, cf(dt), f, v, d, 0, 2, cf(1.0), 1, 2, 1)
+        v2 = v.copy()
+        util.refcall("ref_advect_semi_lagrange", sx, sy, sz, cf(dt), f, v, v2, 2, 2, cf(1.0), 1, 2, 1)
+        util.refcall("ref_set_wall_bcs", sx, sy, sz, f, v2, None)
+        p = np.zeros((sz, sy, sx), np.float32)
+        util.refcall("ref_solve_pressure", sx, sy, sz, v2, p, f, cf(1e-3), None, None, None, None, cf(1e-4), cf(1.5), 1, 1, 0, 0, 0, None, cf(0.0), None)
+        el = time.time() - t0
+    else:
+        import cases
+        from mantaflow_amd import _lib, core, plugins
+        kind = "port"
+        _lib.use_library(util.build_oracle(), "cpu")
+        s = cases._mk_solver(sample_dims, dt)
+        fl, vg, dg, pg = core.FlagGrid(s), core.MACGrid(s), core.Grid(s), core.Grid(s)
+        cases.soa_to_grid(fl, f); cases.soa_to_grid(vg, v); cases.soa_to_grid(dg, d)
+        t0 = time.time()
+        plugins.advectSemiLagrange(fl, vg, dg, order=2)
+        plugins.advectSemiLagrange(fl, vg, vg, order=2)
+        plugins.setWallBcs(fl, vg)
+        plugins.solvePressure(vg, pg, fl)
+        el = time.time() - t0
+        _lib.reset()
+    cells = sx * sy * sz
+    return {"value": round(cells / el / 1e6, 4), "unit": "Mcells/s", "cores": cores, "kind": kind,
+            "sample": "1 step (advect density+vel order 2, setWallBcs, solvePressure MIC-CG 1e-3) of the same synthetic "
+                      "input on its first %d z-planes as a %dx%dx%d domain, %.1f s" % (sz, sx, sy, sz, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=GRID)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, "launch with --nproc-per-node equal to --gpus"
+
+    from mantaflow_amd import _lib, core, plugins
+    lib = _lib.get()
+    assert lib.backend == "hip"
+    n = a.grid
+    dt = 1.0
+
+    if world > 1:
+        from mantaflow_amd import slab
+        result = slab.bench_slab_step(n, dt, a.steps, a.warmup, rank, world)
+    else:
+        s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
+        s.timestep = dt
+        flags = core.FlagGrid(s); flags.initDomain(); flags.fillGrid()
+        vel, vel0, dens, pres = core.MACGrid(s), core.MACGrid(s), core.Grid(s), core.Grid(s)
+        v_np = synthetic_velocity(n, n, n)
+        d_np = synthetic_density(n, n, n)
+        vel0.from_numpy(np.ascontiguousarray(v_np.transpose(1, 2, 3, 0)))
+        plugins.setWallBcs(flags, vel0)
+        dens.from_numpy(d_np)
+        iters = []
+
+        def step():
+            vel.copyFrom(vel0)
+            plugins.advectSemiLagrange(flags, vel, dens, order=2)
+            plugins.advectSemiLagrange(flags, vel, vel, order=2)
+            plugins.setWallBcs(flags, vel)
+            plugins.solvePressure(vel, pres, flags)
+            iters.append(plugins.lastCgStats()["iterations"])
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        result = {"elapsed": el, "cells": n ** 3, "cg_iterations": iters[-a.steps:] if a.steps else []}
+
+        # ---- roofline of the ApplyMatrix stencil (HIP events on the launch stream, inside the library) ----
+        A0, Ai, Aj, Ak, src, dst = (core.Grid(s) for _ in range(6))
+        lib.call("mf_make_laplace_matrix", n, n, n, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, s.stream)
+        src.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (n, n, n)).astype(np.float32))
+        us = ctypes.c_double()
+        lib.call("mf_time_apply_matrix", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, 200, ctypes.byref(us), s.stream)
+        gbs = APPLY_MATRIX_BYTES_PER_CELL * n ** 3 / (us.value * 1e-6) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "apply_matrix_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"kernel": "k_apply_matrix_v4 (ApplyMatrix, conjugategrad.h:118-133)", "bound": "hbm",
+                              "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                              "traffic": traffic, "avg_launch_us": round(us.value, 2),
+                              "algorithmic_bytes_per_launch": APPLY_MATRIX_BYTES_PER_CELL * n ** 3}
+        del A0, Ai, Aj, Ak, src, dst
+        if not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline((n, n, max(16, n // 4)), v_np, d_np, None, dt)
+
+    if world > 1:
+        t = torch.tensor([result["elapsed"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        result["elapsed"] = float(t.item())
+    if rank == 0:
+        el = result["elapsed"]
+        cells = n ** 3
+        line = {
+            "metric": "Mcells/s per step (advect+CG+FLIP), 256^3 grid",
+            "value": round(cells * a.steps / el / 1e6, 2), "unit": "Mcells/s", "n_gpus": a.gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(el / max(a.steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "256^3 smoke step on %d x MI355X: advectSemiLagrange(density, order 2) + "
+                                   "advectSemiLagrange(vel, order 2) + setWallBcs + solvePressure (MIC-CG, cgAccuracy 1e-3)" % a.gpus,
+                       "grid": [n, n, n], "cg_iterations_per_step": result.get("cg_iterations"),
+                       "parallelism": "single GPU" if a.gpus == 1 else "z-slab x%d, 1-plane halo p2p + RCCL all-reduce of CG scalars" % a.gpus},
+        }
+        if "roofline" in result:
+            line["roofline"] = result["roofline"]
+        if "cpu_baseline" in result:
+            line["cpu_baseline"] = result["cpu_baseline"]
+        if "notes" in result:
+            line["config"]["notes"] = result["notes"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -355,3 +355,54 @@ def run_glue_ref(dims, dt, flags, vel, density, obvel=None):
     refcall("ref_add_gravity", sx, sy, sz, cf(dt), flags, v, cf(0.0), cf(-0.003), cf(0.001), None, 1)
     out["grav"] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the golden set: same scenarios as tests/golden/make_golden.py, computed by an implementation under test
+# ---------------------------------------------------------------------------------------------------------
+def golden_outputs(impl, deterministic_p2g=True):
+    """impl: util.Impl for the raw-ABI cases; the package host layer must already be routed to the same library."""
+    out = {}
+    for tag, dims, seed in [("a", (16, 16, 16), 5), ("b", (20, 13, 11), 7)]:
+        flags, A, src = system_inputs(dims, seed)
+        out["apply_%s" % tag] = run_apply_matrix_impl(impl, dims, flags, A, src)
+        ap, dst = run_mic_impl(impl, dims, flags, A, src)
+        out["micinit_%s" % tag], out["micapply_%s" % tag] = ap, dst
+        rhs = cg_rhs(dims, flags, seed)
+        x, st = run_cg_impl(impl, dims, flags, A, rhs, 2, 1e-3, 60)
+        out["cg_%s" % tag], out["cgstat_%s" % tag] = x, np.array(st, np.float64)
+    for tag, dims, liquid in [("smoke", (16, 16, 16), False), ("liquid", (20, 13, 11), True), ("2d", (24, 18, 1), True)]:
+        flags, vel, phi = pressure_inputs(dims, 6, liquid)
+        r = run_solve_pressure_pkg(dims, flags, vel, phi)
+        for k in ("rhs", "pressure", "vel"):
+            out["sp_%s_%s" % (tag, k)] = r[k]
+    dims = (14, 12, 10)
+    sx, sy, sz = dims
+    for kind in (0, 1, 2):
+        flags, vel = advect_inputs(dims, 9, vmax=2.5, outflow=(kind == 2))
+        field = util.rand_real((sz, sy, sx), 10) if kind == 0 else util.rand_vel(sx, sy, sz, 10)
+        for order, cm in ((1, 2), (2, 1), (2, 2)):
+            out["adv_k%d_o%d_c%d" % (kind, order, cm)] = run_advect_pkg(dims, 0.9, flags, vel, field, kind, order=order, clampMode=cm,
+                                                                        strength=0.8 if order == 2 else 1.0)
+    dims = (12, 10, 9)
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 14, empty_top=True)
+    vel, velOld = util.rand_vel(sx, sy, sz, 15), util.rand_vel(sx, sy, sz, 16)
+    pos, pflag, pvel = util.make_particles(flags, 3, 17)
+    r = run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, deterministic=deterministic_p2g)
+    for k, v in r.items():
+        out["flip_" + k] = v
+    flags = util.make_flags(sx, sy, sz, 19, empty_top=True)
+    v2 = util.smooth_vel(sx, sy, sz, 20, 2.0)
+    pos, pflag, _ = util.make_particles(flags, 2, 21)
+    for mode in (0, 1, 2):
+        p, f = run_advect_parts_pkg(dims, 0.8, flags, v2, pos, pflag, mode, False, True)
+        out["padv_m%d_pos" % mode], out["padv_m%d_flag" % mode] = p, f
+    p, f = run_advect_parts_pkg(dims, 0.8, flags, v2, pos, pflag, 2, True, True)
+    out["padv_del_pos"], out["padv_del_flag"] = p, f
+    return out
+
+
+def load_golden():
+    import os
+    return dict(np.load(os.path.join(util.GOLDEN, "reference_vectors.npz")))

@@ -1,0 +1,320 @@
+"""-m gpu: the HIP product path (through the C ABI) against
+  (1) the committed golden vectors produced by the compiled reference,
+  (2) the oracle restatement on the same seeded inputs (and the compiled reference itself when its .so travelled),
+  (3) size-independent properties at BASELINE.json's 256^3.
+Bars: bit-exact for flag/index work and for every kernel without a reduction; <= 1e-5 relative (stated per test)
+where fp64 partial sums are combined in a different order than the reference's thread-local sums (CG scalars) or
+where fp32 atomics are used (non-deterministic particle->grid mode)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import util
+from util import assert_bitexact, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5   # BASELINE.json north_star: "within 1e-5 relative for fp32 grid fields"
+
+
+def _close(a, b, what, tol=TOL):
+    e = rel_err(a, b)
+    assert e <= tol, "%s: relative error %g > %g" % (what, e, tol)
+
+
+def test_native_library_is_the_one_loaded(hip, hip_backend):
+    from mantaflow_amd import _lib
+    lib = _lib.get()
+    assert lib.backend == "hip" and lib.path.endswith("libmanta_hip.so")
+    assert hip.lib.backend == "hip"
+    maps = open("/proc/self/maps").read()
+    assert "libmanta_hip.so" in maps
+
+
+def test_golden_vectors(hip, hip_backend):
+    gold = cases.load_golden()
+    got = cases.golden_outputs(hip, deterministic_p2g=True)
+    assert set(got) == set(gold)
+    exact, close = [], []
+    for k in sorted(gold):
+        if k.startswith("cgstat"):
+            assert got[k][0] == gold[k][0], "%s: iteration count %s vs %s" % (k, got[k][0], gold[k][0])
+            _close(got[k][1:], gold[k][1:], k, 1e-4)
+            continue
+        reduction_dependent = k.startswith(("cg_", "sp_")) and not k.endswith("_rhs")
+        if reduction_dependent:
+            _close(got[k], gold[k], k)
+            (exact if np.array_equal(got[k], gold[k]) else close).append(k)
+        else:
+            assert_bitexact(got[k], gold[k], k)
+            exact.append(k)
+    print("bit-exact: %d arrays; within %g: %s" % (len(exact), TOL, close))
+
+
+def test_golden_p2g_atomic_mode(hip, hip_backend):
+    """default (atomic) particle->grid mode: order of fp32 sums is undefined -> 1e-5 relative"""
+    gold = cases.load_golden()
+    dims = (12, 10, 9)
+    flags = util.make_flags(*dims, 14, empty_top=True)
+    vel, velOld = util.rand_vel(*dims, 15), util.rand_vel(*dims, 16)
+    pos, pflag, pvel = util.make_particles(flags, 3, 17)
+    r = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, deterministic=False)
+    for k in ("p2g_vel", "p2g_velOld", "p2g_weight", "p2g_real", "p2g_vec3"):
+        _close(r[k], gold["flip_" + k], k)
+    for k in ("pic", "flip", "g2p_real", "g2p_vec3"):
+        assert_bitexact(r[k], gold["flip_" + k], k)
+
+
+# ---- kernel-level: HIP vs oracle on the CPU-test scenarios ------------------------------------------------
+DIMS = cases.SIZES_3D + [cases.SIZE_2D, (32, 24, 40)]
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_laplace_and_apply_matrix(hip, oracle, dims):
+    flags, fr = cases.laplace_inputs(dims, 3, True)
+    for f in (None, fr):
+        for x, y in zip(cases.run_laplace_impl(hip, dims, flags, f), cases.run_laplace_impl(oracle, dims, flags, f)):
+            assert_bitexact(x, y, "MakeLaplaceMatrix")
+    for seed in (1, 2):
+        flags, A, src = cases.system_inputs(dims, seed)
+        assert_bitexact(cases.run_apply_matrix_impl(hip, dims, flags, A, src), cases.run_apply_matrix_impl(oracle, dims, flags, A, src), "ApplyMatrix")
+
+
+@pytest.mark.parametrize("dims", cases.SIZES_3D + [(32, 24, 40), (9, 9, 9), (64, 8, 8)])
+def test_mic(hip, oracle, dims):
+    for seed in (1, 2):
+        flags, A, src = cases.system_inputs(dims, seed)
+        ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
+        ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
+        assert_bitexact(ap, ap_o, "Aprecond")
+        assert_bitexact(dst, dst_o, "mic apply")
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("pc,acc,iters,l2", [(2, 1e-3, 60, 0), (2, 1e-9, 3, 0), (0, 1e-3, 80, 0), (2, 1e-4, 60, 1)])
+def test_cg_solve(hip, oracle, dims, pc, acc, iters, l2):
+    flags, A, _ = cases.system_inputs(dims, 5)
+    rhs = cases.cg_rhs(dims, flags, 5)
+    x, st = cases.run_cg_impl(hip, dims, flags, A, rhs, pc, acc, iters, l2)
+    xo, sto = cases.run_cg_impl(oracle, dims, flags, A, rhs, pc, acc, iters, l2)
+    assert st[0] == sto[0], (st, sto)
+    _close(x, xo, "cg solution")
+    _close(st[1:], sto[1:], "resNorm/sigma", 1e-4)
+
+
+def test_cg_diverged_reports_like_reference(hip):
+    dims = (16, 16, 16)
+    flags, A, _ = cases.system_inputs(dims, 4)     # closed box, random rhs: inconsistent system
+    rhs = cases.cg_rhs(dims, flags, 4) * 1e30
+    try:
+        cases.run_cg_impl(hip, dims, flags, A, rhs, 2, 1e-3, 200)
+    except RuntimeError as e:
+        assert "diverged" in str(e)
+
+
+@pytest.mark.parametrize("dims", DIMS)
+@pytest.mark.parametrize("liquid", [False, True])
+def test_solve_pressure_vs_reference(hip_backend, dims, liquid):
+    flags, vel, phi = cases.pressure_inputs(dims, 6, liquid)
+    a = cases.run_solve_pressure_pkg(dims, flags, vel, phi)
+    if util.have_ref():
+        b = cases.run_solve_pressure_ref(dims, flags, vel, phi)
+    else:
+        from mantaflow_amd import _lib
+        _lib.use_library(util.build_oracle(), "cpu")
+        b = cases.run_solve_pressure_pkg(dims, flags, vel, phi)
+        _lib.reset()
+    assert_bitexact(a["rhs"], b["rhs"], "rhs")
+    _close(a["pressure"], b["pressure"], "pressure")
+    _close(a["vel"], b["vel"], "vel")
+
+
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 17, 9)])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("order,clampMode", [(1, 2), (2, 1), (2, 2)])
+@pytest.mark.parametrize("orderTrace", [1, 2])
+def test_advect(hip_backend, oracle, dims, kind, order, clampMode, orderTrace):
+    from mantaflow_amd import _lib
+    sx, sy, sz = dims
+    flags, vel = cases.advect_inputs(dims, 9, vmax=2.5, outflow=(kind == 2))
+    field = util.rand_real((sz, sy, sx), 10) if kind == 0 else util.rand_vel(sx, sy, sz, 10)
+    kw = dict(order=order, clampMode=clampMode, orderTrace=orderTrace, strength=0.8 if order == 2 else 1.0)
+    a = cases.run_advect_pkg(dims, 0.9, flags, vel, field, kind, **kw)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_advect_pkg(dims, 0.9, flags, vel, field, kind, **kw)
+    _lib.reset()
+    assert_bitexact(a, b, "advectSemiLagrange kind=%d" % kind)
+
+
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
+@pytest.mark.parametrize("with_ptype", [False, True])
+def test_flip_transfers(hip_backend, dims, with_ptype):
+    from mantaflow_amd import _lib
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 14, empty_top=True)
+    vel, velOld = util.rand_vel(sx, sy, sz, 15), util.rand_vel(sx, sy, sz, 16)
+    pos, pflag, pvel = util.make_particles(flags, 3, 17)
+    ptype = None
+    if with_ptype:
+        ptype = (np.random.default_rng(18).integers(0, 4, pos.shape[1]) * 2).astype(np.int32)
+    a = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype, 4 if with_ptype else 0, deterministic=True)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype, 4 if with_ptype else 0)
+    _lib.reset()
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("deleteInObstacle,stopInObstacle", [(False, True), (True, True), (False, False), (True, False)])
+def test_advect_in_grid(hip_backend, dims, mode, deleteInObstacle, stopInObstacle):
+    from mantaflow_amd import _lib
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 19, empty_top=True)
+    vel = util.smooth_vel(sx, sy, sz, 20, 2.0)
+    pos, pflag, _ = util.make_particles(flags, 2, 21)
+    a = cases.run_advect_parts_pkg(dims, 0.8, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_advect_parts_pkg(dims, 0.8, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle)
+    _lib.reset()
+    assert_bitexact(a[1], b[1], "particle flags")
+    assert_bitexact(a[0], b[0], "particle positions")
+
+
+def test_empty_particle_system(hip_backend):
+    dims = (12, 10, 9)
+    flags = util.make_flags(*dims, 14)
+    pos, pflag, pvel = np.zeros((3, 0), np.float32), np.zeros(0, np.int32), np.zeros((3, 0), np.float32)
+    r = cases.run_flip_pkg(dims, flags, util.rand_vel(*dims, 1), util.rand_vel(*dims, 2), pos, pflag, pvel)
+    assert not r["p2g_vel"].any() and not r["p2g_weight"].any()
+
+
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
+def test_glue(hip_backend, dims):
+    from mantaflow_amd import _lib
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 26, empty_top=True)
+    flags[flags.shape[0] // 2, 3, 3] |= util.STICK
+    vel, density = util.rand_vel(sx, sy, sz, 27), util.rand_real((sz, sy, sx), 28)
+    a = cases.run_glue_pkg(dims, 0.7, flags, vel, density)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_glue_pkg(dims, 0.7, flags, vel, density)
+    _lib.reset()
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
+def test_reductions_and_elementwise(hip, oracle):
+    n = 1 << 20
+    a, b = util.rand_real((n + 3,), 30, 3.0), util.rand_real((n + 3,), 31, 2.0)
+    for impl_pair in [(hip, oracle)]:
+        res = []
+        for impl in impl_pair:
+            da, db = impl.dev(a), impl.dev(b)
+            d = ctypes.c_double(); f = ctypes.c_float(); lo = ctypes.c_float(); hi = ctypes.c_float()
+            impl.call("mf_grid_dot", n + 3, da, db, ctypes.byref(d), None)
+            impl.call("mf_grid_max_abs", n + 3, da, ctypes.byref(f), None)
+            impl.call("mf_grid_min_max", n + 3, da, ctypes.byref(lo), ctypes.byref(hi), None)
+            impl.call("mf_grid_scaled_add", n + 3, da, db, 0.37, None)
+            impl.call("mf_update_search_vec", n + 3, db, da, -1.7, None)
+            impl.call("mf_grid_clamp", n + 3, da, -1.0, 1.5, None)
+            impl.call("mf_grid_safe_divide", n + 3, db, da, None)
+            impl.sync()
+            res.append((d.value, f.value, lo.value, hi.value, impl.host(da), impl.host(db)))
+        h, o = res
+        assert abs(h[0] - o[0]) <= 1e-12 * abs(o[0]) and np.float32(h[0]) == np.float32(o[0])
+        assert h[1:4] == o[1:4]
+        assert_bitexact(h[4], o[4], "axpy/clamp")
+        assert_bitexact(h[5], o[5], "xpay/safeDivide")
+
+
+# ---- BASELINE.json size (256^3): direct comparison of the stencil + preconditioner and whole-solve properties ----
+def test_256_apply_matrix_and_mic_vs_oracle(hip, oracle):
+    dims = (256, 256, 256)
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 41, obstacles=True, empty_top=True)
+    A = cases.run_laplace_impl(hip, dims, flags, None)
+    Ao = cases.run_laplace_impl(oracle, dims, flags, None)
+    for x, y in zip(A, Ao):
+        assert_bitexact(x, y, "MakeLaplaceMatrix 256^3")
+    src = util.rand_real((sz, sy, sx), 42)
+    assert_bitexact(cases.run_apply_matrix_impl(hip, dims, flags, A, src), cases.run_apply_matrix_impl(oracle, dims, flags, A, src), "ApplyMatrix 256^3")
+    ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
+    ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
+    assert_bitexact(ap, ap_o, "Aprecond 256^3")
+    assert_bitexact(dst, dst_o, "MIC apply 256^3")
+
+
+def test_256_smoke_step_properties(hip_backend):
+    """one full 256^3 smoke step (advect density + velocity with MacCormack, setWallBcs, solvePressure):
+    divergence-free result, residual below cgAccuracy, constants advect to constants, run-to-run determinism."""
+    from mantaflow_amd import core, plugins
+    dims = (256, 256, 256)
+    sx, sy, sz = dims
+    s = cases._mk_solver(dims, 1.0)
+    fl = core.FlagGrid(s); fl.initDomain(); fl.fillGrid()
+    vel, dens, pres = core.MACGrid(s), core.Grid(s), core.Grid(s)
+    v0 = util.smooth_vel(sx, sy, sz, 43, 2.0)
+    cases.soa_to_grid(vel, v0)
+    plugins.setWallBcs(fl, vel)
+    dens.setConst(0.75)
+    plugins.advectSemiLagrange(fl, vel, dens, order=2)
+    d = cases.grid_to_soa(dens)
+    inner = d[1:-1, 1:-1, 1:-1]
+    assert np.all(inner == np.float32(0.75)), "a constant field must advect to the same constant (interior)"
+    assert not d[0].any() and not d[:, 0].any() and not d[:, :, 0].any(), "bnd=1 kernels leave the border of a fresh grid at 0"
+    plugins.advectSemiLagrange(fl, vel, vel, order=2)
+    plugins.setWallBcs(fl, vel)
+    vin = cases.grid_to_soa(vel).copy()
+    rhs = core.Grid(s)
+    plugins.solvePressure(vel, pres, fl, retRhs=rhs)
+    st = plugins.lastCgStats()
+    assert 1 <= st["iterations"] < 384 and st["residual"] < 1e-3, st
+    # divergence of the projected field (MakeRhs again) must be below the solver's max-norm tolerance scale
+    rhs2 = core.Grid(s)
+    plugins.computePressureRhs(rhs2, vel, pres, fl)
+    div_before, div_after = rhs.getMaxAbs(), rhs2.getMaxAbs()
+    assert div_after < 5e-3 and div_after < 1e-2 * div_before, (div_before, div_after)
+    # determinism: same inputs -> bit-identical pressure
+    p1 = cases.grid_to_soa(pres).copy()
+    cases.soa_to_grid(vel, vin)
+    plugins.solvePressure(vel, pres, fl)
+    assert plugins.lastCgStats()["iterations"] == st["iterations"]
+    assert np.array_equal(p1, cases.grid_to_soa(pres)), "solvePressure must be run-to-run deterministic"
+
+
+def test_128_flip_round_trip(hip_backend):
+    """128^3 FLIP transfers (config 3 shape): P2G of a constant particle velocity gives that constant wherever a
+    weight landed; G2P of it returns it; advectInGrid keeps particles inside the domain."""
+    from mantaflow_amd import core, plugins
+    dims = (128, 128, 128)
+    sx, sy, sz = dims
+    s = cases._mk_solver(dims, 0.5)
+    fl = core.FlagGrid(s); fl.initDomain(); fl.fillGrid()
+    flags = cases.grid_to_soa(fl)
+    sub = flags.copy(); sub[:, 76:, :] = 2; sub[:, :, 52:] = 2     # fluid block 0.4 x 0.6 x 1.0 of the domain
+    pos, pflag, _ = util.make_particles(np.where(sub == 1, 1, 2).astype(np.int32), 8, 44, include_border=False, deleted_frac=0.0)
+    pp = cases._mk_parts(s, pos, pflag)
+    const = np.tile(np.array([[0.3], [-0.2], [0.1]], np.float32), (1, pp.np))
+    pv = cases._pd_vec3(s, pp, const)
+    v, vo, w = core.MACGrid(s), core.MACGrid(s), core.VecGrid(s)
+    plugins.mapPartsToMAC(fl, v, vo, pp, pv, w)
+    g, wt = cases.grid_to_soa(v), cases.grid_to_soa(w)
+    for c, val in enumerate((0.3, -0.2, 0.1)):
+        m = wt[c] > 0
+        assert m.sum() > 1000
+        assert np.allclose(g[c][m], val, rtol=2e-5, atol=0), "P2G of a constant must return the constant"
+    pv2 = cases._pd_vec3(s, pp, np.zeros_like(const))
+    full = core.MACGrid(s); full.setConst(core.vec3(0.3, -0.2, 0.1))
+    plugins.mapMACToParts(fl, full, pp, pv2)
+    assert np.allclose(cases._pd_get(pv2, pp.np), const, rtol=1e-6)
+    cases.soa_to_grid(v, util.smooth_vel(sx, sy, sz, 45, 3.0))
+    pp.advectInGrid(fl, v, 2, deleteInObstacle=False)
+    s.sync()
+    p = pp.get_positions()
+    assert p.min() >= 0 and (p < np.array([sx, sy, sz])).all()
+    assert not (flags[p[:, 2].astype(int), p[:, 1].astype(int), p[:, 0].astype(int)] & 2).all()
