@@ -48,6 +48,11 @@ const char* mf_last_error(void);
 /* "hip" | "oracle" | "reference" -- which implementation answered (tests assert on this) */
 const char* mf_backend(void);
 
+/* z-slab window (multi-GPU, no reference counterpart): subsequent calls on this thread treat every grid as the
+ * planes [zoff, zoff+sz) of a global grid with gsz planes -- positions handed to the interpolators are global
+ * coordinates, so a slab reproduces the undivided domain bit for bit.  (0, 0) restores the default (whole domain). */
+int mf_set_slab_window(int zoff, int gsz);
+
 /* ------------------------------------------------------------------------------------------------
  * Element-wise grid ops used inside the CG loop and by scenes
  * ---------------------------------------------------------------------------------------------- */

@@ -25,7 +25,7 @@ k_semi_lagrange(Dim d, const float* __restrict__ vel, float* __restrict__ dst, c
 	if (!INTERIOR(d)) return;
 	float vx, vy, vz, px, py, pz;
 	get_centered(d, vel, idx, vx, vy, vz);
-	const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)k + 0.5f;
+	const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)(k + d.zoff) + 0.5f;
 	if (orderTrace == 1) {
 		px = cx - vx * dt;
 		py = cy - vy * dt;
@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_semi_lagrange_mac(Dim d, const float* __restrict__ vel, float* __restrict__ dst, const float* __restrict__ src, float dt, int orderTrace) {
 	CELL_IJK(d)
 	if (!INTERIOR(d)) return;
-	const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)k + 0.5f;
+	const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)(k + d.zoff) + 0.5f;
+	const int kg = k + d.zoff;
 	float vx, vy, vz, rx, ry, rz;
 	if (orderTrace == 1) {
 		get_at_mac_x(d, vel, idx, vx, vy, vz);
@@ -69,7 +70,7 @@ k_semi_lagrange_mac(Dim d, const float* __restrict__ vel, float* __restrict__ ds
 		interpol_mac(d, src, cx - (vx * dt) * 0.5f, (float)j - (vy * dt) * 0.5f, cz - (vz * dt) * 0.5f, ux, uy, uz);
 		ry = interpol1(d, src + d.n, cx - ux * dt, cy - uy * dt, cz - uz * dt);
 		get_at_mac_z(d, src, idx, vx, vy, vz);
-		interpol_mac(d, src, cx - (vx * dt) * 0.5f, cy - (vy * dt) * 0.5f, (float)k - (vz * dt) * 0.5f, ux, uy, uz);
+		interpol_mac(d, src, cx - (vx * dt) * 0.5f, cy - (vy * dt) * 0.5f, (float)kg - (vz * dt) * 0.5f, ux, uy, uz);
 		rz = interpol1(d, src + 2 * d.n, cx - ux * dt, cy - uy * dt, cz - uz * dt);
 	}
 	dst[idx] = rx;
@@ -146,12 +147,14 @@ k_maccormack_clamp(Dim d, const int32_t* __restrict__ flags, const float* __rest
 		maxv[c] = -FLT_MAX;
 	}
 	bool haveFl = false;
-	const int gx = d.sx - 1, gy = d.sy - 1, gz = d.sz - 1;  // gridUpper = size - 1
+	const int gx = d.sx - 1, gy = d.sy - 1, gz = d.gsz - 1;  // gridUpper = size - 1 (global z extent)
+	const int kg = k + d.zoff;
 	const int numPos = (clampMode == 1) ? 2 : 1;
 	for (int l = 0; l < numPos; l++) {
 		const float sg = l == 0 ? -1.f : 1.f;
-		const int cxp = (int)((float)i + sg * vx), cyp = (int)((float)j + sg * vy), czp = (int)((float)k + sg * vz);
-		const int i0 = clampi(cxp, 0, gx - 1), j0 = clampi(cyp, 0, gy - 1), k0 = clampi(czp, 0, d.is3d ? (gz - 1) : 1);
+		const int cxp = (int)((float)i + sg * vx), cyp = (int)((float)j + sg * vy), czp = (int)((float)kg + sg * vz);
+		const int i0 = clampi(cxp, 0, gx - 1), j0 = clampi(cyp, 0, gy - 1);
+		const int k0 = local_z(d, clampi(czp, 0, d.is3d ? (gz - 1) : 1), 1);
 		const int nz = d.is3d ? 2 : 1;
 		for (int dz = 0; dz < nz; dz++)
 			for (int dy = 0; dy < 2; dy++)
@@ -184,13 +187,14 @@ k_maccormack_clamp(Dim d, const int32_t* __restrict__ flags, const float* __rest
 		}
 	}
 	if (clampMode == 1) {
-		const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)k + 0.5f;
+		const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)kg + 0.5f;
 		const int fx = (int)(cx - vx), fy = (int)(cy - vy), fz = (int)(cz - vz);
 		const int bx = (int)(cx + vx), by = (int)(cy + vy), bz = (int)(cz + vz);
 		bool bad = fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > gx || fy > gy || ((fz > gz) && d.is3d) ||
 		           bx > gx || by > gy || ((bz > gz) && d.is3d);
 		if (!bad)
-			bad = (flags[(int64_t)fx + d.Y * fy + d.Z * fz] & MF_OBSTACLE) || (flags[(int64_t)bx + d.Y * by + d.Z * bz] & MF_OBSTACLE);
+			bad = (flags[(int64_t)fx + d.Y * fy + d.Z * local_z(d, fz, 0)] & MF_OBSTACLE) ||
+			      (flags[(int64_t)bx + d.Y * by + d.Z * local_z(d, bz, 0)] & MF_OBSTACLE);
 		if (bad) {
 #pragma unroll
 			for (int c = 0; c < NCOMP; c++) dval[c] = fw[c];
@@ -208,13 +212,15 @@ __device__ __forceinline__ float clamp_component_mac(const Dim& d, int c, const 
 	const int64_t o = (int64_t)i + d.Y * j + d.Z * k;
 	const int64_t nbo = o - (c == 0 ? 1 : (c == 1 ? d.Y : d.Z));
 	if (clampMode == 2 && !(checkflag(flags[o]) && checkflag(flags[nbo]))) return fwdv;
-	const int gx = d.sx - 1, gy = d.sy - 1, gz = d.sz - 1;
+	const int gx = d.sx - 1, gy = d.sy - 1, gz = d.gsz - 1;
+	const int kg = k + d.zoff;
 	const float* oc = orig + c * d.n;
 	const int numPos = (clampMode == 1) ? 2 : 1;
 	for (int l = 0; l < numPos; l++) {
 		const float sg = l == 0 ? -1.f : 1.f;
-		const int cxp = (int)((float)i + sg * vx), cyp = (int)((float)j + sg * vy), czp = (int)((float)k + sg * vz);
-		const int i0 = clampi(cxp, 0, gx - 1), j0 = clampi(cyp, 0, gy - 1), k0 = clampi(czp, 0, d.is3d ? (gz - 1) : 0);
+		const int cxp = (int)((float)i + sg * vx), cyp = (int)((float)j + sg * vy), czp = (int)((float)kg + sg * vz);
+		const int i0 = clampi(cxp, 0, gx - 1), j0 = clampi(cyp, 0, gy - 1);
+		const int k0 = local_z(d, clampi(czp, 0, d.is3d ? (gz - 1) : 0), 1);
 		const int nz = d.is3d ? 2 : 1;
 		for (int dz = 0; dz < nz; dz++)
 			for (int dy = 0; dy < 2; dy++)

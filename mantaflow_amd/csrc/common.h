@@ -42,18 +42,30 @@ int get_workspace(Workspace** ws);
 struct Dim {
 	int sx, sy, sz;
 	int is3d;
+	int zoff, gsz;    // z-slab window: this grid holds planes [zoff, zoff+sz) of a global grid of gsz planes
 	int64_t Y, Z, n;  // strides (X == 1); Z == 0 in 2-D (reference grid.cpp:56)
 };
+extern thread_local int g_slab_zoff, g_slab_gsz;  // set by mf_set_slab_window; (0,0) = the grid is the whole domain
 static inline Dim mkdim(int sx, int sy, int sz) {
 	Dim d;
 	d.sx = sx;
 	d.sy = sy;
 	d.sz = sz;
 	d.is3d = sz > 1;
+	d.zoff = g_slab_gsz > 0 ? g_slab_zoff : 0;
+	d.gsz = g_slab_gsz > 0 ? g_slab_gsz : sz;
 	d.Y = sx;
 	d.Z = d.is3d ? (int64_t)sx * sy : 0;
 	d.n = (int64_t)sx * sy * sz;
 	return d;
+}
+// global plane index -> index inside the local window, kept addressable for the ghost fringe (whose results are
+// discarded); the identity when the grid is the whole domain
+__device__ __forceinline__ int local_z(const Dim& d, int zi, int hi_off) {
+	if (d.sz <= 1) return zi;
+	zi -= d.zoff;
+	const int hi = d.sz - 1 - hi_off;
+	return zi < 0 ? 0 : (zi > hi ? hi : zi);
 }
 static inline int check_dim(int sx, int sy, int sz) {
 	if (sx < 2 || sy < 2 || sz < 1) return fail("invalid grid size %dx%dx%d", sx, sy, sz);
@@ -132,12 +144,28 @@ __device__ __forceinline__ void block_minmax(float& lo, float& hi) {
 	}
 }
 
+// per-thread strided sum over per-block partials with 8 loads in flight (a plain loop serialises one
+// memory round trip per element); fixed order -> deterministic
+__device__ __forceinline__ double strided_sum(const double* __restrict__ p, int nb) {
+	double acc = 0.0;
+	int i = threadIdx.x;
+	const int S = blockDim.x;
+	for (; i + 7 * S < nb; i += 8 * S) {
+		const double v0 = p[i], v1 = p[i + S], v2 = p[i + 2 * S], v3 = p[i + 3 * S];
+		const double v4 = p[i + 4 * S], v5 = p[i + 5 * S], v6 = p[i + 6 * S], v7 = p[i + 7 * S];
+		acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+	}
+	for (; i < nb; i += S) acc += p[i];
+	return acc;
+}
+
 // ---- interpolation primitives, reference util/interpol.h -------------------------------------------------
 struct Bi {
 	int xi, yi, zi;
 	float s0, s1, t0, t1, f0, f1;
 };
-// BUILD_INDEX, interpol.h:52-69.  `1.-s1` is an fp64 subtraction rounded to fp32 in the reference; for
+// Positions are GLOBAL grid coordinates (z includes the slab offset), so a slab computes bit-identical weights to
+// the undivided domain.  BUILD_INDEX, interpol.h:52-69.  `1.-s1` is an fp64 subtraction rounded to fp32 in the reference; for
 // s1 in [0,1) that equals the fp32 subtraction (exact in fp64 when s1 >= 2^-29, both give 1 below), and
 // outside that range the clamps overwrite the weights.  The fork clamps the upper side on px, not xi.
 __device__ __forceinline__ Bi build_index(const Dim& d, float x, float y, float z) {
@@ -157,7 +185,8 @@ __device__ __forceinline__ Bi build_index(const Dim& d, float x, float y, float 
 	if (pz < 0.f) { b.zi = 0; b.f0 = 1.f; b.f1 = 0.f; }
 	if (px >= (float)(d.sx - 1)) { b.xi = d.sx - 2; b.s0 = 0.f; b.s1 = 1.f; }
 	if (py >= (float)(d.sy - 1)) { b.yi = d.sy - 2; b.t0 = 0.f; b.t1 = 1.f; }
-	if (d.sz > 1) { if (pz >= (float)(d.sz - 1)) { b.zi = d.sz - 2; b.f0 = 0.f; b.f1 = 1.f; } }
+	if (d.gsz > 1) { if (pz >= (float)(d.gsz - 1)) { b.zi = d.gsz - 2; b.f0 = 0.f; b.f1 = 1.f; } }
+	b.zi = local_z(d, b.zi, 1);
 	return b;
 }
 // shifted half of BUILD_INDEX_SHIFT, interpol.h:116-129 (upper clamp on the integer index)
@@ -177,7 +206,8 @@ __device__ __forceinline__ Bi build_index_shift(const Dim& d, float x, float y, 
 	if (z < 0.f) { b.zi = 0; b.f0 = 1.f; b.f1 = 0.f; }
 	if (b.xi >= d.sx - 1) { b.xi = d.sx - 2; b.s0 = 0.f; b.s1 = 1.f; }
 	if (b.yi >= d.sy - 1) { b.yi = d.sy - 2; b.t0 = 0.f; b.t1 = 1.f; }
-	if (d.sz > 1) { if (b.zi >= d.sz - 1) { b.zi = d.sz - 2; b.f0 = 0.f; b.f1 = 1.f; } }
+	if (d.gsz > 1) { if (b.zi >= d.gsz - 1) { b.zi = d.gsz - 2; b.f0 = 0.f; b.f1 = 1.f; } }
+	b.zi = local_z(d, b.zi, 1);
 	return b;
 }
 // 8-corner gather with the reference's association order, interpol.h:77-80 / 90-93

@@ -285,11 +285,7 @@ k_make_rhs(Dim d, const int32_t* __restrict__ flags, float* __restrict__ rhs, co
 }
 // second-level reduction for grids with more blocks than one finishing block can hold in `partials`
 __global__ void __launch_bounds__(BLOCK) k_sum2_finish(int nb, const double* __restrict__ p0, const double* __restrict__ p1, double* __restrict__ out) {
-	double a = 0.0, b = 0.0;
-	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-		a += p0[i];
-		b += p1[i];
-	}
+	double a = strided_sum(p0, nb), b = strided_sum(p1, nb);
 	a = block_sum(a);
 	__syncthreads();
 	b = block_sum(b);
@@ -431,7 +427,39 @@ __global__ void k_fix_pressure(Dim d, int64_t p, float value, float* rhs, float*
 //   MODE 1: forward substitution     dst := tmp, var1 := residual
 //   MODE 2: backward substitution (tile and in-tile coordinates mirrored)
 // =========================================================================================================
-template <int MODE>
+// load 8 consecutive floats of one x-row (logical order a = 0..7 <-> physical li); branch-free so that the
+// compiler issues every load of a tile before the first wait.  `nv` = number of in-domain cells of the row (0..8).
+template <bool VEC, bool REV>
+__device__ __forceinline__ void load_row8(const float* __restrict__ base, int64_t rowidx, int nv, float out[8]) {
+	float t[8];
+	if (VEC) {
+		// x0 % 8 == 0 and sx % 4 == 0: both halves are 16-byte aligned; a half is either fully inside or outside
+		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		const int64_t i0 = nv > 0 ? rowidx : 0, i1 = nv > 4 ? rowidx + 4 : 0;
+		float4 lo = *(const float4*)(base + i0), hi = *(const float4*)(base + i1);
+		if (nv <= 0) lo = z;
+		if (nv <= 4) hi = z;
+		t[0] = lo.x; t[1] = lo.y; t[2] = lo.z; t[3] = lo.w;
+		t[4] = hi.x; t[5] = hi.y; t[6] = hi.z; t[7] = hi.w;
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const float v = base[e < nv ? rowidx + e : 0];
+			t[e] = e < nv ? v : 0.f;
+		}
+	}
+#pragma unroll
+	for (int a = 0; a < 8; a++) out[a] = t[REV ? 7 - a : a];
+}
+template <bool VEC, bool REV>
+__device__ __forceinline__ void load_row8i(const int32_t* __restrict__ base, int64_t rowidx, int nv, int out[8]) {
+	float t[8];
+	load_row8<VEC, REV>((const float*)base, rowidx, nv, t);
+#pragma unroll
+	for (int a = 0; a < 8; a++) out[a] = __float_as_int(t[a]);
+}
+
+template <int MODE, bool VEC>
 __global__ void __launch_bounds__(64)
 k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restrict__ flags, float* __restrict__ dst,
             const float* __restrict__ var1, const float* __restrict__ Ap, const float* __restrict__ Ai,
@@ -449,79 +477,105 @@ k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restri
 	const bool row_in = (j < d.sy) && (k < d.sz);
 	const int64_t rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
 	const int back = REV ? 1 : -1;  // physical offset of the logical predecessor
+	const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;  // in-domain cells of a row of this tile
+	const int nv = row_in ? nvx : 0;
 
 	__shared__ float sV[512], sAi[512], sAj[512], sAk[512], sP[512], sD[512];
 	__shared__ int sF[512];
 	__shared__ float sHj[NC][64], sHk[NC][64];
 
-	// ---- stage my row (logical order a = 0..7 <-> physical li) ----
+	// ---- issue every global load of the tile (own row, i-halo cell, j-/k-halo rows), then consume ----
+	int rF[8];
+	float rV[8], rAi[8], rAj[8], rAk[8], rP[8], rD[8];
+	load_row8i<VEC, REV>(flags, rowbase, nv, rF);
+	load_row8<VEC, REV>(var1, rowbase, nv, rV);
+	load_row8<VEC, REV>(Ai, rowbase, nv, rAi);
+	load_row8<VEC, REV>(Aj, rowbase, nv, rAj);
+	load_row8<VEC, REV>(Ak, rowbase, nv, rAk);
+	if (MODE != 0) {
+		load_row8<VEC, REV>(Ap, rowbase, nv, rP);
+		load_row8<VEC, REV>(dst, rowbase, nv, rD);
+	}
+	// i-halo: the cell before my row (one per lane)
+	const int gi = x0 + (REV ? 8 : -1);
+	const bool hin = row_in && gi >= 0 && gi < d.sx;
+	const int64_t hidx = hin ? rowbase + (REV ? 8 : -1) : 0;
+	const float hAi = Ai[hidx], hAj = Aj[hidx], hAk = Ak[hidx], hD = dst[hidx];
+	const float hP = (MODE == 1) ? Ap[hidx] : 0.f;
+	// j-halo row (used by lanes with b == 0) and k-halo row (lanes with c == 0)
+	const int jn = j + back, kn = k + back;
+	const int nvj = ((b == 0) && (jn >= 0) && (jn < d.sy) && (k < d.sz)) ? nvx : 0;
+	const int nvk = ((c == 0) && (kn >= 0) && (kn < d.sz) && (j < d.sy)) ? nvx : 0;
+	const int64_t jrow = rowbase + (int64_t)back * d.Y, krow = rowbase + (int64_t)back * d.Z;
+	float jD[8], jA[8], jB[8], jC[8], jP[8], kD[8], kA[8], kB[8], kC[8], kP[8];
+	if (b == 0) {
+		load_row8<VEC, REV>(dst, jrow, nvj, jD);
+		if (MODE != 2) load_row8<VEC, REV>(Aj, jrow, nvj, jA);
+		if (MODE == 1) load_row8<VEC, REV>(Ap, jrow, nvj, jP);
+		if (MODE == 0) {
+			load_row8<VEC, REV>(Ai, jrow, nvj, jB);
+			load_row8<VEC, REV>(Ak, jrow, nvj, jC);
+		}
+	}
+	if (c == 0) {
+		load_row8<VEC, REV>(dst, krow, nvk, kD);
+		if (MODE != 2) load_row8<VEC, REV>(Ak, krow, nvk, kA);
+		if (MODE == 1) load_row8<VEC, REV>(Ap, krow, nvk, kP);
+		if (MODE == 0) {
+			load_row8<VEC, REV>(Ai, krow, nvk, kB);
+			load_row8<VEC, REV>(Aj, krow, nvk, kC);
+		}
+	}
+
+	// value(s) a finished neighbour cell hands to its logical successor in direction `dir`:
+	//   MODE 1: (dst*A_dir)*Ap   MODE 2: dst   MODE 0: square(A_dir*Ap), A_dir*(A_o1+A_o2)*square(Ap)
+	auto hand = [&](float dv, float adir, float osum, float ap, float& h0, float& h1) {
+		h1 = 0.f;
+		if (MODE == 1) {
+			h0 = (dv * adir) * ap;
+		} else if (MODE == 2) {
+			h0 = dv;
+		} else {
+			const float t = adir * dv;  // dv = Aprecond of the neighbour (being built)
+			h0 = t * t;
+			h1 = adir * osum * (dv * dv);
+		}
+	};
 #pragma unroll
 	for (int a = 0; a < 8; a++) {
-		const int li = REV ? 7 - a : a;
-		const bool in = row_in && (x0 + li < d.sx);
-		const int64_t idx = rowbase + li;
-		const int fl = in ? (flags[idx] & MF_FLUID) : 0;
 		const int s = lane * 8 + a;
-		sF[s] = in ? (fl ? 1 : 2) : 0;  // 1 fluid, 2 in-domain non-fluid, 0 outside
-		sV[s] = fl ? var1[idx] : 0.f;
-		sAi[s] = in ? Ai[idx] : 0.f;
-		sAj[s] = in ? Aj[idx] : 0.f;
-		sAk[s] = in ? Ak[idx] : 0.f;
+		const bool in = a < 8 && ((REV ? 7 - a : a) < nv);
+		const int fl = in ? ((rF[a] & MF_FLUID) ? 1 : 2) : 0;  // 1 fluid, 2 in-domain non-fluid, 0 outside
+		sF[s] = fl;
+		sV[s] = (fl == 1) ? rV[a] : 0.f;
+		sAi[s] = rAi[a];
+		sAj[s] = rAj[a];
+		sAk[s] = rAk[a];
 		if (MODE == 0) {
 			sP[s] = 0.f;
 			sD[s] = 0.f;  // Aprecond.clear(): non-fluid cells stay 0
 		} else {
-			sP[s] = in ? Ap[idx] : 0.f;
-			sD[s] = (MODE == 2) ? (in ? dst[idx] : 0.f) : ((in && !fl) ? dst[idx] : 0.f);
+			sP[s] = rP[a];
+			sD[s] = rD[a];
 		}
 	}
-
-	// value(s) a finished neighbour cell hands to its logical successor in direction dir (0 i, 1 j, 2 k)
-	auto halo = [&](int64_t nidx, bool in, int dir, float& h0, float& h1) {
-		h0 = 0.f;
-		h1 = 0.f;
-		if (!in) return;
-		const float ai = Ai[nidx], aj = Aj[nidx], ak = Ak[nidx];
-		const float adir = dir == 0 ? ai : (dir == 1 ? aj : ak);
-		if (MODE == 1) {
-			h0 = (dst[nidx] * adir) * Ap[nidx];
-		} else if (MODE == 2) {
-			h0 = dst[nidx];
-		} else {
-			const float ap = dst[nidx];  // Aprecond being built
-			const float o = dir == 0 ? (aj + ak) : (dir == 1 ? (ai + ak) : (ai + aj));
-			const float t = adir * ap;
-			h0 = t * t;
-			h1 = adir * o * (ap * ap);
-		}
-	};
-	// i-halo: one cell per lane
 	float hi0, hi1;
-	{
-		const int gi = x0 + (REV ? 8 : -1);
-		halo(rowbase + (REV ? 8 : -1), row_in && gi >= 0 && gi < d.sx, 0, hi0, hi1);
-	}
-	// j-halo: rows of the lanes with b == 0 ; k-halo: rows of the lanes with c == 0
+	hand(hin ? hD : 0.f, hin ? hAi : 0.f, hAj + hAk, hP, hi0, hi1);
+	if (!hin) hi0 = hi1 = 0.f;
 	if (b == 0) {
-		const int jn = j + back;
-		const bool rin = (jn >= 0) && (jn < d.sy) && (k < d.sz);
 #pragma unroll
 		for (int a = 0; a < 8; a++) {
-			const int li = REV ? 7 - a : a;
 			float h0, h1;
-			halo(rowbase + (int64_t)back * d.Y + li, rin && (x0 + li < d.sx), 1, h0, h1);
+			hand(jD[a], MODE != 2 ? jA[a] : 0.f, MODE == 0 ? (jB[a] + jC[a]) : 0.f, MODE == 1 ? jP[a] : 0.f, h0, h1);
 			sHj[0][c * 8 + a] = h0;
 			if (NC == 2) sHj[NC - 1][c * 8 + a] = h1;
 		}
 	}
 	if (c == 0) {
-		const int kn = k + back;
-		const bool rin = (kn >= 0) && (kn < d.sz) && (j < d.sy);
 #pragma unroll
 		for (int a = 0; a < 8; a++) {
-			const int li = REV ? 7 - a : a;
 			float h0, h1;
-			halo(rowbase + (int64_t)back * d.Z + li, rin && (x0 + li < d.sx), 2, h0, h1);
+			hand(kD[a], MODE != 2 ? kA[a] : 0.f, MODE == 0 ? (kB[a] + kC[a]) : 0.f, MODE == 1 ? kP[a] : 0.f, h0, h1);
 			sHk[0][b * 8 + a] = h0;
 			if (NC == 2) sHk[NC - 1][b * 8 + a] = h1;
 		}
@@ -598,12 +652,17 @@ k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restri
 		}
 	}
 	__syncthreads();
-	// ---- write back my row ----
+	// ---- write back my row (non-fluid cells carry their loaded value, so whole in-domain halves are stored) ----
+	float w[8];
 #pragma unroll
-	for (int a = 0; a < 8; a++) {
-		const int li = REV ? 7 - a : a;
-		const int s = lane * 8 + a;
-		if (sF[s] == 1) dst[rowbase + li] = sD[s];
+	for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = sD[lane * 8 + a];
+	if (VEC) {
+		if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
+		if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (e < nv) dst[rowbase + e] = w[e];
 	}
 }
 
@@ -612,8 +671,13 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
                       const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
 	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
 	const int levels = nti + ntj + ntk - 2;
-	for (int L = 0; L < levels; L++)
-		hipLaunchKernelGGL((k_mic_tiles<MODE>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
+	for (int L = 0; L < levels; L++) {
+		if (vec)
+			hipLaunchKernelGGL((k_mic_tiles<MODE, true>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+		else
+			hipLaunchKernelGGL((k_mic_tiles<MODE, false>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+	}
 	MF_LAUNCH_CHECK();
 	return 0;
 }
@@ -622,8 +686,7 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 // PCG scalar kernels (one block) -- scalars never leave the device inside an iteration
 // =========================================================================================================
 __global__ void __launch_bounds__(BLOCK) k_cg_begin(CgScalars* sc, int nb, const double* __restrict__ partials, float accuracy, int useL2) {
-	double acc = 0.0;
-	for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partials[i];
+	double acc = strided_sum(partials, nb);
 	acc = block_sum(acc);
 	if (threadIdx.x == 0) {
 		sc->sigma = (float)acc;  // mSigma = GridDotProduct(mTmp, mResidual), conjugategrad.cpp:234
@@ -639,8 +702,7 @@ __global__ void __launch_bounds__(BLOCK) k_cg_begin(CgScalars* sc, int nb, const
 // alpha = sigma / dp, conjugategrad.cpp:250-252
 __global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const double* __restrict__ partials) {
 	if (sc->done) return;
-	double acc = 0.0;
-	for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partials[i];
+	double acc = strided_sum(partials, nb);
 	acc = block_sum(acc);
 	if (threadIdx.x == 0) {
 		const float dp = (float)acc;
@@ -743,7 +805,7 @@ k_cg_beta(CgScalars* sc, int nbr, const float* __restrict__ fpart, const double*
 			hi = fmaxf(hi, fpart[2 * i + 1]);
 		}
 	}
-	for (int i = threadIdx.x; i < nbd; i += blockDim.x) dd += dpart_dot[i];
+	dd = strided_sum(dpart_dot, nbd);
 	block_minmax(lo, hi);
 	__syncthreads();
 	ss = block_sum(ss);

@@ -5,6 +5,7 @@
 
 namespace mf {
 thread_local char g_err[512];
+thread_local int g_slab_zoff = 0, g_slab_gsz = 0;
 int fail(const char* fmt, ...) {
 	va_list ap;
 	va_start(ap, fmt);
@@ -154,8 +155,7 @@ __global__ void __launch_bounds__(BLOCK) k_dot_partials(int64_t n, const float* 
 	if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 __global__ void __launch_bounds__(BLOCK) k_sum_finish(int nb, const double* __restrict__ partials, double* __restrict__ out) {
-	double acc = 0.0;
-	for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partials[i];
+	double acc = strided_sum(partials, nb);
 	acc = block_sum(acc);
 	if (threadIdx.x == 0) *out = acc;
 }
@@ -219,6 +219,12 @@ extern "C" {
 
 const char* mf_last_error(void) { return mf::g_err; }
 const char* mf_backend(void) { return "hip"; }
+int mf_set_slab_window(int zoff, int gsz) {
+	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid slab window %d / %d", zoff, gsz);
+	mf::g_slab_zoff = zoff;
+	mf::g_slab_gsz = gsz;
+	return 0;
+}
 
 int mf_fill_f32(int64_t n, float* a, float v, void* s) { return run_unary<OP_FILL>(n, a, v, 0.f, s); }
 int mf_fill_i32(int64_t n, int32_t* a, int32_t v, void* s) {

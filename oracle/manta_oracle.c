@@ -35,14 +35,24 @@ const char* mf_backend(void) { return "oracle"; }
 typedef struct {
 	int sx, sy, sz;
 	int is3d;
+	int zoff, gsz;      /* z-slab window (multi-GPU tests): planes [zoff, zoff+sz) of a global grid of gsz planes */
 	int64_t X, Y, Z, n; /* strides (Z == 0 in 2-D, grid.cpp:56) */
 } Dim;
+static _Thread_local int g_slab_zoff = 0, g_slab_gsz = 0;
+int mf_set_slab_window(int zoff, int gsz) {
+	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid slab window");
+	g_slab_zoff = zoff;
+	g_slab_gsz = gsz;
+	return 0;
+}
 static Dim mkdim(int sx, int sy, int sz) {
 	Dim d;
 	d.sx = sx;
 	d.sy = sy;
 	d.sz = sz;
 	d.is3d = sz > 1;
+	d.zoff = g_slab_gsz > 0 ? g_slab_zoff : 0;
+	d.gsz = g_slab_gsz > 0 ? g_slab_gsz : sz;
 	d.X = 1;
 	d.Y = sx;
 	d.Z = d.is3d ? (int64_t)sx * sy : 0;
@@ -673,6 +683,13 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 /* ================================================================================================
  * interpolation primitives, util/interpol.h
  * ============================================================================================== */
+/* global plane index -> index inside the slab window, kept addressable in the ghost fringe; identity by default */
+static inline int local_z(const Dim* d, int zi, int hi_off) {
+	if (d->sz <= 1) return zi;
+	zi -= d->zoff;
+	int hi = d->sz - 1 - hi_off;
+	return zi < 0 ? 0 : (zi > hi ? hi : zi);
+}
 typedef struct {
 	int xi, yi, zi;
 	float s0, s1, t0, t1, f0, f1;
@@ -695,7 +712,8 @@ static inline Bi build_index(const Dim* d, float x, float y, float z) {
 	if (pz < 0.) { b.zi = 0; b.f0 = 1.0; b.f1 = 0.0; }
 	if (px >= d->sx - 1) { b.xi = d->sx - 2; b.s0 = 0.0; b.s1 = 1.0; }
 	if (py >= d->sy - 1) { b.yi = d->sy - 2; b.t0 = 0.0; b.t1 = 1.0; }
-	if (d->sz > 1) { if (pz >= d->sz - 1) { b.zi = d->sz - 2; b.f0 = 0.0; b.f1 = 1.0; } }
+	if (d->gsz > 1) { if (pz >= d->gsz - 1) { b.zi = d->gsz - 2; b.f0 = 0.0; b.f1 = 1.0; } }
+	b.zi = local_z(d, b.zi, 1);
 	return b;
 }
 /* the shifted half of BUILD_INDEX_SHIFT, interpol.h:116-129 (upper clamp tests the integer index) */
@@ -715,7 +733,8 @@ static inline Bi build_index_shift(const Dim* d, float x, float y, float z) {
 	if (z < 0) { b.zi = 0; b.f0 = 1.0; b.f1 = 0.0; }
 	if (b.xi >= d->sx - 1) { b.xi = d->sx - 2; b.s0 = 0.0; b.s1 = 1.0; }
 	if (b.yi >= d->sy - 1) { b.yi = d->sy - 2; b.t0 = 0.0; b.t1 = 1.0; }
-	if (d->sz > 1) { if (b.zi >= d->sz - 1) { b.zi = d->sz - 2; b.f0 = 0.0; b.f1 = 1.0; } }
+	if (d->gsz > 1) { if (b.zi >= d->gsz - 1) { b.zi = d->gsz - 2; b.f0 = 0.0; b.f1 = 1.0; } }
+	b.zi = local_z(d, b.zi, 1);
 	return b;
 }
 /* interpol<T> / interpolComponent<c>, interpol.h:71-94 on one scalar plane */
@@ -792,20 +811,21 @@ static int semi_lagrange(int sx, int sy, int sz, int ncomp, const float* vel, fl
 			for (int i = 1; i < sx - 1; i++) {
 				int64_t idx = IDX(d, i, j, k);
 				float v[3], px, py, pz;
+				const int kg = k + d.zoff;
 				get_centered(&d, vel, idx, v);
 				if (orderTrace == 1) {
 					px = (i + 0.5f) - v[0] * dt;
 					py = (j + 0.5f) - v[1] * dt;
-					pz = (k + 0.5f) - v[2] * dt;
+					pz = (kg + 0.5f) - v[2] * dt;
 				} else {
 					float p1x = (i + 0.5f) - (float)((v[0] * dt) * 0.5);
 					float p1y = (j + 0.5f) - (float)((v[1] * dt) * 0.5);
-					float p1z = (k + 0.5f) - (float)((v[2] * dt) * 0.5);
+					float p1z = (kg + 0.5f) - (float)((v[2] * dt) * 0.5);
 					float u[3];
 					interpol_mac(&d, vel, p1x, p1y, p1z, u);
 					px = (i + 0.5f) - u[0] * dt;
 					py = (j + 0.5f) - u[1] * dt;
-					pz = (k + 0.5f) - u[2] * dt;
+					pz = (kg + 0.5f) - u[2] * dt;
 				}
 				for (int c = 0; c < ncomp; c++) dst[c * d.n + idx] = interpol1(&d, src + c * d.n, px, py, pz);
 			}
@@ -833,28 +853,29 @@ int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, c
 		for (int j = 1; j < sy - 1; j++)
 			for (int i = 1; i < sx - 1; i++) {
 				int64_t idx = IDX(d, i, j, k);
+				const int kg = k + d.zoff;
 				float v[3], r[3];
 				if (orderTrace == 1) {
 					get_at_mac_x(&d, vel, idx, v);
-					r[0] = interpol1(&d, src, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (k + 0.5f) - v[2] * dt);
+					r[0] = interpol1(&d, src, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt);
 					get_at_mac_y(&d, vel, idx, v);
-					r[1] = interpol1(&d, src + n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (k + 0.5f) - v[2] * dt);
+					r[1] = interpol1(&d, src + n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt);
 					get_at_mac_z(&d, vel, idx, v);
-					r[2] = interpol1(&d, src + 2 * n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (k + 0.5f) - v[2] * dt);
+					r[2] = interpol1(&d, src + 2 * n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt);
 				} else {
 					float u[3];
-					const float p0x = (float)(i + 0.5), p0y = (float)(j + 0.5), p0z = (float)(k + 0.5);
+					const float p0x = (float)(i + 0.5), p0y = (float)(j + 0.5), p0z = (float)(kg + 0.5);
 					get_at_mac_x(&d, src, idx, v);
 					interpol_mac(&d, src, (float)i - (float)((v[0] * dt) * 0.5), (j + 0.5f) - (float)((v[1] * dt) * 0.5),
-					             (k + 0.5f) - (float)((v[2] * dt) * 0.5), u);
+					             (kg + 0.5f) - (float)((v[2] * dt) * 0.5), u);
 					r[0] = interpol1(&d, src, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
 					get_at_mac_y(&d, src, idx, v);
 					interpol_mac(&d, src, (i + 0.5f) - (float)((v[0] * dt) * 0.5), (float)j - (float)((v[1] * dt) * 0.5),
-					             (k + 0.5f) - (float)((v[2] * dt) * 0.5), u);
+					             (kg + 0.5f) - (float)((v[2] * dt) * 0.5), u);
 					r[1] = interpol1(&d, src + n, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
 					get_at_mac_z(&d, src, idx, v);
 					interpol_mac(&d, src, (i + 0.5f) - (float)((v[0] * dt) * 0.5), (j + 0.5f) - (float)((v[1] * dt) * 0.5),
-					             (float)k - (float)((v[2] * dt) * 0.5), u);
+					             (float)kg - (float)((v[2] * dt) * 0.5), u);
 					r[2] = interpol1(&d, src + 2 * n, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
 				}
 				dst[idx] = r[0];
@@ -938,11 +959,11 @@ static void do_clamp_component(const Dim* d, int ncomp, const int32_t* flags, fl
 		pos[1][1] = (int)(py + vel[1]);
 		pos[1][2] = (int)(pz + vel[2]);
 	}
-	const int gx = d->sx - 1, gy = d->sy - 1, gz = d->sz - 1;
+	const int gx = d->sx - 1, gy = d->sy - 1, gz = d->gsz - 1;
 	for (int l = 0; l < numPos; l++) {
 		const int i0 = clampi(pos[l][0], 0, gx - 1);
 		const int j0 = clampi(pos[l][1], 0, gy - 1);
-		const int k0 = clampi(pos[l][2], 0, d->is3d ? (gz - 1) : 1);
+		const int k0 = local_z(d, clampi(pos[l][2], 0, d->is3d ? (gz - 1) : 1), 1);
 		const int i1 = i0 + 1, j1 = j0 + 1, k1 = d->is3d ? (k0 + 1) : k0;
 		const int ii[8] = {i0, i1, i0, i1, i0, i1, i0, i1};
 		const int jj[8] = {j0, j0, j1, j1, j0, j0, j1, j1};
@@ -982,12 +1003,13 @@ int mf_maccormack_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags,
 	(void)st;
 	Dim d = mkdim(sx, sy, sz);
 	const int64_t n = d.n;
-	const int gx = sx - 1, gy = sy - 1, gz = sz - 1;
+	const int gx = sx - 1, gy = sy - 1, gz = d.gsz - 1;
 #pragma omp parallel for
 	for (int k = K0(d, 1); k < K1(d, 1); k++)
 		for (int j = 1; j < sy - 1; j++)
 			for (int i = 1; i < sx - 1; i++) {
 				int64_t idx = IDX(d, i, j, k);
+				const int kg = k + d.zoff;
 				float dval[3], fw[3], v[3], vd[3];
 				for (int c = 0; c < ncomp; c++) {
 					dval[c] = dst[c * n + idx];
@@ -997,14 +1019,14 @@ int mf_maccormack_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags,
 				vd[0] = v[0] * dt;
 				vd[1] = v[1] * dt;
 				vd[2] = v[2] * dt;
-				do_clamp_component(&d, ncomp, flags, dval, orig, fw, (float)i, (float)j, (float)k, vd, clampMode);
+				do_clamp_component(&d, ncomp, flags, dval, orig, fw, (float)i, (float)j, (float)kg, vd, clampMode);
 				if (clampMode == 1) {
 					/* Vec3(i,j,k) + Vec3(0.5,0.5,0.5) -+ vel*dt, truncated */
-					int fx = (int)(((float)i + 0.5f) - vd[0]), fy = (int)(((float)j + 0.5f) - vd[1]), fz = (int)(((float)k + 0.5f) - vd[2]);
-					int bx = (int)(((float)i + 0.5f) + vd[0]), by = (int)(((float)j + 0.5f) + vd[1]), bz = (int)(((float)k + 0.5f) + vd[2]);
+					int fx = (int)(((float)i + 0.5f) - vd[0]), fy = (int)(((float)j + 0.5f) - vd[1]), fz = (int)(((float)kg + 0.5f) - vd[2]);
+					int bx = (int)(((float)i + 0.5f) + vd[0]), by = (int)(((float)j + 0.5f) + vd[1]), bz = (int)(((float)kg + 0.5f) + vd[2]);
 					int bad = fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > gx || fy > gy ||
 					          ((fz > gz) && d.is3d) || bx > gx || by > gy || ((bz > gz) && d.is3d);
-					if (!bad) bad = (flags[IDX(d, fx, fy, fz)] & MF_OBSTACLE) || (flags[IDX(d, bx, by, bz)] & MF_OBSTACLE);
+					if (!bad) bad = (flags[IDX(d, fx, fy, local_z(&d, fz, 0))] & MF_OBSTACLE) || (flags[IDX(d, bx, by, local_z(&d, bz, 0))] & MF_OBSTACLE);
 					if (bad)
 						for (int c = 0; c < ncomp; c++) dval[c] = fw[c];
 				}
@@ -1016,7 +1038,7 @@ int mf_maccormack_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags,
 static float do_clamp_component_mac(const Dim* d, int c, const int32_t* flags, float dst, const float* orig, float fwd,
                                     int i, int j, int k, const float vel[3], int clampMode) {
 	float minv = FLT_MAX, maxv = -FLT_MAX;
-	const float px = (float)i, py = (float)j, pz = (float)k;
+	const float px = (float)i, py = (float)j, pz = (float)(k + d->zoff);
 	int pos[2][3];
 	int numPos = 1;
 	pos[0][0] = (int)(px - vel[0]);
@@ -1032,12 +1054,12 @@ static float do_clamp_component_mac(const Dim* d, int c, const int32_t* flags, f
 	nb[c] -= 1;
 	if (clampMode == 2 && !(CHECKFLAG(flags[IDX(*d, o[0], o[1], o[2])]) && CHECKFLAG(flags[IDX(*d, nb[0], nb[1], nb[2])])))
 		return fwd;
-	const int gx = d->sx - 1, gy = d->sy - 1, gz = d->sz - 1;
+	const int gx = d->sx - 1, gy = d->sy - 1, gz = d->gsz - 1;
 	const float* oc = orig + c * d->n;
 	for (int l = 0; l < numPos; l++) {
 		const int i0 = clampi(pos[l][0], 0, gx - 1);
 		const int j0 = clampi(pos[l][1], 0, gy - 1);
-		const int k0 = clampi(pos[l][2], 0, d->is3d ? (gz - 1) : 0);
+		const int k0 = local_z(d, clampi(pos[l][2], 0, d->is3d ? (gz - 1) : 0), 1);
 		const int i1 = i0 + 1, j1 = j0 + 1, k1 = d->is3d ? (k0 + 1) : k0;
 		const int ii[8] = {i0, i1, i0, i1, i0, i1, i0, i1};
 		const int jj[8] = {j0, j0, j1, j1, j0, j0, j1, j1};

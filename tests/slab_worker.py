@@ -1,0 +1,58 @@
+"""Worker for the z-slab tests: run under torch.distributed.run (gloo on CPU with the oracle library, or -- on the
+GPU box -- gloo with every rank on cuda:0 through the HIP library).  Writes the owned planes of its results."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import util  # noqa: E402
+from mantaflow_amd import _lib  # noqa: E402
+
+
+def main():
+    out, backend = sys.argv[1], sys.argv[2]
+    dims = tuple(int(v) for v in sys.argv[3].split("x"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    if backend == "oracle":
+        _lib.use_library(util.build_oracle(), "cpu")
+    else:
+        torch.cuda.set_device(0)
+        _lib.get()
+    from mantaflow_amd import core, slab
+    NX, NY, NZ = dims
+    dom = slab.SlabDomain((NX, NY, NZ), slab.required_ghost(2.0))
+    s = dom.solver
+    s.timestep = 0.9
+    flags_g = util.make_flags(NX, NY, NZ, 51, obstacles=True, empty_top=True)
+    vel_g = util.smooth_vel(NX, NY, NZ, 52, 2.0)
+    vel_g[2] *= 0.95
+    dens_g = util.rand_real((NZ, NY, NX), 53)
+    flags, vel, dens, pres = core.FlagGrid(s), core.MACGrid(s), core.Grid(s), core.Grid(s)
+    dom.scatter_global(flags, flags_g); dom.scatter_global(vel, vel_g); dom.scatter_global(dens, dens_g)
+    slab.advectSemiLagrange(dom, flags, vel, dens, order=2)
+    slab.advectSemiLagrange(dom, flags, vel, vel, order=2)
+    dom.exchange(vel, 1)
+    slab.setWallBcs(dom, flags, vel)
+    vel_adv = dom.gather_owned(vel).copy()
+    st = {}
+    slab.solvePressure(dom, vel, pres, flags, cgAccuracy=1e-4, stats=st)
+    # divergence of the projected field on the owned planes
+    dom.exchange(vel, 1)
+    rhs = core.Grid(s)
+    s.lib.call("mf_make_rhs", NX, NY, dom.LZ, flags.ptr, rhs.ptr, vel.ptr, None, None, None, None, None, 0.0, 1e-4, None, None, s.stream)
+    np.savez(out + ".%d.npz" % dom.comm.rank, z0=dom.z0, z1=dom.z1, dens=dom.gather_owned(dens), vel_adv=vel_adv,
+             vel=dom.gather_owned(vel), pres=dom.gather_owned(pres), div=dom.gather_owned(rhs), iters=st["iterations"], res=st["residual"])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+"""-m gpu: the z-slab path through the HIP library, rehearsed with 2 ranks sharing the one GPU of the box (gloo, halo
+planes staged through the host).  The N>1 RCCL launch itself is exercised by the driver's scaling bench."""
+import numpy as np
+import pytest
+
+import util
+from test_slab_gloo import check_against_single, run_world
+
+pytestmark = pytest.mark.gpu
+
+
+def test_slab_two_ranks_on_hip(tmp_path):
+    single = run_world(tmp_path, 1, "hip", dims="32x24x40")
+    multi = run_world(tmp_path, 2, "hip", dims="32x24x40")
+    check_against_single(single, multi)
+    # and the single-rank HIP slab run equals the oracle's single-rank run (advection bit-exact)
+    ora = run_world(tmp_path, 1, "oracle", dims="32x24x40")
+    util.assert_bitexact(single["dens"], ora["dens"], "density hip vs oracle")
+    util.assert_bitexact(single["vel_adv"], ora["vel_adv"], "velocity hip vs oracle")
+    assert single["iters"] == ora["iters"]
+    assert util.rel_err(single["pres"], ora["pres"]) < 1e-5

@@ -1,0 +1,79 @@
+"""z-slab multi-rank path on CPU: world_size 2 and 3 over gloo (oracle library) against the single-rank run.
+Advection must be bit-identical on every owned plane; the pressure solve uses slab-local MIC, so it is validated at
+converged-solution level (same stopping rule, divergence removed, pressure close to the single-rank solution)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slab_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(tmp_path, world, backend, dims="20x16x36"):
+    out = str(tmp_path / ("w%d" % world))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    if world == 1:
+        cmd = [sys.executable, WORKER, out, backend, dims]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), WORKER, out, backend, dims]
+    subprocess.run(cmd, check=True, env=env, timeout=600)
+    parts = [dict(np.load(out + ".%d.npz" % r)) for r in range(world)]
+    cat = lambda k, ax: np.concatenate([p[k] for p in parts], axis=ax)
+    return dict(dens=cat("dens", 0), vel_adv=cat("vel_adv", 1), vel=cat("vel", 1), pres=cat("pres", 0), div=cat("div", 0),
+                iters=[int(p["iters"]) for p in parts], res=[float(p["res"]) for p in parts])
+
+
+def check_against_single(single, multi):
+    util.assert_bitexact(multi["dens"], single["dens"], "advected density")
+    util.assert_bitexact(multi["vel_adv"], single["vel_adv"], "advected velocity")
+    assert len(set(multi["iters"])) == 1, "every rank must take identical CG branches"
+    assert max(multi["res"]) < 1e-4
+    assert np.abs(multi["div"]).max() < 2e-3
+    scale = np.abs(single["pres"]).max()
+    assert np.abs(multi["pres"] - single["pres"]).max() < 5e-3 * scale
+    assert np.abs(multi["vel"] - single["vel"]).max() < 5e-3 * max(np.abs(single["vel"]).max(), 1)
+
+
+@pytest.fixture(scope="module")
+def single(tmp_path_factory):
+    return run_world(tmp_path_factory.mktemp("slab1"), 1, "oracle")
+
+
+def test_single_rank_slab_equals_plugin_path(single, oracle_backend):
+    """world 1: the slab driver is the reference algorithm -> bit-identical advection, same CG iterates"""
+    import cases
+    from mantaflow_amd import core, plugins
+    dims = (20, 16, 36)
+    s = cases._mk_solver(dims, 0.9)
+    flags_g = util.make_flags(*dims, 51, obstacles=True, empty_top=True)
+    vel_g = util.smooth_vel(*dims, 52, 2.0); vel_g[2] *= 0.95
+    fl, v, d, p = core.FlagGrid(s), core.MACGrid(s), core.Grid(s), core.Grid(s)
+    cases.soa_to_grid(fl, flags_g); cases.soa_to_grid(v, vel_g); cases.soa_to_grid(d, util.rand_real((36, 16, 20), 53))
+    plugins.advectSemiLagrange(fl, v, d, order=2)
+    plugins.advectSemiLagrange(fl, v, v, order=2)
+    plugins.setWallBcs(fl, v)
+    util.assert_bitexact(cases.grid_to_soa(d), single["dens"], "density")
+    util.assert_bitexact(cases.grid_to_soa(v), single["vel_adv"], "velocity")
+    plugins.solvePressure(v, p, fl, cgAccuracy=1e-4)
+    assert plugins.lastCgStats()["iterations"] == single["iters"][0]
+    assert util.rel_err(cases.grid_to_soa(p), single["pres"]) < 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_world(tmp_path, single, world):
+    multi = run_world(tmp_path, world, "oracle")
+    check_against_single(single, multi)
