@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Focused launcher for rocprofv3: runs one hot kernel family at 256^3 so kernel-trace / PMC output stays small.
+  python3 tools/prof_kernels.py apply_matrix [reps]   |   mic [reps]   |   advect
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import torch  # noqa: E402
+from mantaflow_amd import _lib, core, plugins  # noqa: E402
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "apply_matrix"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    n = int(os.environ.get("MF_GRID", "256"))
+    lib = _lib.get()
+    s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
+    flags = core.FlagGrid(s); flags.initDomain(); flags.fillGrid()
+    A0, Ai, Aj, Ak, src, dst, ap = (core.Grid(s) for _ in range(7))
+    lib.call("mf_make_laplace_matrix", n, n, n, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, s.stream)
+    src.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (n, n, n)).astype(np.float32))
+    if what == "apply_matrix":
+        us = ctypes.c_double()
+        lib.call("mf_time_apply_matrix", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, reps, ctypes.byref(us), s.stream)
+        print("apply_matrix avg %.2f us  %.1f GB/s" % (us.value, 28 * n ** 3 / us.value / 1e3))
+    elif what == "mic":
+        lib.call("mf_mic_init", n, n, n, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.call("mf_mic_apply", n, n, n, flags.ptr, dst.ptr, src.ptr, ap.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        e1.record()
+        torch.cuda.synchronize()
+        print("mic_apply avg %.1f us" % (e0.elapsed_time(e1) * 1e3 / reps))
+    elif what == "advect":
+        vel, dens = core.MACGrid(s), core.Grid(s)
+        vel.from_numpy(np.ascontiguousarray(bench.synthetic_velocity(n, n, n).transpose(1, 2, 3, 0)))
+        dens.from_numpy(bench.synthetic_density(n, n, n))
+        for _ in range(reps):
+            plugins.advectSemiLagrange(flags, vel, dens, order=2)
+            plugins.advectSemiLagrange(flags, vel, vel, order=2)
+        torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
