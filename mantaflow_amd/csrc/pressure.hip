@@ -3,6 +3,7 @@
 // Reference: source/conjugategrad.{h,cpp}, source/plugin/pressure.cpp (cited per kernel).
 #include "common.h"
 #include <float.h>
+#include <stdlib.h>
 
 using namespace mf;
 
@@ -666,12 +667,287 @@ k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restri
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MIC apply as ONE launch per sweep ("dataflow"): one wave per tile, tiles are handed out in hyperplane order by an
+// atomic ticket (a ticketed tile's predecessors hold smaller tickets, i.e. they are already running or finished, so the
+// wait below always ends whatever the dispatch order), and the three faces a tile hands to its +i/+j/+k successors
+// travel as 8-byte {value, tag} granules written with ONE agent-scope (sc1, write-through) store each and polled with
+// agent-scope (sc1, L1-bypassing) loads: no flag, no fence (MI355X_MICROARCH.md, "handoff-1to1").  tag = launch
+// generation, so the exchange buffer never needs clearing.  Per-cell arithmetic is identical to k_mic_tiles.
+// ---------------------------------------------------------------------------------------------------------
+struct FlowCtl {
+	int ticket, finished, err, pad;
+};
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(unsigned long long* p, float v, unsigned tag) {
+	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int FLOW_SPIN_LIMIT = 1 << 21;
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(64)
+k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__ order, FlowCtl* ctl,
+           unsigned long long* xch, unsigned gen, const int32_t* __restrict__ flags, float* __restrict__ dst,
+           const float* __restrict__ var1, const float* __restrict__ Ap, const float* __restrict__ Ai,
+           const float* __restrict__ Aj, const float* __restrict__ Ak, const CgScalars* __restrict__ sc) {
+	static_assert(MODE == 1 || MODE == 2, "dataflow kernel implements the apply sweeps");
+	constexpr bool REV = (MODE == 2);
+	if (sc && sc->done) return;
+	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	int t = 0;
+	if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
+	t = __builtin_amdgcn_readfirstlane(t);
+	const int packed = order[t];
+	const int til = packed & 1023, tjl = (packed >> 10) & 1023, tkl = (packed >> 20) & 1023;
+	const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
+	const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
+	const int x0 = ti * 8, j = tj * 8 + lj, k = tk * 8 + lk;
+	const bool row_in = (j < d.sy) && (k < d.sz);
+	const int64_t rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
+	const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+	const int nv = row_in ? nvx : 0;
+	// logical tile ids (granule addressing)
+	const int64_t tid = ((int64_t)tkl * ntj + tjl) * nti + til;
+	const bool has_pi = til > 0, has_pj = tjl > 0, has_pk = tkl > 0;
+	const bool has_si = til + 1 < nti, has_sj = tjl + 1 < ntj, has_sk = tkl + 1 < ntk;
+	unsigned long long* out_i = xch + ((tid * 3 + 0) << 6);
+	unsigned long long* out_j = xch + ((tid * 3 + 1) << 6);
+	unsigned long long* out_k = xch + ((tid * 3 + 2) << 6);
+	const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6);
+	const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6);
+	const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6);
+
+	__shared__ float sV[512], sAi[512], sAj[512], sAk[512], sP[512], sD[512];
+	__shared__ int sF[512];
+	__shared__ float sHj[64], sHk[64];
+
+	// ---- own row: static operands (issued before the wait on the predecessors, so their latency is hidden) ----
+	int rF[8];
+	float rV[8], rAi[8], rAj[8], rAk[8], rP[8], rD[8];
+	load_row8i<VEC, REV>(flags, rowbase, nv, rF);
+	load_row8<VEC, REV>(var1, rowbase, nv, rV);
+	load_row8<VEC, REV>(Ai, rowbase, nv, rAi);
+	load_row8<VEC, REV>(Aj, rowbase, nv, rAj);
+	load_row8<VEC, REV>(Ak, rowbase, nv, rAk);
+	load_row8<VEC, REV>(Ap, rowbase, nv, rP);
+	load_row8<VEC, REV>(dst, rowbase, nv, rD);
+#pragma unroll
+	for (int a = 0; a < 8; a++) {
+		const int s = lane * 8 + a;
+		const bool in = ((REV ? 7 - a : a) < nv);
+		const int fl = in ? ((rF[a] & MF_FLUID) ? 1 : 2) : 0;
+		sF[s] = fl;
+		sV[s] = (fl == 1) ? rV[a] : 0.f;
+		sAi[s] = rAi[a];
+		sAj[s] = rAj[a];
+		sAk[s] = rAk[a];
+		sP[s] = rP[a];
+		sD[s] = rD[a];
+	}
+
+	// ---- wait for the predecessors' faces ----
+	float hi0 = 0.f;
+	int spins = 0;
+	bool timeout = false;
+	if (has_pi) {
+		unsigned long long g = granule_load(in_i + lane);
+		while ((unsigned)(g >> 32) != gen) {
+			if (++spins > FLOW_SPIN_LIMIT) { timeout = true; break; }
+			__builtin_amdgcn_s_sleep(8);
+			g = granule_load(in_i + lane);
+		}
+		hi0 = __uint_as_float((unsigned)g);
+	}
+	if (has_pj && b == 0) {
+		for (;;) {
+			unsigned long long g[8];
+			bool ok = true;
+#pragma unroll
+			for (int a = 0; a < 8; a++) g[a] = granule_load(in_j + c * 8 + a);
+#pragma unroll
+			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(g[a] >> 32) == gen);
+			if (ok || ++spins > FLOW_SPIN_LIMIT) {
+				timeout = timeout || !ok;
+#pragma unroll
+				for (int a = 0; a < 8; a++) sHj[c * 8 + a] = __uint_as_float((unsigned)g[a]);
+				break;
+			}
+			__builtin_amdgcn_s_sleep(8);
+		}
+	} else if (b == 0) {
+#pragma unroll
+		for (int a = 0; a < 8; a++) sHj[c * 8 + a] = 0.f;
+	}
+	if (has_pk && c == 0) {
+		for (;;) {
+			unsigned long long g[8];
+			bool ok = true;
+#pragma unroll
+			for (int a = 0; a < 8; a++) g[a] = granule_load(in_k + b * 8 + a);
+#pragma unroll
+			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(g[a] >> 32) == gen);
+			if (ok || ++spins > FLOW_SPIN_LIMIT) {
+				timeout = timeout || !ok;
+#pragma unroll
+				for (int a = 0; a < 8; a++) sHk[b * 8 + a] = __uint_as_float((unsigned)g[a]);
+				break;
+			}
+			__builtin_amdgcn_s_sleep(8);
+		}
+	} else if (c == 0) {
+#pragma unroll
+		for (int a = 0; a < 8; a++) sHk[b * 8 + a] = 0.f;
+	}
+	if (timeout) atomicExch(&ctl->err, 1);
+	__syncthreads();
+
+	// ---- 22 cell hyperplanes; faces are published the moment they are final ----
+	float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+#pragma unroll 2
+	for (int h = 0; h < 22; h++) {
+		const int a = h - b - c;
+		const bool valid = (a >= 0) && (a < 8);
+		const int ac = a < 0 ? 0 : (a > 7 ? 7 : a);
+		float ij0 = __shfl_up(oj0, 1, 64), ik0 = __shfl_up(ok0, 8, 64);
+		if (b == 0) ij0 = sHj[c * 8 + ac];
+		if (c == 0) ik0 = sHk[b * 8 + ac];
+		const float ii0 = (a == 0) ? hi0 : oi0;
+		if (valid) {
+			const int s = lane * 8 + ac;
+			const int fl = sF[s];
+			const float ai = sAi[s], aj = sAj[s], ak = sAk[s];
+			const float p = sP[s];
+			float val = sD[s];
+			if (MODE == 1) {
+				if (fl == 1) {
+					val = p * (sV[s] - ii0 - ij0 - ik0);
+					sD[s] = val;
+				}
+				oi0 = (val * ai) * p;
+				oj0 = (val * aj) * p;
+				ok0 = (val * ak) * p;
+			} else {
+				if (fl == 1) {
+					val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+					sD[s] = val;
+				}
+				oi0 = oj0 = ok0 = val;
+			}
+			if (has_si && a == 7) granule_store(out_i + lane, oi0, gen);
+			if (has_sj && b == 7) granule_store(out_j + c * 8 + a, oj0, gen);
+			if (has_sk && c == 7) granule_store(out_k + b * 8 + a, ok0, gen);
+		}
+	}
+	__syncthreads();
+	float w[8];
+#pragma unroll
+	for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = sD[lane * 8 + a];
+	if (VEC) {
+		if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
+		if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (e < nv) dst[rowbase + e] = w[e];
+	}
+	// the last tile to finish re-arms the ticket for the next sweep (visible at the kernel boundary)
+	if (lane == 0) {
+		const int f = atomicAdd(&ctl->finished, 1);
+		if (f == ntiles - 1) {
+			ctl->ticket = 0;
+			ctl->finished = 0;
+		}
+	}
+}
+
+// host-side state of the dataflow sweeps (per device): tile order for the current grid, exchange buffer, generation
+struct FlowState {
+	int nti = 0, ntj = 0, ntk = 0, ntiles = 0;
+	int* order = nullptr;
+	unsigned long long* xch = nullptr;
+	size_t xch_cap = 0;
+	FlowCtl* ctl = nullptr;
+	unsigned gen = 0;
+};
+static FlowState g_flow[16];
+
+static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
+	if (nti > 1023 || ntj > 1023 || ntk > 1023) return fail("grid too large for the MIC tile order table");
+	if (!f.ctl) {
+		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+	}
+	if (f.nti != nti || f.ntj != ntj || f.ntk != ntk) {
+		MF_HIP(hipStreamSynchronize(st));
+		const int nt = nti * ntj * ntk;
+		int* h = (int*)malloc(sizeof(int) * nt);
+		int q = 0;
+		for (int L = 0; L <= nti + ntj + ntk - 3; L++)
+			for (int tk = 0; tk < ntk; tk++)
+				for (int tj = 0; tj < ntj; tj++) {
+					const int ti = L - tj - tk;
+					if (ti >= 0 && ti < nti) h[q++] = ti | (tj << 10) | (tk << 20);
+				}
+		if (f.order) MF_HIP(hipFree(f.order));
+		MF_HIP(hipMalloc((void**)&f.order, sizeof(int) * nt));
+		MF_HIP(hipMemcpy(f.order, h, sizeof(int) * nt, hipMemcpyHostToDevice));
+		free(h);
+		const size_t need = (size_t)nt * 3 * 64 * sizeof(unsigned long long);
+		if (need > f.xch_cap) {
+			if (f.xch) MF_HIP(hipFree(f.xch));
+			MF_HIP(hipMalloc((void**)&f.xch, need));
+			f.xch_cap = need;
+		}
+		MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+		f.gen = 0;
+		f.nti = nti;
+		f.ntj = ntj;
+		f.ntk = ntk;
+		f.ntiles = nt;
+	}
+	*out = &f;
+	return 0;
+}
+static int g_mic_mode = -1;  // 0: one launch per tile hyperplane, 1: dataflow (default)
+static int mic_mode() {
+	if (g_mic_mode < 0) {
+		const char* e = getenv("MF_MIC_MODE");
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : 1;
+	}
+	return g_mic_mode;
+}
+
 template <int MODE>
 static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                       const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
 	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
 	const int levels = nti + ntj + ntk - 2;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
+	if constexpr (MODE != 0) {
+		if (mic_mode() == 1) {
+			FlowState* f;
+			MF_TRY(flow_prepare(d, &f, st));
+			f->gen++;
+			if (f->gen == 0) {  // 32-bit wrap: stale tags could alias -> clear once
+				MF_HIP(hipMemsetAsync(f->xch, 0, f->xch_cap, st));
+				f->gen = 1;
+			}
+			if (vec)
+				hipLaunchKernelGGL((k_mic_flow<MODE, true>), dim3(f->ntiles), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+			else
+				hipLaunchKernelGGL((k_mic_flow<MODE, false>), dim3(f->ntiles), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+			MF_LAUNCH_CHECK();
+			return 0;
+		}
+	}
 	for (int L = 0; L < levels; L++) {
 		if (vec)
 			hipLaunchKernelGGL((k_mic_tiles<MODE, true>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
@@ -1046,6 +1322,18 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	out_host[0] = (float)h.iterations;
 	out_host[1] = h.resNorm;
 	out_host[2] = h.sigma;
+	if (pc == MF_PC_MICP && mic_mode() == 1) {
+		int dev = 0;
+		MF_HIP(hipGetDevice(&dev));
+		if (g_flow[dev].ctl) {
+			FlowCtl fc;
+			MF_HIP(hipMemcpy(&fc, g_flow[dev].ctl, sizeof fc, hipMemcpyDeviceToHost));
+			if (fc.err) {
+				MF_HIP(hipMemset(g_flow[dev].ctl, 0, sizeof(FlowCtl)));
+				return fail("MIC dataflow sweep: a tile timed out waiting for its predecessor faces");
+			}
+		}
+	}
 	if (h.diverged) return fail("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.");
 	return 0;
 }
