@@ -711,140 +711,134 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 	const int nv = row_in ? nvx : 0;
 	// logical tile ids (granule addressing)
 	const int64_t tid = ((int64_t)tkl * ntj + tjl) * nti + til;
-	const bool has_pi = til > 0, has_pj = tjl > 0, has_pk = tkl > 0;
-	const bool has_si = til + 1 < nti, has_sj = tjl + 1 < ntj, has_sk = tkl + 1 < ntk;
-	unsigned long long* out_i = xch + ((tid * 3 + 0) << 6);
-	unsigned long long* out_j = xch + ((tid * 3 + 1) << 6);
-	unsigned long long* out_k = xch + ((tid * 3 + 2) << 6);
-	const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6);
-	const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6);
-	const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6);
+	const bool has_pi = til > 0, has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
+	const bool has_si = til + 1 < nti, has_sj = (tjl + 1 < ntj) && (b == 7), has_sk = (tkl + 1 < ntk) && (c == 7);
+	unsigned long long* out_i = xch + ((tid * 3 + 0) << 6) + lane;
+	unsigned long long* out_j = xch + ((tid * 3 + 1) << 6) + c * 8;
+	unsigned long long* out_k = xch + ((tid * 3 + 2) << 6) + b * 8;
+	const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6) + lane;
+	const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6) + c * 8;
+	const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6) + b * 8;
+	const unsigned long long fresh0 = (unsigned long long)gen << 32;  // {0.f, gen}: "no predecessor" reads as a ready zero
 
-	__shared__ float sV[512], sAi[512], sAj[512], sAk[512], sP[512], sD[512];
-	__shared__ int sF[512];
-	__shared__ float sHj[64], sHk[64];
+	// per cell: {V, Ai, Aj, Ak} and {P, D, fluid}; the faces of the predecessors as {value, tag} granules
+	__shared__ float4 sA[512];
+	__shared__ float4 sB[512];
+	__shared__ unsigned long long sGj[64], sGk[64];
 
-	// ---- own row: static operands (issued before the wait on the predecessors, so their latency is hidden) ----
-	int rF[8];
-	float rV[8], rAi[8], rAj[8], rAk[8], rP[8], rD[8];
-	load_row8i<VEC, REV>(flags, rowbase, nv, rF);
-	load_row8<VEC, REV>(var1, rowbase, nv, rV);
-	load_row8<VEC, REV>(Ai, rowbase, nv, rAi);
-	load_row8<VEC, REV>(Aj, rowbase, nv, rAj);
-	load_row8<VEC, REV>(Ak, rowbase, nv, rAk);
-	load_row8<VEC, REV>(Ap, rowbase, nv, rP);
-	load_row8<VEC, REV>(dst, rowbase, nv, rD);
+	// ---- first (non-blocking) look at the predecessors' faces + own row; everything is in flight together ----
+	unsigned long long gi = has_pi ? granule_load(in_i) : fresh0;
+	if (b == 0) {
+		unsigned long long g[8];
 #pragma unroll
-	for (int a = 0; a < 8; a++) {
-		const int s = lane * 8 + a;
-		const bool in = ((REV ? 7 - a : a) < nv);
-		const int fl = in ? ((rF[a] & MF_FLUID) ? 1 : 2) : 0;
-		sF[s] = fl;
-		sV[s] = (fl == 1) ? rV[a] : 0.f;
-		sAi[s] = rAi[a];
-		sAj[s] = rAj[a];
-		sAk[s] = rAk[a];
-		sP[s] = rP[a];
-		sD[s] = rD[a];
+		for (int a = 0; a < 8; a++) g[a] = has_pj ? granule_load(in_j + a) : fresh0;
+#pragma unroll
+		for (int a = 0; a < 8; a++) sGj[c * 8 + a] = g[a];
 	}
-
-	// ---- wait for the predecessors' faces ----
-	float hi0 = 0.f;
-	int spins = 0;
-	bool timeout = false;
-	if (has_pi) {
-		unsigned long long g = granule_load(in_i + lane);
-		while ((unsigned)(g >> 32) != gen) {
-			if (++spins > FLOW_SPIN_LIMIT) { timeout = true; break; }
-			__builtin_amdgcn_s_sleep(8);
-			g = granule_load(in_i + lane);
+	if (c == 0) {
+		unsigned long long g[8];
+#pragma unroll
+		for (int a = 0; a < 8; a++) g[a] = has_pk ? granule_load(in_k + a) : fresh0;
+#pragma unroll
+		for (int a = 0; a < 8; a++) sGk[b * 8 + a] = g[a];
+	}
+	{
+		int rF[8];
+		float rV[8], rAi[8], rAj[8], rAk[8], rP[8], rD[8];
+		load_row8i<VEC, REV>(flags, rowbase, nv, rF);
+		load_row8<VEC, REV>(var1, rowbase, nv, rV);
+		load_row8<VEC, REV>(Ai, rowbase, nv, rAi);
+		load_row8<VEC, REV>(Aj, rowbase, nv, rAj);
+		load_row8<VEC, REV>(Ak, rowbase, nv, rAk);
+		load_row8<VEC, REV>(Ap, rowbase, nv, rP);
+		load_row8<VEC, REV>(dst, rowbase, nv, rD);
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			const int s = lane * 8 + a;
+			const bool in = ((REV ? 7 - a : a) < nv);
+			const bool fl = in && (rF[a] & MF_FLUID);
+			sA[s] = make_float4(fl ? rV[a] : 0.f, rAi[a], rAj[a], rAk[a]);
+			sB[s] = make_float4(rP[a], rD[a], fl ? 1.f : 0.f, 0.f);
 		}
-		hi0 = __uint_as_float((unsigned)g);
 	}
-	if (has_pj && b == 0) {
-		for (;;) {
-			unsigned long long g[8];
-			bool ok = true;
-#pragma unroll
-			for (int a = 0; a < 8; a++) g[a] = granule_load(in_j + c * 8 + a);
-#pragma unroll
-			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(g[a] >> 32) == gen);
-			if (ok || ++spins > FLOW_SPIN_LIMIT) {
-				timeout = timeout || !ok;
-#pragma unroll
-				for (int a = 0; a < 8; a++) sHj[c * 8 + a] = __uint_as_float((unsigned)g[a]);
-				break;
-			}
-			__builtin_amdgcn_s_sleep(8);
-		}
-	} else if (b == 0) {
-#pragma unroll
-		for (int a = 0; a < 8; a++) sHj[c * 8 + a] = 0.f;
-	}
-	if (has_pk && c == 0) {
-		for (;;) {
-			unsigned long long g[8];
-			bool ok = true;
-#pragma unroll
-			for (int a = 0; a < 8; a++) g[a] = granule_load(in_k + b * 8 + a);
-#pragma unroll
-			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(g[a] >> 32) == gen);
-			if (ok || ++spins > FLOW_SPIN_LIMIT) {
-				timeout = timeout || !ok;
-#pragma unroll
-				for (int a = 0; a < 8; a++) sHk[b * 8 + a] = __uint_as_float((unsigned)g[a]);
-				break;
-			}
-			__builtin_amdgcn_s_sleep(8);
-		}
-	} else if (c == 0) {
-#pragma unroll
-		for (int a = 0; a < 8; a++) sHk[b * 8 + a] = 0.f;
-	}
-	if (timeout) atomicExch(&ctl->err, 1);
 	__syncthreads();
 
-	// ---- 22 cell hyperplanes; faces are published the moment they are final ----
+	// ---- 22 cell hyperplanes.  Operands of step h+1 are fetched from LDS while step h computes; a face value that is
+	// not there yet is polled for when (and only when) it is needed, so a tile runs as close as 8 steps behind its
+	// predecessors instead of a whole tile behind. ----
 	float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+	int spins = 0;
+	const int a0 = -b - c;
+	int an = a0 < 0 ? 0 : a0;
+	float4 nA = sA[lane * 8 + an], nB = sB[lane * 8 + an];
+	unsigned long long nGj = sGj[c * 8 + an], nGk = sGk[b * 8 + an];
 #pragma unroll 2
 	for (int h = 0; h < 22; h++) {
 		const int a = h - b - c;
 		const bool valid = (a >= 0) && (a < 8);
 		const int ac = a < 0 ? 0 : (a > 7 ? 7 : a);
-		float ij0 = __shfl_up(oj0, 1, 64), ik0 = __shfl_up(ok0, 8, 64);
-		if (b == 0) ij0 = sHj[c * 8 + ac];
-		if (c == 0) ik0 = sHk[b * 8 + ac];
-		const float ii0 = (a == 0) ? hi0 : oi0;
+		const float4 cA = nA, cB = nB;
+		unsigned long long gj = nGj, gk = nGk;
+		{
+			const int a1 = a + 1;
+			an = a1 < 0 ? 0 : (a1 > 7 ? 7 : a1);
+			nA = sA[lane * 8 + an];
+			nB = sB[lane * 8 + an];
+			nGj = sGj[c * 8 + an];
+			nGk = sGk[b * 8 + an];
+		}
+		// neighbours inside the tile: lane-1 (same 16-lane DPP row for b > 0) and lane-8
+		float ij0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+		float ik0 = __shfl_up(ok0, 8, 64);
+		float ii0 = oi0;
 		if (valid) {
-			const int s = lane * 8 + ac;
-			const int fl = sF[s];
-			const float ai = sAi[s], aj = sAj[s], ak = sAk[s];
-			const float p = sP[s];
-			float val = sD[s];
-			if (MODE == 1) {
-				if (fl == 1) {
-					val = p * (sV[s] - ii0 - ij0 - ik0);
-					sD[s] = val;
+			if (b == 0) {
+				while ((unsigned)(gj >> 32) != gen) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+					gj = granule_load(in_j + ac);
 				}
+				ij0 = __uint_as_float((unsigned)gj);
+			}
+			if (c == 0) {
+				while ((unsigned)(gk >> 32) != gen) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+					gk = granule_load(in_k + ac);
+				}
+				ik0 = __uint_as_float((unsigned)gk);
+			}
+			if (a == 0) {
+				while ((unsigned)(gi >> 32) != gen) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+					gi = granule_load(in_i);
+				}
+				ii0 = __uint_as_float((unsigned)gi);
+			}
+			const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+			const bool fl = cB.z != 0.f;
+			float val = cB.y;
+			if (MODE == 1) {
+				if (fl) val = p * (cA.x - ii0 - ij0 - ik0);
 				oi0 = (val * ai) * p;
 				oj0 = (val * aj) * p;
 				ok0 = (val * ak) * p;
 			} else {
-				if (fl == 1) {
-					val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
-					sD[s] = val;
-				}
+				if (fl) val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
 				oi0 = oj0 = ok0 = val;
 			}
-			if (has_si && a == 7) granule_store(out_i + lane, oi0, gen);
-			if (has_sj && b == 7) granule_store(out_j + c * 8 + a, oj0, gen);
-			if (has_sk && c == 7) granule_store(out_k + b * 8 + a, ok0, gen);
+			if (has_si && a == 7) granule_store(out_i, oi0, gen);
+			if (has_sj) granule_store(out_j + a, oj0, gen);
+			if (has_sk) granule_store(out_k + a, ok0, gen);
+			if (fl) sB[lane * 8 + ac].y = val;
 		}
 	}
+	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
 	__syncthreads();
 	float w[8];
 #pragma unroll
-	for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = sD[lane * 8 + a];
+	for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = sB[lane * 8 + a].y;
 	if (VEC) {
 		if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
 		if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
