@@ -29,17 +29,27 @@ APPLY_MATRIX_BYTES_PER_CELL = 28  # flags 4 + src 4 + A0,Ai,Aj,Ak 16 
 
 
 def synthetic_velocity(sx, sy, sz, seed=7, vmax=2.0):
-    """S-smoke: seeded band-limited velocity, max |v| dt = vmax cells (MAC, SoA [3][z][y][x])"""
+    """S-smoke: MAC velocity = discrete curl of a seeded band-limited vector potential living on the cell
+    edges, so the field is discretely divergence-free like a projected simulation state; scaled to max |v| dt = vmax
+    cells.  SoA [3][z][y][x]."""
     rng = np.random.default_rng(seed)
-    z = np.arange(sz, dtype=np.float32)[:, None, None]
-    y = np.arange(sy, dtype=np.float32)[None, :, None]
-    x = np.arange(sx, dtype=np.float32)[None, None, :]
-    v = np.zeros((3, sz, sy, sx), np.float32)
+    z = np.arange(sz + 1, dtype=np.float32)[:, None, None]
+    y = np.arange(sy + 1, dtype=np.float32)[None, :, None]
+    x = np.arange(sx + 1, dtype=np.float32)[None, None, :]
+    psi = []
     for c in range(3):
+        p = np.zeros((sz + 1, sy + 1, sx + 1), np.float32)
         for _ in range(3):
             k = rng.uniform(0.5, 3.0, 3) * 2 * np.pi / np.array([sz, sy, sx])
             ph = rng.uniform(0, 2 * np.pi, 3)
-            v[c] += np.float32(rng.uniform(-1, 1)) * (np.sin(k[0] * z + ph[0]) * np.sin(k[1] * y + ph[1]) * np.sin(k[2] * x + ph[2])).astype(np.float32)
+            p += np.float32(rng.uniform(-1, 1)) * (np.sin(k[0] * z + ph[0]) * np.sin(k[1] * y + ph[1]) * np.sin(k[2] * x + ph[2])).astype(np.float32)
+        psi.append(p)
+    px, py, pz = psi
+    v = np.empty((3, sz, sy, sx), np.float32)
+    # u = d(psi_z)/dy - d(psi_y)/dz on x-faces, etc. (edge-centred potential -> face-centred curl)
+    v[0] = (pz[:-1, 1:, :-1] - pz[:-1, :-1, :-1]) - (py[1:, :-1, :-1] - py[:-1, :-1, :-1])
+    v[1] = (px[1:, :-1, :-1] - px[:-1, :-1, :-1]) - (pz[:-1, :-1, 1:] - pz[:-1, :-1, :-1])
+    v[2] = (py[:-1, :-1, 1:] - py[:-1, :-1, :-1]) - (px[:-1, 1:, :-1] - px[:-1, :-1, :-1])
     v *= np.float32(vmax / max(np.abs(v).max(), 1e-9))
     return v
 

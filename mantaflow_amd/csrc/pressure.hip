@@ -697,9 +697,14 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
 	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	__shared__ float4 sA[512];
+	__shared__ float4 sB[512];
+	__shared__ unsigned long long sGj[64], sGk[64];
+	for (;;) {
 	int t = 0;
 	if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
 	t = __builtin_amdgcn_readfirstlane(t);
+	if (t >= ntiles) break;
 	const int packed = order[t];
 	const int til = packed & 1023, tjl = (packed >> 10) & 1023, tkl = (packed >> 20) & 1023;
 	const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
@@ -721,10 +726,7 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 	const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6) + b * 8;
 	const unsigned long long fresh0 = (unsigned long long)gen << 32;  // {0.f, gen}: "no predecessor" reads as a ready zero
 
-	// per cell: {V, Ai, Aj, Ak} and {P, D, fluid}; the faces of the predecessors as {value, tag} granules
-	__shared__ float4 sA[512];
-	__shared__ float4 sB[512];
-	__shared__ unsigned long long sGj[64], sGk[64];
+	// per cell: {V, Ai, Aj, Ak} and {P, D, fluid}; the faces of the predecessors as {value, tag} granules (LDS above)
 
 	// ---- first (non-blocking) look at the predecessors' faces + own row; everything is in flight together ----
 	unsigned long long gi = has_pi ? granule_load(in_i) : fresh0;
@@ -847,10 +849,262 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 		for (int e = 0; e < 8; e++)
 			if (e < nv) dst[rowbase + e] = w[e];
 	}
-	// the last tile to finish re-arms the ticket for the next sweep (visible at the kernel boundary)
+	__syncthreads();
+	}  // ticket loop
+	// the last workgroup to leave re-arms the ticket for the next sweep (visible at the kernel boundary)
 	if (lane == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
-		if (f == ntiles - 1) {
+		if (f == (int)gridDim.x - 1) {
+			ctl->ticket = 0;
+			ctl->finished = 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MIC apply, streaming form: one workgroup of 4 waves owns a 16x16 block of x-rows (2x2 "pencils" of 8x8 rows) and
+// streams along x.  Lane (B,C) of the block works on cell a = h - B - C at step h, so the i-dependency stays in a
+// register, the j/k dependencies inside a wave move by DPP / ds_bpermute, between the 4 waves through LDS (one
+// s_barrier per step), and only the two outer faces of a block cross workgroups -- as tagged 8-byte sc1 granules,
+// fetched in batches of 8 x-positions.  A block never re-loads operands per tile: its rows are fetched once in
+// 8-cell chunks, two chunks ahead, through a 3-slot LDS ring.  256^3: 256 blocks = one per CU, 30 block hops per
+// sweep instead of 94 tile hops.  Per-cell arithmetic is identical to k_mic_tiles / the reference.
+// ---------------------------------------------------------------------------------------------------------
+template <bool VEC, bool REV>
+__device__ __forceinline__ void load_chunk8(const float* __restrict__ base, int64_t rowidx0, bool row_in, int q, int sx, float out[8]) {
+	const int xs = REV ? sx - 8 * q - 8 : 8 * q;  // physical x of the chunk's first element (may be < 0 / partly >= sx)
+	float t[8];
+	if (VEC) {
+		const bool v0 = row_in && xs >= 0 && xs < sx, v1 = row_in && xs + 4 >= 0 && xs + 4 < sx;
+		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		float4 lo = *(const float4*)(base + (v0 ? rowidx0 + xs : 0)), hi = *(const float4*)(base + (v1 ? rowidx0 + xs + 4 : 0));
+		if (!v0) lo = z;
+		if (!v1) hi = z;
+		t[0] = lo.x; t[1] = lo.y; t[2] = lo.z; t[3] = lo.w;
+		t[4] = hi.x; t[5] = hi.y; t[6] = hi.z; t[7] = hi.w;
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const int x = xs + e;
+			const bool v = row_in && x >= 0 && x < sx;
+			const float val = base[v ? rowidx0 + x : 0];
+			t[e] = v ? val : 0.f;
+		}
+	}
+#pragma unroll
+	for (int a = 0; a < 8; a++) out[a] = t[REV ? 7 - a : a];
+}
+struct ChunkRegs {
+	float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+	int F[8];
+};
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(256, 1)
+k_mic_stream(Dim d, int nbj, int nbk, int nblocks, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
+             unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
+             float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
+             const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
+             const CgScalars* __restrict__ sc) {
+	static_assert(MODE == 1 || MODE == 2, "streaming kernel implements the apply sweeps");
+	constexpr bool REV = (MODE == 2);
+	if (sc && sc->done) return;
+	const int tidx = threadIdx.x, wave = tidx >> 6, lane = tidx & 63;
+	const int b = lane & 7, c = lane >> 3, wj = wave & 1, wk = wave >> 1;
+	const int B = b + 8 * wj, C = c + 8 * wk;  // position inside the 16x16 block
+	const int woff = 8 * (wj + wk);            // this wave's step offset
+	const int NXL = 8 * nchunks;
+	const int HTOT = (NXL + 32 + 15) & ~15;
+
+	// operand ring: [wave][slot 0..2][cell 0..7][lane]; cell-major so that a wave's accesses are lane-contiguous
+	__shared__ float4 sA[4 * 3 * 8 * 64];   // {V, Ai, Aj, Ak}
+	__shared__ float2 sB[4 * 3 * 8 * 64];   // {Aprecond, dst}
+	__shared__ unsigned char sF[4 * 3 * 64]; // fluid bit per cell of the chunk
+	__shared__ float hxj[2][2][8], hxk[2][2][8];  // [step parity][wk | wj][c | b] faces handed between the 4 waves
+	__shared__ int sTicket;
+	float4* mA = sA + wave * (3 * 8 * 64);
+	float2* mB = sB + wave * (3 * 8 * 64);
+	unsigned char* mF = sF + wave * (3 * 64);
+
+	for (;;) {
+		if (tidx == 0) sTicket = atomicAdd(&ctl->ticket, 1);
+		__syncthreads();
+		const int t = sTicket;
+		__syncthreads();
+		if (t >= nblocks) break;
+		const int packed = order[t];
+		const int Bjl = packed & 0xffff, Bkl = packed >> 16;  // logical block coordinates
+		const int Jl = 16 * Bjl + B, Kl = 16 * Bkl + C;       // logical row
+		const bool row_in = (Jl < d.sy) && (Kl < d.sz);
+		const int j = REV ? d.sy - 1 - Jl : Jl, k = REV ? d.sz - 1 - Kl : Kl;
+		const int64_t rowidx0 = row_in ? (d.Y * j + d.Z * k) : 0;
+		const int64_t blk = (int64_t)Bkl * nbj + Bjl;
+		const bool pred_j = (Bjl > 0) && (wj == 0) && (b == 0), pred_k = (Bkl > 0) && (wk == 0) && (c == 0);
+		const bool succ_j = (Bjl + 1 < nbj) && (wj == 1) && (b == 7), succ_k = (Bkl + 1 < nbk) && (wk == 1) && (c == 7);
+		unsigned long long* out_j = xj + (blk * 16 + C) * NXL;
+		unsigned long long* out_k = xk + (blk * 16 + B) * NXL;
+		const unsigned long long* in_j = xj + ((blk - 1) * 16 + C) * NXL;
+		const unsigned long long* in_k = xk + ((blk - nbj) * 16 + B) * NXL;
+
+		ChunkRegs st0, st1;  // staging sets for chunks with even / odd index
+		auto issue = [&](ChunkRegs& r, int q) {
+			load_chunk8<VEC, REV>((const float*)flags, rowidx0, row_in, q, d.sx, (float*)r.F);
+			load_chunk8<VEC, REV>(var1, rowidx0, row_in, q, d.sx, r.V);
+			load_chunk8<VEC, REV>(Ai, rowidx0, row_in, q, d.sx, r.Ai);
+			load_chunk8<VEC, REV>(Aj, rowidx0, row_in, q, d.sx, r.Aj);
+			load_chunk8<VEC, REV>(Ak, rowidx0, row_in, q, d.sx, r.Ak);
+			load_chunk8<VEC, REV>(Ap, rowidx0, row_in, q, d.sx, r.P);
+			load_chunk8<VEC, REV>(dst, rowidx0, row_in, q, d.sx, r.D);
+		};
+		auto commit = [&](const ChunkRegs& r, int q) {  // staged registers -> LDS ring slot q % 3
+			const int slot = q % 3;
+			unsigned fm = 0;
+#pragma unroll
+			for (int a = 0; a < 8; a++) {
+				const int x = REV ? d.sx - 1 - (8 * q + a) : 8 * q + a;
+				const bool fl = row_in && x >= 0 && x < d.sx && (r.F[a] & MF_FLUID);
+				fm |= fl ? (1u << a) : 0u;
+				mA[(slot * 8 + a) * 64 + lane] = make_float4(fl ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
+				mB[(slot * 8 + a) * 64 + lane] = make_float2(r.P[a], r.D[a]);
+			}
+			mF[slot * 64 + lane] = (unsigned char)fm;
+		};
+		auto writeback = [&](int q) {  // finished chunk q: LDS ring -> dst (non-fluid cells carry their loaded value)
+			const int slot = q % 3;
+			float w[8];
+#pragma unroll
+			for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = mB[(slot * 8 + a) * 64 + lane].y;
+			const int xs = REV ? d.sx - 8 * q - 8 : 8 * q;
+			if (VEC) {
+				if (row_in && xs >= 0 && xs < d.sx) *(float4*)(dst + rowidx0 + xs) = make_float4(w[0], w[1], w[2], w[3]);
+				if (row_in && xs + 4 >= 0 && xs + 4 < d.sx) *(float4*)(dst + rowidx0 + xs + 4) = make_float4(w[4], w[5], w[6], w[7]);
+			} else {
+#pragma unroll
+				for (int e = 0; e < 8; e++)
+					if (row_in && xs + e >= 0 && xs + e < d.sx) dst[rowidx0 + xs + e] = w[e];
+			}
+		};
+
+		// ---- prologue: chunk 0 straight into the ring, chunks 1 and 2 in flight in the staging registers ----
+		issue(st0, 0);
+		commit(st0, 0);
+		if (nchunks > 1) issue(st1, 1);
+		if (nchunks > 2) issue(st0, 2);
+
+		unsigned long long gj[8], gk[8];
+#pragma unroll
+		for (int e = 0; e < 8; e++) gj[e] = gk[e] = (unsigned long long)gen << 32;
+		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+		int spins = 0;
+		// operands of the first step
+		float4 nA = mA[lane];
+		float2 nB = mB[lane];
+		unsigned nF = mF[lane];
+		if (tidx < 32) ((float*)hxj)[tidx] = 0.f;
+		else if (tidx < 64) ((float*)hxk)[tidx - 32] = 0.f;
+		__syncthreads();
+
+		for (int h0 = 0; h0 < HTOT; h0 += 16) {
+#pragma unroll
+			for (int s = 0; s < 16; s++) {
+				const int h = h0 + s;
+				const int hw = h - woff;
+				const int a = hw - b - c;
+				const bool valid = (a >= 0) && (a < NXL);
+				// ---- every 8 steps: fetch the next batch of the predecessors' face values (blocking poll) ----
+				if ((s & 7) == 0) {
+					if (pred_j) {
+						for (;;) {
+							bool ok = true;
+#pragma unroll
+							for (int e = 0; e < 8; e++) {
+								const int ae = hw - c + e;
+								if (ae >= 0 && ae < NXL) gj[e] = granule_load(in_j + ae);
+								else gj[e] = (unsigned long long)gen << 32;
+							}
+#pragma unroll
+							for (int e = 0; e < 8; e++) ok = ok && ((unsigned)(gj[e] >> 32) == gen);
+							if (ok || ++spins > FLOW_SPIN_LIMIT) break;
+							__builtin_amdgcn_s_sleep(2);
+						}
+					}
+					if (pred_k) {
+						for (;;) {
+							bool ok = true;
+#pragma unroll
+							for (int e = 0; e < 8; e++) {
+								const int ae = hw - b + e;
+								if (ae >= 0 && ae < NXL) gk[e] = granule_load(in_k + ae);
+								else gk[e] = (unsigned long long)gen << 32;
+							}
+#pragma unroll
+							for (int e = 0; e < 8; e++) ok = ok && ((unsigned)(gk[e] >> 32) == gen);
+							if (ok || ++spins > FLOW_SPIN_LIMIT) break;
+							__builtin_amdgcn_s_sleep(2);
+						}
+					}
+				}
+				// ---- every 8 steps: retire the finished chunk, land the staged one, start the loads two chunks ahead ----
+				if ((s & 7) == 6) {
+					const int qd = (hw - 22) >> 3;
+					if (hw >= 22 && qd < nchunks) writeback(qd);
+					const int qc = (hw + 2) >> 3;
+					if (hw + 2 >= 8 && qc < nchunks) {
+						if (qc & 1) {
+							commit(st1, qc);
+							if (qc + 2 < nchunks) issue(st1, qc + 2);
+						} else {
+							commit(st0, qc);
+							if (qc + 2 < nchunks) issue(st0, qc + 2);
+						}
+					}
+				}
+				const float4 cA = nA;
+				const float2 cB = nB;
+				const unsigned cF = nF;
+				{   // operands of the next step (cell a+1 of my row)
+					int a1 = a + 1;
+					a1 = a1 < 0 ? 0 : (a1 >= NXL ? NXL - 1 : a1);
+					const int idx = (((a1 >> 3) % 3) * 8 + (a1 & 7)) * 64 + lane;
+					nA = mA[idx];
+					nB = mB[idx];
+					nF = mF[((a1 >> 3) % 3) * 64 + lane];
+				}
+				float ij0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+				float ik0 = __shfl_up(ok0, 8, 64);
+				const int par = h & 1;
+				if (b == 0) ij0 = (wj == 0) ? __uint_as_float((unsigned)gj[s & 7]) : hxj[par ^ 1][wk][c];
+				if (c == 0) ik0 = (wk == 0) ? __uint_as_float((unsigned)gk[s & 7]) : hxk[par ^ 1][wj][b];
+				const float ii0 = (a == 0) ? 0.f : oi0;
+				if (valid) {
+					const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+					const bool fl = (cF >> (a & 7)) & 1u;
+					float val = cB.y;
+					if (MODE == 1) {
+						if (fl) val = p * (cA.x - ii0 - ij0 - ik0);
+						oi0 = (val * ai) * p;
+						oj0 = (val * aj) * p;
+						ok0 = (val * ak) * p;
+					} else {
+						if (fl) val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+						oi0 = oj0 = ok0 = val;
+					}
+					if (fl) mB[(((a >> 3) % 3) * 8 + (a & 7)) * 64 + lane].y = val;
+					if (succ_j) granule_store(out_j + a, oj0, gen);
+					if (succ_k) granule_store(out_k + a, ok0, gen);
+				}
+				// faces handed to the neighbouring wave of this block (consumed at the next step)
+				if (b == 7 && wj == 0) hxj[par][wk][c] = valid ? oj0 : 0.f;
+				if (c == 7 && wk == 0) hxk[par][wj][b] = valid ? ok0 : 0.f;
+				__syncthreads();
+			}
+		}
+		if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+		__syncthreads();
+	}  // ticket loop
+	if (tidx == 0) {
+		const int f = atomicAdd(&ctl->finished, 1);
+		if (f == (int)gridDim.x - 1) {
 			ctl->ticket = 0;
 			ctl->finished = 0;
 		}
@@ -860,6 +1114,11 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 // host-side state of the dataflow sweeps (per device): tile order for the current grid, exchange buffer, generation
 struct FlowState {
 	int nti = 0, ntj = 0, ntk = 0, ntiles = 0;
+	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;   // streaming form
+	int* border = nullptr;
+	unsigned long long *sxj = nullptr, *sxk = nullptr;
+	size_t sx_cap = 0;
+	unsigned sgen = 0;
 	int* order = nullptr;
 	unsigned long long* xch = nullptr;
 	size_t xch_cap = 0;
@@ -910,11 +1169,55 @@ static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	*out = &f;
 	return 0;
 }
-static int g_mic_mode = -1;  // 0: one launch per tile hyperplane, 1: dataflow (default)
+static int stream_prepare(const Dim& d, FlowState** out, hipStream_t st) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	const int nbj = (d.sy + 15) / 16, nbk = (d.sz + 15) / 16, nchunks = (d.sx + 7) / 8;
+	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC block order table");
+	if (!f.ctl) {
+		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+	}
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks) {
+		MF_HIP(hipStreamSynchronize(st));
+		const int nb = nbj * nbk;
+		int* h = (int*)malloc(sizeof(int) * nb);
+		int q = 0;
+		for (int L = 0; L <= nbj + nbk - 2; L++)
+			for (int bk = 0; bk < nbk; bk++) {
+				const int bj = L - bk;
+				if (bj >= 0 && bj < nbj) h[q++] = bj | (bk << 16);
+			}
+		if (f.border) MF_HIP(hipFree(f.border));
+		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * nb));
+		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * nb, hipMemcpyHostToDevice));
+		free(h);
+		const size_t need = (size_t)nb * 16 * (8 * nchunks) * sizeof(unsigned long long);
+		if (need > f.sx_cap) {
+			if (f.sxj) MF_HIP(hipFree(f.sxj));
+			if (f.sxk) MF_HIP(hipFree(f.sxk));
+			MF_HIP(hipMalloc((void**)&f.sxj, need));
+			MF_HIP(hipMalloc((void**)&f.sxk, need));
+			f.sx_cap = need;
+		}
+		MF_HIP(hipMemset(f.sxj, 0, f.sx_cap));
+		MF_HIP(hipMemset(f.sxk, 0, f.sx_cap));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+		f.sgen = 0;
+		f.nbj = nbj;
+		f.nbk = nbk;
+		f.nblocks = nb;
+		f.nchunks = nchunks;
+	}
+	*out = &f;
+	return 0;
+}
+static int g_mic_mode = -1;  // 0: one launch per tile hyperplane, 1: tile dataflow, 2: block streaming (default)
 static int mic_mode() {
 	if (g_mic_mode < 0) {
 		const char* e = getenv("MF_MIC_MODE");
-		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : 1;
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : 2);
 	}
 	return g_mic_mode;
 }
@@ -926,6 +1229,24 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 	const int levels = nti + ntj + ntk - 2;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
 	if constexpr (MODE != 0) {
+		if (mic_mode() == 2) {
+			FlowState* f;
+			MF_TRY(stream_prepare(d, &f, st));
+			f->sgen++;
+			if (f->sgen == 0) {
+				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
+				MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
+				f->sgen = 1;
+			}
+			int ncu = 256;
+			const int grid = f->nblocks < ncu ? f->nblocks : ncu;
+			if (vec)
+				hipLaunchKernelGGL((k_mic_stream<MODE, true>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+			else
+				hipLaunchKernelGGL((k_mic_stream<MODE, false>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+			MF_LAUNCH_CHECK();
+			return 0;
+		}
 		if (mic_mode() == 1) {
 			FlowState* f;
 			MF_TRY(flow_prepare(d, &f, st));
@@ -934,10 +1255,17 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				MF_HIP(hipMemsetAsync(f->xch, 0, f->xch_cap, st));
 				f->gen = 1;
 			}
+			static int wgs = -1;
+			if (wgs < 0) {
+				const char* e = getenv("MF_FLOW_WGS");
+				wgs = e ? atoi(e) : 1024;
+				if (wgs < 1) wgs = 1;
+			}
+			const int grid = f->ntiles < wgs ? f->ntiles : wgs;
 			if (vec)
-				hipLaunchKernelGGL((k_mic_flow<MODE, true>), dim3(f->ntiles), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_flow<MODE, true>), dim3(grid), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
 			else
-				hipLaunchKernelGGL((k_mic_flow<MODE, false>), dim3(f->ntiles), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_flow<MODE, false>), dim3(grid), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
@@ -1316,7 +1644,7 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	out_host[0] = (float)h.iterations;
 	out_host[1] = h.resNorm;
 	out_host[2] = h.sigma;
-	if (pc == MF_PC_MICP && mic_mode() == 1) {
+	if (pc == MF_PC_MICP && mic_mode() >= 1) {
 		int dev = 0;
 		MF_HIP(hipGetDevice(&dev));
 		if (g_flow[dev].ctl) {

@@ -19,10 +19,29 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "apply_matrix"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n = int(os.environ.get("MF_GRID", "256"))
+    dims = [int(v) for v in os.environ.get("MF_DIMS", "%d,%d,%d" % (n, n, n)).split(",")]
     lib = _lib.get()
-    s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
+    s = core.Solver(gridSize=core.vec3(*dims), dim=3)
     flags = core.FlagGrid(s); flags.initDomain(); flags.fillGrid()
     A0, Ai, Aj, Ak, src, dst, ap = (core.Grid(s) for _ in range(7))
+    if what == "mic":
+        nx, ny, nz = dims
+        lib.call("mf_make_laplace_matrix", nx, ny, nz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, s.stream)
+        src.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (nz, ny, nx)).astype(np.float32))
+        lib.call("mf_mic_init", nx, ny, nz, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            lib.call("mf_mic_apply", nx, ny, nz, flags.ptr, dst.ptr, src.ptr, ap.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        e0.record()
+        for _ in range(reps):
+            lib.call("mf_mic_apply", nx, ny, nz, flags.ptr, dst.ptr, src.ptr, ap.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        e1.record()
+        torch.cuda.synchronize()
+        nt = [(v + 7) // 8 for v in dims]
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        print("mic_apply %s: %.1f us per apply (2 sweeps), tile levels %d -> %.2f us per level per sweep" % (dims, us, sum(nt) - 2, us / 2 / (sum(nt) - 2)))
+        return
     lib.call("mf_make_laplace_matrix", n, n, n, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, s.stream)
     src.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (n, n, n)).astype(np.float32))
     if what == "apply_matrix":
