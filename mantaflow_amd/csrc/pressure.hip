@@ -470,7 +470,6 @@ k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restri
 	const int tjl = blockIdx.x, tkl = blockIdx.y;
 	const int til = level - tjl - tkl;
 	if (til < 0 || til >= nti) return;
-	if (sc && sc->done) return;
 	const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
 	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
 	const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
@@ -582,6 +581,7 @@ k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restri
 		}
 	}
 	__syncthreads();
+	if (sc && sc->done) return;   // checked after the loads were issued: one global round trip less per level
 
 	// ---- 22 cell hyperplanes ----
 	float oi0 = 0.f, oi1 = 0.f, oj0 = 0.f, oj1 = 0.f, ok0 = 0.f, ok1 = 0.f;
@@ -697,160 +697,195 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
 	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
-	__shared__ float4 sA[512];
-	__shared__ float4 sB[512];
-	__shared__ unsigned long long sGj[64], sGk[64];
-	for (;;) {
-	int t = 0;
-	if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
-	t = __builtin_amdgcn_readfirstlane(t);
-	if (t >= ntiles) break;
-	const int packed = order[t];
-	const int til = packed & 1023, tjl = (packed >> 10) & 1023, tkl = (packed >> 20) & 1023;
-	const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
-	const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
-	const int x0 = ti * 8, j = tj * 8 + lj, k = tk * 8 + lk;
-	const bool row_in = (j < d.sy) && (k < d.sz);
-	const int64_t rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
-	const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
-	const int nv = row_in ? nvx : 0;
-	// logical tile ids (granule addressing)
-	const int64_t tid = ((int64_t)tkl * ntj + tjl) * nti + til;
-	const bool has_pi = til > 0, has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
-	const bool has_si = til + 1 < nti, has_sj = (tjl + 1 < ntj) && (b == 7), has_sk = (tkl + 1 < ntk) && (c == 7);
-	unsigned long long* out_i = xch + ((tid * 3 + 0) << 6) + lane;
-	unsigned long long* out_j = xch + ((tid * 3 + 1) << 6) + c * 8;
-	unsigned long long* out_k = xch + ((tid * 3 + 2) << 6) + b * 8;
-	const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6) + lane;
-	const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6) + c * 8;
-	const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6) + b * 8;
-	const unsigned long long fresh0 = (unsigned long long)gen << 32;  // {0.f, gen}: "no predecessor" reads as a ready zero
+	// double-buffered tile operands: while tile n runs its 22 steps out of one buffer, the operands of the tile this
+	// wave will run next are already in flight (its ticket was drawn one tile earlier), so ticket, tile lookup and the
+	// HBM round trip of the operands are off the dependency chain between tiles
+	__shared__ float4 sA[2][512];   // {V, Ai, Aj, Ak}
+	__shared__ float4 sB[2][512];   // {Aprecond, dst, fluid, -}
+	__shared__ float sHj[64], sHk[64];
+	const unsigned long long fresh0 = (unsigned long long)gen << 32;
 
-	// per cell: {V, Ai, Aj, Ak} and {P, D, fluid}; the faces of the predecessors as {value, tag} granules (LDS above)
-
-	// ---- first (non-blocking) look at the predecessors' faces + own row; everything is in flight together ----
-	unsigned long long gi = has_pi ? granule_load(in_i) : fresh0;
-	if (b == 0) {
-		unsigned long long g[8];
-#pragma unroll
-		for (int a = 0; a < 8; a++) g[a] = has_pj ? granule_load(in_j + a) : fresh0;
-#pragma unroll
-		for (int a = 0; a < 8; a++) sGj[c * 8 + a] = g[a];
-	}
-	if (c == 0) {
-		unsigned long long g[8];
-#pragma unroll
-		for (int a = 0; a < 8; a++) g[a] = has_pk ? granule_load(in_k + a) : fresh0;
-#pragma unroll
-		for (int a = 0; a < 8; a++) sGk[b * 8 + a] = g[a];
-	}
-	{
-		int rF[8];
-		float rV[8], rAi[8], rAj[8], rAk[8], rP[8], rD[8];
-		load_row8i<VEC, REV>(flags, rowbase, nv, rF);
-		load_row8<VEC, REV>(var1, rowbase, nv, rV);
-		load_row8<VEC, REV>(Ai, rowbase, nv, rAi);
-		load_row8<VEC, REV>(Aj, rowbase, nv, rAj);
-		load_row8<VEC, REV>(Ak, rowbase, nv, rAk);
-		load_row8<VEC, REV>(Ap, rowbase, nv, rP);
-		load_row8<VEC, REV>(dst, rowbase, nv, rD);
+	struct TileRegs {
+		int F[8];
+		float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+	};
+	auto tile_geom = [&](int packed, int& x0, int64_t& rowbase, int& nv) {
+		const int til = packed & 1023, tjl = (packed >> 10) & 1023, tkl = (packed >> 20) & 1023;
+		const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
+		const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
+		x0 = ti * 8;
+		const int j = tj * 8 + lj, k = tk * 8 + lk;
+		const bool row_in = (j < d.sy) && (k < d.sz);
+		rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
+		const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+		nv = row_in ? nvx : 0;
+	};
+	auto issue = [&](TileRegs& r, int packed) {
+		int x0, nv;
+		int64_t rowbase;
+		tile_geom(packed, x0, rowbase, nv);
+		load_row8i<VEC, REV>(flags, rowbase, nv, r.F);
+		load_row8<VEC, REV>(var1, rowbase, nv, r.V);
+		load_row8<VEC, REV>(Ai, rowbase, nv, r.Ai);
+		load_row8<VEC, REV>(Aj, rowbase, nv, r.Aj);
+		load_row8<VEC, REV>(Ak, rowbase, nv, r.Ak);
+		load_row8<VEC, REV>(Ap, rowbase, nv, r.P);
+		load_row8<VEC, REV>(dst, rowbase, nv, r.D);
+	};
+	auto commit = [&](const TileRegs& r, int packed, int buf) {
+		int x0, nv;
+		int64_t rowbase;
+		tile_geom(packed, x0, rowbase, nv);
 #pragma unroll
 		for (int a = 0; a < 8; a++) {
-			const int s = lane * 8 + a;
 			const bool in = ((REV ? 7 - a : a) < nv);
-			const bool fl = in && (rF[a] & MF_FLUID);
-			sA[s] = make_float4(fl ? rV[a] : 0.f, rAi[a], rAj[a], rAk[a]);
-			sB[s] = make_float4(rP[a], rD[a], fl ? 1.f : 0.f, 0.f);
+			const bool fl = in && (r.F[a] & MF_FLUID);
+			sA[buf][a * 64 + lane] = make_float4(fl ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
+			sB[buf][a * 64 + lane] = make_float4(r.P[a], r.D[a], fl ? 1.f : 0.f, 0.f);
 		}
-	}
-	__syncthreads();
+	};
+	auto draw = [&]() {
+		int t = 0;
+		if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
+		return __builtin_amdgcn_readfirstlane(t);
+	};
 
-	// ---- 22 cell hyperplanes.  Operands of step h+1 are fetched from LDS while step h computes; a face value that is
-	// not there yet is polled for when (and only when) it is needed, so a tile runs as close as 8 steps behind its
-	// predecessors instead of a whole tile behind. ----
-	float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
-	int spins = 0;
-	const int a0 = -b - c;
-	int an = a0 < 0 ? 0 : a0;
-	float4 nA = sA[lane * 8 + an], nB = sB[lane * 8 + an];
-	unsigned long long nGj = sGj[c * 8 + an], nGk = sGk[b * 8 + an];
-#pragma unroll 2
-	for (int h = 0; h < 22; h++) {
-		const int a = h - b - c;
-		const bool valid = (a >= 0) && (a < 8);
-		const int ac = a < 0 ? 0 : (a > 7 ? 7 : a);
-		const float4 cA = nA, cB = nB;
-		unsigned long long gj = nGj, gk = nGk;
-		{
-			const int a1 = a + 1;
-			an = a1 < 0 ? 0 : (a1 > 7 ? 7 : a1);
-			nA = sA[lane * 8 + an];
-			nB = sB[lane * 8 + an];
-			nGj = sGj[c * 8 + an];
-			nGk = sGk[b * 8 + an];
+	int t_cur = draw();
+	int t_nxt = draw();
+	int pk_cur = (t_cur < ntiles) ? order[t_cur] : 0;
+	int pk_nxt = (t_nxt < ntiles) ? order[t_nxt] : 0;
+	TileRegs R;
+	if (t_cur < ntiles) {
+		issue(R, pk_cur);
+		commit(R, pk_cur, 0);
+	}
+	int buf = 0, spins = 0;
+	while (t_cur < ntiles) {
+		int tnn_raw = 0;           // ticket of the tile after next: drawn now, looked at when this tile is done
+		if (lane == 0) tnn_raw = atomicAdd(&ctl->ticket, 1);
+		// ---- geometry of the current tile ----
+		const int til = pk_cur & 1023, tjl = (pk_cur >> 10) & 1023, tkl = (pk_cur >> 20) & 1023;
+		const int64_t tid = ((int64_t)tkl * ntj + tjl) * nti + til;
+		const bool has_pi = til > 0, has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
+		const bool has_si = til + 1 < nti, has_sj = (tjl + 1 < ntj) && (b == 7), has_sk = (tkl + 1 < ntk) && (c == 7);
+		unsigned long long* out_i = xch + ((tid * 3 + 0) << 6) + lane;
+		unsigned long long* out_j = xch + ((tid * 3 + 1) << 6) + c * 8;
+		unsigned long long* out_k = xch + ((tid * 3 + 2) << 6) + b * 8;
+		const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6) + lane;
+		const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6) + c * 8;
+		const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6) + b * 8;
+		// ---- first look at the predecessors' faces, then the next tile's operands (both stay in flight) ----
+		unsigned long long gi = has_pi ? granule_load(in_i) : fresh0;
+		unsigned long long gj[8], gk[8];
+#pragma unroll
+		for (int a = 0; a < 8; a++) gj[a] = has_pj ? granule_load(in_j + a) : fresh0;
+#pragma unroll
+		for (int a = 0; a < 8; a++) gk[a] = has_pk ? granule_load(in_k + a) : fresh0;
+		if (t_nxt < ntiles) issue(R, pk_nxt);
+		// ---- wait until every face value is there ----
+		for (;;) {
+			bool ok = ((unsigned)(gi >> 32) == gen);
+#pragma unroll
+			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(gj[a] >> 32) == gen) && ((unsigned)(gk[a] >> 32) == gen);
+			if (ok || ++spins > FLOW_SPIN_LIMIT) break;
+			__builtin_amdgcn_s_sleep(1);
+			if ((unsigned)(gi >> 32) != gen) gi = granule_load(in_i);
+#pragma unroll
+			for (int a = 0; a < 8; a++) {
+				if ((unsigned)(gj[a] >> 32) != gen) gj[a] = granule_load(in_j + a);
+				if ((unsigned)(gk[a] >> 32) != gen) gk[a] = granule_load(in_k + a);
+			}
 		}
-		// neighbours inside the tile: lane-1 (same 16-lane DPP row for b > 0) and lane-8
-		float ij0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
-		float ik0 = __shfl_up(ok0, 8, 64);
-		float ii0 = oi0;
-		if (valid) {
-			if (b == 0) {
-				while ((unsigned)(gj >> 32) != gen) {
-					if (++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(1);
-					gj = granule_load(in_j + ac);
-				}
-				ij0 = __uint_as_float((unsigned)gj);
+		if (b == 0) {
+#pragma unroll
+			for (int a = 0; a < 8; a++) sHj[c * 8 + a] = __uint_as_float((unsigned)gj[a]);
+		}
+		if (c == 0) {
+#pragma unroll
+			for (int a = 0; a < 8; a++) sHk[b * 8 + a] = __uint_as_float((unsigned)gk[a]);
+		}
+		const float hi0 = __uint_as_float((unsigned)gi);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// ---- 22 cell hyperplanes (no global loads inside) ----
+		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+		int a = -b - c;
+		int ac = 0;
+		float4 nA = sA[buf][lane], nB = sB[buf][lane];
+		float nHj = sHj[c * 8], nHk = sHk[b * 8];
+#pragma unroll 2
+		for (int h = 0; h < 22; h++) {
+			const float4 cA = nA, cB = nB;
+			const float hj = nHj, hk = nHk;
+			const int cc = ac;
+			{
+				const int a1 = a + 1;
+				ac = a1 < 0 ? 0 : (a1 > 7 ? 7 : a1);
+				nA = sA[buf][ac * 64 + lane];
+				nB = sB[buf][ac * 64 + lane];
+				nHj = sHj[c * 8 + ac];
+				nHk = sHk[b * 8 + ac];
 			}
-			if (c == 0) {
-				while ((unsigned)(gk >> 32) != gen) {
-					if (++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(1);
-					gk = granule_load(in_k + ac);
-				}
-				ik0 = __uint_as_float((unsigned)gk);
-			}
-			if (a == 0) {
-				while ((unsigned)(gi >> 32) != gen) {
-					if (++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(1);
-					gi = granule_load(in_i);
-				}
-				ii0 = __uint_as_float((unsigned)gi);
-			}
+			const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+			const float sk = __shfl_up(ok0, 8, 64);
+			const float ij0 = (b == 0) ? hj : dj;
+			const float ik0 = (c == 0) ? hk : sk;
+			const float ii0 = (a == 0) ? hi0 : oi0;
+			const bool valid = (unsigned)a < 8u;
 			const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
-			const bool fl = cB.z != 0.f;
+			const bool fl = valid && (cB.z != 0.f);
 			float val = cB.y;
 			if (MODE == 1) {
-				if (fl) val = p * (cA.x - ii0 - ij0 - ik0);
+				const float nv = p * (cA.x - ii0 - ij0 - ik0);
+				val = fl ? nv : val;
 				oi0 = (val * ai) * p;
 				oj0 = (val * aj) * p;
 				ok0 = (val * ak) * p;
 			} else {
-				if (fl) val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+				const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+				val = fl ? nv : val;
 				oi0 = oj0 = ok0 = val;
 			}
-			if (has_si && a == 7) granule_store(out_i, oi0, gen);
-			if (has_sj) granule_store(out_j + a, oj0, gen);
-			if (has_sk) granule_store(out_k + a, ok0, gen);
-			if (fl) sB[lane * 8 + ac].y = val;
+			if (valid) {
+				sB[buf][cc * 64 + lane].y = val;
+				if (has_si && a == 7) granule_store(out_i, oi0, gen);
+				if (has_sj) granule_store(out_j + a, oj0, gen);
+				if (has_sk) granule_store(out_k + a, ok0, gen);
+			}
+			a++;
 		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// ---- write back the finished tile ----
+		{
+			int x0, nv;
+			int64_t rowbase;
+			tile_geom(pk_cur, x0, rowbase, nv);
+			float w[8];
+#pragma unroll
+			for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sB[buf][e * 64 + lane].y;
+			if (VEC) {
+				if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
+				if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
+			} else {
+#pragma unroll
+				for (int e = 0; e < 8; e++)
+					if (e < nv) dst[rowbase + e] = w[e];
+			}
+		}
+		// ---- land the next tile's operands in the other buffer, rotate ----
+		if (t_nxt < ntiles) commit(R, pk_nxt, buf ^ 1);
+		const int t_nn = __builtin_amdgcn_readfirstlane(tnn_raw);
+		buf ^= 1;
+		t_cur = t_nxt;
+		pk_cur = pk_nxt;
+		t_nxt = t_nn;
+		pk_nxt = (t_nn < ntiles) ? order[t_nn] : 0;
 	}
 	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
-	__syncthreads();
-	float w[8];
-#pragma unroll
-	for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = sB[lane * 8 + a].y;
-	if (VEC) {
-		if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
-		if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
-	} else {
-#pragma unroll
-		for (int e = 0; e < 8; e++)
-			if (e < nv) dst[rowbase + e] = w[e];
-	}
-	__syncthreads();
-	}  // ticket loop
 	// the last workgroup to leave re-arms the ticket for the next sweep (visible at the kernel boundary)
 	if (lane == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
@@ -905,7 +940,7 @@ k_mic_stream(Dim d, int nbj, int nbk, int nblocks, int nchunks, const int* __res
              unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
              float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
              const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-             const CgScalars* __restrict__ sc) {
+             const CgScalars* __restrict__ sc, int dbg) {
 	static_assert(MODE == 1 || MODE == 2, "streaming kernel implements the apply sweeps");
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
@@ -991,15 +1026,59 @@ k_mic_stream(Dim d, int nbj, int nbk, int nblocks, int nchunks, const int* __res
 		if (nchunks > 1) issue(st1, 1);
 		if (nchunks > 2) issue(st0, 2);
 
-		unsigned long long gj[8], gk[8];
+		// face granules of the predecessor blocks: two register sets, the batch for steps [h+8, h+16) is requested
+		// while the batch for [h, h+8) is consumed
+		const unsigned long long fresh0 = (unsigned long long)gen << 32;
+		unsigned long long gjA[8], gjB[8], gkA[8], gkB[8];
 #pragma unroll
-		for (int e = 0; e < 8; e++) gj[e] = gk[e] = (unsigned long long)gen << 32;
-		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+		for (int e = 0; e < 8; e++) gjA[e] = gjB[e] = gkA[e] = gkB[e] = fresh0;
+		auto request = [&](unsigned long long* g, const unsigned long long* src, int a0, bool on) {
+			if (on) {
+#pragma unroll
+				for (int e = 0; e < 8; e++) {
+					const int ae = a0 + e;
+					g[e] = (ae >= 0 && ae < NXL) ? granule_load(src + ae) : fresh0;
+				}
+			}
+		};
 		int spins = 0;
-		// operands of the first step
-		float4 nA = mA[lane];
-		float2 nB = mB[lane];
-		unsigned nF = mF[lane];
+		auto settle = [&](unsigned long long* g, const unsigned long long* src, int a0, bool on) {
+			if (on) {
+				for (;;) {
+					bool ok = true;
+#pragma unroll
+					for (int e = 0; e < 8; e++) ok = ok && ((unsigned)(g[e] >> 32) == gen);
+					if (ok || ++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+#pragma unroll
+					for (int e = 0; e < 8; e++) {
+						const int ae = a0 + e;
+						if (ae >= 0 && ae < NXL && (unsigned)(g[e] >> 32) != gen) g[e] = granule_load(src + ae);
+					}
+				}
+			}
+		};
+		// first batch (steps 0..7 of this wave's timeline start at hw = -woff)
+		request(gjA, in_j, -woff - c, pred_j);
+		request(gkA, in_k, -woff - b, pred_k);
+
+		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+		// lane-constant selectors
+		const bool dppJ = (b != 0), granJ = (b == 0) && (wj == 0);
+		const bool shfK = (c != 0), granK = (c == 0) && (wk == 0);
+		const bool wrJ = (b == 7) && (wj == 0), wrK = (c == 7) && (wk == 0);
+		const float* rdJ = &hxj[0][wk][c];
+		const float* rdK = &hxk[0][wj][b];
+		float* wtJ = &hxj[0][wk][c];
+		float* wtK = &hxk[0][wj][b];
+		unsigned mbits = 0;     // fluid bits of the 24 ring cells of my row
+		{   // chunk 0 was committed above: recover its mask
+			mbits = mF[lane];
+		}
+		int a = -woff - b - c;               // my cell at step h = 0
+		int cidx = ((a % 24) + 24) % 24;     // ring cell of `a`
+		float4 nA = mA[cidx * 64 + lane];
+		float2 nB = mB[cidx * 64 + lane];
 		if (tidx < 32) ((float*)hxj)[tidx] = 0.f;
 		else if (tidx < 64) ((float*)hxk)[tidx - 32] = 0.f;
 		__syncthreads();
@@ -1007,45 +1086,23 @@ k_mic_stream(Dim d, int nbj, int nbk, int nblocks, int nchunks, const int* __res
 		for (int h0 = 0; h0 < HTOT; h0 += 16) {
 #pragma unroll
 			for (int s = 0; s < 16; s++) {
-				const int h = h0 + s;
-				const int hw = h - woff;
-				const int a = hw - b - c;
-				const bool valid = (a >= 0) && (a < NXL);
-				// ---- every 8 steps: fetch the next batch of the predecessors' face values (blocking poll) ----
+				const int hw = h0 + s - woff;
 				if ((s & 7) == 0) {
-					if (pred_j) {
-						for (;;) {
-							bool ok = true;
-#pragma unroll
-							for (int e = 0; e < 8; e++) {
-								const int ae = hw - c + e;
-								if (ae >= 0 && ae < NXL) gj[e] = granule_load(in_j + ae);
-								else gj[e] = (unsigned long long)gen << 32;
-							}
-#pragma unroll
-							for (int e = 0; e < 8; e++) ok = ok && ((unsigned)(gj[e] >> 32) == gen);
-							if (ok || ++spins > FLOW_SPIN_LIMIT) break;
-							__builtin_amdgcn_s_sleep(2);
-						}
-					}
-					if (pred_k) {
-						for (;;) {
-							bool ok = true;
-#pragma unroll
-							for (int e = 0; e < 8; e++) {
-								const int ae = hw - b + e;
-								if (ae >= 0 && ae < NXL) gk[e] = granule_load(in_k + ae);
-								else gk[e] = (unsigned long long)gen << 32;
-							}
-#pragma unroll
-							for (int e = 0; e < 8; e++) ok = ok && ((unsigned)(gk[e] >> 32) == gen);
-							if (ok || ++spins > FLOW_SPIN_LIMIT) break;
-							__builtin_amdgcn_s_sleep(2);
-						}
+					// batch boundary: the batch requested 8 steps ago must be complete; request the next one
+					if (s == 0) {
+						settle(gjA, in_j, hw - c, pred_j);
+						settle(gkA, in_k, hw - b, pred_k);
+						request(gjB, in_j, hw + 8 - c, pred_j);
+						request(gkB, in_k, hw + 8 - b, pred_k);
+					} else {
+						settle(gjB, in_j, hw - c, pred_j);
+						settle(gkB, in_k, hw - b, pred_k);
+						request(gjA, in_j, hw + 8 - c, pred_j);
+						request(gkA, in_k, hw + 8 - b, pred_k);
 					}
 				}
-				// ---- every 8 steps: retire the finished chunk, land the staged one, start the loads two chunks ahead ----
 				if ((s & 7) == 6) {
+					// retire the finished chunk, land the staged one, start the loads two chunks ahead
 					const int qd = (hw - 22) >> 3;
 					if (hw >= 22 && qd < nchunks) writeback(qd);
 					const int qc = (hw + 2) >> 3;
@@ -1057,46 +1114,60 @@ k_mic_stream(Dim d, int nbj, int nbk, int nblocks, int nchunks, const int* __res
 							commit(st0, qc);
 							if (qc + 2 < nchunks) issue(st0, qc + 2);
 						}
+						const int slot = qc % 3;
+						mbits = (mbits & ~(0xffu << (8 * slot))) | ((unsigned)mF[slot * 64 + lane] << (8 * slot));
 					}
 				}
 				const float4 cA = nA;
 				const float2 cB = nB;
-				const unsigned cF = nF;
-				{   // operands of the next step (cell a+1 of my row)
-					int a1 = a + 1;
-					a1 = a1 < 0 ? 0 : (a1 >= NXL ? NXL - 1 : a1);
-					const int idx = (((a1 >> 3) % 3) * 8 + (a1 & 7)) * 64 + lane;
-					nA = mA[idx];
-					nB = mB[idx];
-					nF = mF[((a1 >> 3) % 3) * 64 + lane];
+				const int ccell = cidx;
+				// next step's operands
+				cidx = (cidx == 23) ? 0 : cidx + 1;
+				if (!(dbg & 4)) {
+					nA = mA[cidx * 64 + lane];
+					nB = mB[cidx * 64 + lane];
 				}
-				float ij0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
-				float ik0 = __shfl_up(ok0, 8, 64);
-				const int par = h & 1;
-				if (b == 0) ij0 = (wj == 0) ? __uint_as_float((unsigned)gj[s & 7]) : hxj[par ^ 1][wk][c];
-				if (c == 0) ik0 = (wk == 0) ? __uint_as_float((unsigned)gk[s & 7]) : hxk[par ^ 1][wj][b];
+				const int par = s & 1;
+				const float hj = rdJ[(par ^ 1) * 16], hk = rdK[(par ^ 1) * 16];
+				const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+				const float sk = (dbg & 2) ? dj : __shfl_up(ok0, 8, 64);
+				const float gjv = __uint_as_float((unsigned)((s < 8) ? gjA[s & 7] : gjB[s & 7]));
+				const float gkv = __uint_as_float((unsigned)((s < 8) ? gkA[s & 7] : gkB[s & 7]));
+				const float ij0 = dppJ ? dj : (granJ ? gjv : hj);
+				const float ik0 = shfK ? sk : (granK ? gkv : hk);
 				const float ii0 = (a == 0) ? 0.f : oi0;
-				if (valid) {
-					const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
-					const bool fl = (cF >> (a & 7)) & 1u;
-					float val = cB.y;
-					if (MODE == 1) {
-						if (fl) val = p * (cA.x - ii0 - ij0 - ik0);
-						oi0 = (val * ai) * p;
-						oj0 = (val * aj) * p;
-						ok0 = (val * ak) * p;
-					} else {
-						if (fl) val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
-						oi0 = oj0 = ok0 = val;
-					}
-					if (fl) mB[(((a >> 3) % 3) * 8 + (a & 7)) * 64 + lane].y = val;
-					if (succ_j) granule_store(out_j + a, oj0, gen);
-					if (succ_k) granule_store(out_k + a, ok0, gen);
+				const bool valid = (unsigned)a < (unsigned)NXL;
+				const bool fl = valid && ((mbits >> ccell) & 1u);
+				const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+				float val = cB.y;
+				if (MODE == 1) {
+					const float nv = p * (cA.x - ii0 - ij0 - ik0);
+					val = fl ? nv : val;
+					oi0 = (val * ai) * p;
+					oj0 = (val * aj) * p;
+					ok0 = (val * ak) * p;
+				} else {
+					const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+					val = fl ? nv : val;
+					oi0 = oj0 = ok0 = val;
 				}
-				// faces handed to the neighbouring wave of this block (consumed at the next step)
-				if (b == 7 && wj == 0) hxj[par][wk][c] = valid ? oj0 : 0.f;
-				if (c == 7 && wk == 0) hxk[par][wj][b] = valid ? ok0 : 0.f;
-				__syncthreads();
+				if (!(dbg & 8)) mB[ccell * 64 + lane].y = val;   // unchanged value for non-fluid / not-yet-started cells
+				if (dbg & 8) {
+				} else if (wj == 1) {
+					if (succ_j && valid) granule_store(out_j + a, oj0, gen);
+				} else if (wrJ) {
+					wtJ[par * 16] = oj0;
+				}
+				if (dbg & 8) {
+				} else if (wk == 1) {
+					if (succ_k && valid) granule_store(out_k + a, ok0, gen);
+				} else if (wrK) {
+					wtK[par * 16] = ok0;
+				}
+				a++;
+				// LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait every step for the write-through
+				// granule stores and for the chunk loads that are meant to stay in flight
+				if (!(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 			}
 		}
 		if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
@@ -1120,6 +1191,7 @@ struct FlowState {
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
 	int* order = nullptr;
+	int level_count[3072];
 	unsigned long long* xch = nullptr;
 	size_t xch_cap = 0;
 	FlowCtl* ctl = nullptr;
@@ -1127,7 +1199,7 @@ struct FlowState {
 };
 static FlowState g_flow[16];
 
-static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st) {
+static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st, bool need_xch = false) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
@@ -1142,29 +1214,37 @@ static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		const int nt = nti * ntj * ntk;
 		int* h = (int*)malloc(sizeof(int) * nt);
 		int q = 0;
-		for (int L = 0; L <= nti + ntj + ntk - 3; L++)
+		for (int L = 0; L <= nti + ntj + ntk - 3; L++) {
+			const int q0 = q;
 			for (int tk = 0; tk < ntk; tk++)
 				for (int tj = 0; tj < ntj; tj++) {
 					const int ti = L - tj - tk;
 					if (ti >= 0 && ti < nti) h[q++] = ti | (tj << 10) | (tk << 20);
 				}
+			f.level_count[L] = q - q0;
+		}
 		if (f.order) MF_HIP(hipFree(f.order));
 		MF_HIP(hipMalloc((void**)&f.order, sizeof(int) * nt));
 		MF_HIP(hipMemcpy(f.order, h, sizeof(int) * nt, hipMemcpyHostToDevice));
 		free(h);
-		const size_t need = (size_t)nt * 3 * 64 * sizeof(unsigned long long);
-		if (need > f.xch_cap) {
-			if (f.xch) MF_HIP(hipFree(f.xch));
-			MF_HIP(hipMalloc((void**)&f.xch, need));
-			f.xch_cap = need;
-		}
-		MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 		f.gen = 0;
 		f.nti = nti;
 		f.ntj = ntj;
 		f.ntk = ntk;
 		f.ntiles = nt;
+		if (f.xch) MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
+	}
+	if (need_xch) {
+		const size_t need = (size_t)f.ntiles * 3 * 64 * sizeof(unsigned long long);
+		if (need > f.xch_cap) {
+			MF_HIP(hipStreamSynchronize(st));
+			if (f.xch) MF_HIP(hipFree(f.xch));
+			MF_HIP(hipMalloc((void**)&f.xch, need));
+			f.xch_cap = need;
+			MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
+			f.gen = 0;
+		}
 	}
 	*out = &f;
 	return 0;
@@ -1213,11 +1293,15 @@ static int stream_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	*out = &f;
 	return 0;
 }
-static int g_mic_mode = -1;  // 0: one launch per tile hyperplane, 1: tile dataflow, 2: block streaming (default)
+// 1 "tiles" : one launch per sweep, ticketed 8^3 tiles + tagged sc1 granules, operands of the next tile prefetched
+//              (default: 1.7x faster than "levels" at 256^3 on MI355X, bit-identical results)
+// 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback)
+// 2 "stream": one launch per sweep, 4-wave blocks streaming along x (experimental, bit-identical, not faster yet)
+static int g_mic_mode = -1;
 static int mic_mode() {
 	if (g_mic_mode < 0) {
 		const char* e = getenv("MF_MIC_MODE");
-		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : 2);
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "stream")) ? 2 : 1);
 	}
 	return g_mic_mode;
 }
@@ -1240,16 +1324,21 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			}
 			int ncu = 256;
 			const int grid = f->nblocks < ncu ? f->nblocks : ncu;
+			static int dbgflags = -1;
+			if (dbgflags < 0) {
+				const char* e = getenv("MF_STREAM_DBG");   // timing experiments only (results are wrong when non-zero)
+				dbgflags = e ? atoi(e) : 0;
+			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_stream<MODE, true>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_stream<MODE, true>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dbgflags);
 			else
-				hipLaunchKernelGGL((k_mic_stream<MODE, false>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_stream<MODE, false>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dbgflags);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
 		if (mic_mode() == 1) {
 			FlowState* f;
-			MF_TRY(flow_prepare(d, &f, st));
+			MF_TRY(flow_prepare(d, &f, st, true));
 			f->gen++;
 			if (f->gen == 0) {  // 32-bit wrap: stale tags could alias -> clear once
 				MF_HIP(hipMemsetAsync(f->xch, 0, f->xch_cap, st));
@@ -1258,7 +1347,7 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			static int wgs = -1;
 			if (wgs < 0) {
 				const char* e = getenv("MF_FLOW_WGS");
-				wgs = e ? atoi(e) : 1024;
+				wgs = e ? atoi(e) : 512;   // two single-wave workgroups per CU measured best (256: too few, 1024: contention)
 				if (wgs < 1) wgs = 1;
 			}
 			const int grid = f->ntiles < wgs ? f->ntiles : wgs;
