@@ -218,6 +218,19 @@ int mf_apply_force(int sx, int sy, int sz, const int32_t* flags, float* vel, flo
                    const float* exclude, int additive, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * "next" rows: FLIP glue between particle->grid and grid->particle
+ * ---------------------------------------------------------------------------------------------- */
+/* extrapolateMACSimple without phiObs, fastmarch.cpp:231-376.  tmp: Int scratch grid, velTmp: MAC scratch grid */
+int mf_extrapolate_mac_simple(int sx, int sy, int sz, const int32_t* flags, float* vel, int distance, int intoObs,
+                              int32_t* tmp, float* velTmp, void* stream);
+/* extrapolateMACFromWeight, fastmarch.cpp:378-430 (the weight grid is destroyed, like in the reference) */
+int mf_extrapolate_mac_from_weight(int sx, int sy, int sz, float* vel, float* weight, int distance, void* stream);
+/* markFluidCells, plugin/flip.cpp:142-188.  phiObs nullable; ftmp: Int scratch grid (used with phiObs only) */
+int mf_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int64_t pstride, const float* pos,
+                        const int32_t* pflag, const int32_t* ptype, int exclude, const float* phiObs, int32_t* ftmp,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HIP-only helpers (return an error in the CPU libraries)
  * ---------------------------------------------------------------------------------------------- */
 /* average duration in microseconds of `reps` back-to-back launches of the named kernel on `stream`,

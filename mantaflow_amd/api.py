@@ -4,10 +4,13 @@ import sys
 
 from .core import (BasicParticleSystem, FlagGrid, FluidSolver, Grid, IntGrid, LevelsetGrid, MACGrid, PdataInt, PdataReal,
                    PdataVec3, RealGrid, Solver, Vec3Grid, VecGrid, vec3)
-from .plugins import (Timings, addBuoyancy, addGravity, addGravityNoScale, advectSemiLagrange, computePressureRhs,
+from .plugins import (Timings, extrapolateMACFromWeight, extrapolateMACSimple, markFluidCells, addBuoyancy, addGravity, addGravityNoScale, advectSemiLagrange, computePressureRhs,
                       correctVelocity, flipVelocityUpdate, lastCgStats, mapGridToParts, mapGridToPartsVec3, mapMACToParts,
                       mapPartsToGrid, mapPartsToGridVec3, mapPartsToMAC, setDeterministicP2G, setWallBcs, solvePressure,
                       solvePressureSystem)
+
+from .scene import (Box, Cylinder, NoiseField, Shape, Sphere, densityInflow, sampleFlagsWithParticles,
+                    sampleLevelsetWithParticles)
 
 # module constants, registry.cpp:390-421
 GUI = False

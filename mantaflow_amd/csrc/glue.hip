@@ -83,7 +83,187 @@ k_apply_force(Dim d, const int32_t* __restrict__ flags, float* __restrict__ vel,
 	}
 }
 
+// ---- FLIP glue ---------------------------------------------------------------------------------
+// marking pass of extrapolateMACSimple (serial FOR_IJK_BND in the reference, fastmarch.cpp:344-356): tmp = 1 where the
+// face belongs to the fluid
+__global__ void __launch_bounds__(BLOCK)
+k_extrap_mark(Dim d, const int32_t* __restrict__ flags, int32_t* __restrict__ tmp, int c, int intoObs) {
+	CELL_IJK(d)
+	int v = 0;
+	if (INTERIOR(d)) {
+		const int64_t o = c == 0 ? 1 : (c == 1 ? d.Y : d.Z);
+		const int f0 = flags[idx], f1 = flags[idx - o];
+		bool mark = (f0 & MF_FLUID) || (f1 & MF_FLUID);
+		if (intoObs) mark = mark && !(f0 & MF_OBSTACLE) && !(f1 & MF_OBSTACLE);
+		v = mark ? 1 : 0;
+	}
+	tmp[idx] = v;
+}
+// knExtrapolateMACSimple, fastmarch.cpp:231-259.  In place like the reference: a pass only reads cells whose marker
+// equals d and only writes cells whose marker is 0 (to d+1), so the result does not depend on the thread order.
+__global__ void __launch_bounds__(BLOCK)
+k_extrap_simple(Dim d, float* __restrict__ velc, int32_t* __restrict__ tmp, int dd) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (tmp[idx] != 0) return;
+	const int64_t nb[6] = {1, -1, d.Y, -d.Y, d.Z, -d.Z};
+	const int nn = d.is3d ? 6 : 4;
+	int nbs = 0;
+	float avg = 0.f;
+	for (int n = 0; n < nn; n++)
+		if (tmp[idx + nb[n]] == dd) {
+			avg += velc[idx + nb[n]];
+			nbs++;
+		}
+	if (nbs > 0) {
+		tmp[idx] = dd + 1;
+		velc[idx] = avg / (float)nbs;
+	}
+}
+// knExtrapolateIntoBnd, fastmarch.cpp:261-300 (bnd = 0: every cell; only border cells change)
+__global__ void __launch_bounds__(BLOCK)
+k_extrap_into_bnd(Dim d, const int32_t* __restrict__ flags, float* __restrict__ vel, const float* __restrict__ velTmp) {
+	CELL_IJK(d)
+	const int64_t n = d.n;
+	int cnt = 0;
+	float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+	const bool isObs = flags[idx] & MF_OBSTACLE;
+#define TAKE(q, comp, cond)                                            \
+	{                                                                  \
+		v0 = velTmp[q];                                                \
+		v1 = velTmp[n + (q)];                                          \
+		v2 = velTmp[2 * n + (q)];                                      \
+		if (isObs && (cond)) { if (comp == 0) v0 = 0.f; else if (comp == 1) v1 = 0.f; else v2 = 0.f; } \
+		cnt++;                                                         \
+	}
+	if (i == 0) TAKE(idx + 1, 0, v0 < 0.f)
+	else if (i == d.sx - 1) TAKE(idx - 1, 0, v0 > 0.f)
+	if (j == 0) TAKE(idx + d.Y, 1, v1 < 0.f)
+	else if (j == d.sy - 1) TAKE(idx - d.Y, 1, v1 > 0.f)
+	if (d.is3d) {
+		if (k == 0) TAKE(idx + d.Z, 2, v2 < 0.f)
+		else if (k == d.sz - 1) TAKE(idx - d.Z, 2, v2 > 0.f)
+	}
+#undef TAKE
+	if (cnt > 0) {
+		const float fc = (float)cnt;
+		vel[idx] = v0 / fc;
+		vel[n + idx] = v1 / fc;
+		vel[2 * n + idx] = v2 / fc;
+	}
+}
+// extrapolateMACFromWeight, fastmarch.cpp:378-430
+__global__ void __launch_bounds__(BLOCK) k_weight_reset(Dim d, float* __restrict__ wc) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (wc[idx] > 0.f) wc[idx] = 1.0f;
+}
+__global__ void __launch_bounds__(BLOCK)
+k_extrap_weight(Dim d, float* __restrict__ velc, float* __restrict__ wc, int dd) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (wc[idx] != 0.f) return;
+	const int64_t nb[6] = {1, -1, d.Y, -d.Y, d.Z, -d.Z};
+	const int nn = d.is3d ? 6 : 4;
+	int nbs = 0;
+	float avg = 0.f;
+	const float fd = (float)dd;
+	for (int n = 0; n < nn; n++)
+		if (wc[idx + nb[n]] == fd) {
+			avg += velc[idx + nb[n]];
+			nbs++;
+		}
+	if (nbs > 0) {
+		wc[idx] = (float)(dd + 1);
+		velc[idx] = avg / (float)nbs;
+	}
+}
+// markFluidCells, flip.cpp:142-188
+__global__ void __launch_bounds__(BLOCK) k_clear_fluid_flags(Dim d, int32_t* __restrict__ flags) {
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (idx >= d.n) return;
+	const int f = flags[idx];
+	if (f & MF_FLUID) flags[idx] = (f | MF_EMPTY) & ~MF_FLUID;
+}
+__global__ void __launch_bounds__(BLOCK)
+k_mark_fluid(Dim d, int32_t* __restrict__ flags, int64_t np, int64_t ps, const float* __restrict__ pos,
+             const int32_t* __restrict__ pflag, const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) return;
+	const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];   // toVec3i truncation
+	if (i < 0 || j < 0 || k < 0 || i >= d.sx || j >= d.sy || k >= d.sz) return;
+	const int64_t idx = (int64_t)i + d.Y * j + d.Z * k;
+	const int f = flags[idx];
+	// every particle of a cell writes the same value, so concurrent marking is order independent
+	if (f & MF_EMPTY) flags[idx] = (f | MF_FLUID) & ~MF_EMPTY;
+}
+// knSetNbObstacle, flip.cpp:149-164
+__global__ void __launch_bounds__(BLOCK)
+k_set_nb_obstacle(Dim d, int32_t* __restrict__ nflags, const int32_t* __restrict__ flags, const float* __restrict__ phiObs) {
+	CELL_IJK(d)
+	if (!INTERIOR(d)) return;
+	if (phiObs[idx] > 0.f) return;
+	if (!(flags[idx] & MF_EMPTY)) return;
+	bool set = false;
+	if ((flags[idx - 1] & MF_FLUID) && (phiObs[idx + 1] <= 0.f)) set = true;
+	if ((flags[idx + 1] & MF_FLUID) && (phiObs[idx - 1] <= 0.f)) set = true;
+	if ((flags[idx - d.Y] & MF_FLUID) && (phiObs[idx + d.Y] <= 0.f)) set = true;
+	if ((flags[idx + d.Y] & MF_FLUID) && (phiObs[idx - d.Y] <= 0.f)) set = true;
+	if (d.is3d) {
+		if ((flags[idx - d.Z] & MF_FLUID) && (phiObs[idx + d.Z] <= 0.f)) set = true;
+		if ((flags[idx + d.Z] & MF_FLUID) && (phiObs[idx - d.Z] <= 0.f)) set = true;
+	}
+	if (set) nflags[idx] = (flags[idx] | MF_FLUID) & ~MF_EMPTY;
+}
+
 extern "C" {
+int mf_extrapolate_mac_simple(int sx, int sy, int sz, const int32_t* flags, float* vel, int distance, int intoObs,
+                              int32_t* tmp, float* velTmp, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	const int dim = d.is3d ? 3 : 2;
+	for (int c = 0; c < dim; c++) {
+		hipLaunchKernelGGL(k_extrap_mark, dim3(nblk(d)), dim3(BLOCK), 0, st, d, flags, tmp, c, intoObs);
+		for (int dd = 1; dd < 1 + distance; dd++)
+			hipLaunchKernelGGL(k_extrap_simple, dim3(nblk(d)), dim3(BLOCK), 0, st, d, vel + c * d.n, tmp, dd);
+	}
+	MF_HIP(hipMemcpyAsync(velTmp, vel, sizeof(float) * 3 * d.n, hipMemcpyDeviceToDevice, st));
+	hipLaunchKernelGGL(k_extrap_into_bnd, dim3(nblk(d)), dim3(BLOCK), 0, st, d, flags, vel, velTmp);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_extrapolate_mac_from_weight(int sx, int sy, int sz, float* vel, float* weight, int distance, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	const int dim = d.is3d ? 3 : 2;
+	for (int c = 0; c < dim; c++) {
+		hipLaunchKernelGGL(k_weight_reset, dim3(nblk(d)), dim3(BLOCK), 0, st, d, weight + c * d.n);
+		for (int dd = 1; dd < 1 + distance; dd++)
+			hipLaunchKernelGGL(k_extrap_weight, dim3(nblk(d)), dim3(BLOCK), 0, st, d, vel + c * d.n, weight + c * d.n, dd);
+	}
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
+                        const int32_t* ptype, int exclude, const float* phiObs, int32_t* ftmp, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(k_clear_fluid_flags, dim3(nblk(d)), dim3(BLOCK), 0, st, d, flags);
+	if (np > 0)
+		hipLaunchKernelGGL(k_mark_fluid, dim3((unsigned)((np + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d, flags, np, ps, pos, pflag, ptype, exclude);
+	if (phiObs) {
+		// FlagGrid tmp(flags); knSetNbObstacle(tmp, flags, phiObs); flags.swap(tmp)
+		MF_HIP(hipMemcpyAsync(ftmp, flags, sizeof(int32_t) * d.n, hipMemcpyDeviceToDevice, st));
+		hipLaunchKernelGGL(k_set_nb_obstacle, dim3(nblk(d)), dim3(BLOCK), 0, st, d, ftmp, flags, phiObs);
+		MF_HIP(hipMemcpyAsync(flags, ftmp, sizeof(int32_t) * d.n, hipMemcpyDeviceToDevice, st));
+	}
+	MF_LAUNCH_CHECK();
+	return 0;
+}
 int mf_set_wall_bcs(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* obvel, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);

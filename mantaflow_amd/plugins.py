@@ -335,6 +335,41 @@ def mapGridToPartsVec3(source, parts, target):
 
 
 # =========================================================================================================
+# FLIP glue
+# =========================================================================================================
+@plugin
+def extrapolateMACSimple(flags, vel, distance=4, phiObs=None, intoObs=False):
+    """fastmarch.cpp:337-376"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(vel, MACGrid, "MACGrid")
+    if phiObs is not None and not (isinstance(phiObs, int) and phiObs == 0):
+        raise RuntimeError("extrapolateMACSimple: the phiObs variant (knUnprojectNormalComp) is outside the hot path")
+    s = flags.parent
+    tmp, velTmp = core.IntGrid(s), MACGrid(s)
+    s.lib.call("mf_extrapolate_mac_simple", flags.sx, flags.sy, flags.sz, flags.ptr, vel.ptr, int(distance), int(bool(intoObs)),
+               tmp.ptr, velTmp.ptr, s.stream)
+
+
+@plugin
+def extrapolateMACFromWeight(vel, weight, distance=2):
+    """fastmarch.cpp:415-430"""
+    _chk(vel, MACGrid, "MACGrid"); _chk(weight, VecGrid, "Grid<Vec3>")
+    s = vel.parent
+    s.lib.call("mf_extrapolate_mac_from_weight", vel.sx, vel.sy, vel.sz, vel.ptr, weight.ptr, int(distance), s.stream)
+
+
+@plugin
+def markFluidCells(parts, flags, phiObs=None, ptype=None, exclude=0):
+    """flip.cpp:166-188"""
+    _chk(flags, FlagGrid, "FlagGrid")
+    phiObs = _opt(phiObs, Grid, "Grid<Real>")
+    s = flags.parent
+    ftmp = core.IntGrid(s) if phiObs is not None else None
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_mark_fluid_cells", flags.sx, flags.sy, flags.sz, flags.ptr, np_, cap, pos, pfl, pt, int(exclude),
+               None if phiObs is None else phiObs.ptr, None if ftmp is None else ftmp.ptr, s.stream)
+
+
+# =========================================================================================================
 # glue (SURVEY 8f-1)
 # =========================================================================================================
 @plugin

@@ -1555,6 +1555,160 @@ int mf_apply_force(int sx, int sy, int sz, const int32_t* flags, float* vel, flo
 	return 0;
 }
 
+/* ================================================================================================
+ * FLIP glue
+ * ============================================================================================== */
+/* extrapolateMACSimple (phiObs == NULL), fastmarch.cpp:231-376 */
+int mf_extrapolate_mac_simple(int sx, int sy, int sz, const int32_t* flags, float* vel, int distance, int intoObs,
+                              int32_t* tmp, float* velTmp, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	const int dim = d.is3d ? 3 : 2;
+	const int64_t nb[6] = {1, -1, d.Y, -d.Y, d.Z, -d.Z};
+	for (int c = 0; c < dim; c++) {
+		const int64_t o = c == 0 ? 1 : (c == 1 ? d.Y : d.Z);
+		float* vc = vel + c * n;
+		memset(tmp, 0, sizeof(int32_t) * n);
+		for (int k = K0(d, 1); k < K1(d, 1); k++)
+			for (int j = 1; j < sy - 1; j++)
+				for (int i = 1; i < sx - 1; i++) {
+					int64_t idx = IDX(d, i, j, k);
+					int mark = (flags[idx] & MF_FLUID) || (flags[idx - o] & MF_FLUID);
+					if (intoObs) mark = mark && !(flags[idx] & MF_OBSTACLE) && !(flags[idx - o] & MF_OBSTACLE);
+					if (mark) tmp[idx] = 1;
+				}
+		for (int dd = 1; dd < 1 + distance; dd++) {
+			/* knExtrapolateMACSimple: in place; a pass reads markers == dd only and writes dd+1 into zeros */
+#pragma omp parallel for
+			for (int k = K0(d, 1); k < K1(d, 1); k++)
+				for (int j = 1; j < sy - 1; j++)
+					for (int i = 1; i < sx - 1; i++) {
+						int64_t idx = IDX(d, i, j, k);
+						if (tmp[idx] != 0) continue;
+						int nbs = 0;
+						float avg = 0.;
+						for (int q = 0; q < 2 * dim; q++)
+							if (tmp[idx + nb[q]] == dd) {
+								avg += vc[idx + nb[q]];
+								nbs++;
+							}
+						if (nbs > 0) {
+							tmp[idx] = dd + 1;
+							vc[idx] = avg / nbs;
+						}
+					}
+		}
+	}
+	memcpy(velTmp, vel, sizeof(float) * 3 * n);
+	/* knExtrapolateIntoBnd, fastmarch.cpp:261-300 */
+#pragma omp parallel for
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int64_t idx = IDX(d, i, j, k);
+				int c = 0;
+				float v[3] = {0, 0, 0};
+				const int isObs = flags[idx] & MF_OBSTACLE;
+#define TAKE(q, comp, neg)                                                       \
+	{                                                                            \
+		v[0] = velTmp[q]; v[1] = velTmp[n + (q)]; v[2] = velTmp[2 * n + (q)];   \
+		if (isObs && ((neg) ? v[comp] < 0. : v[comp] > 0.)) v[comp] = 0.;        \
+		c++;                                                                     \
+	}
+				if (i == 0) TAKE(idx + 1, 0, 1)
+				else if (i == sx - 1) TAKE(idx - 1, 0, 0)
+				if (j == 0) TAKE(idx + d.Y, 1, 1)
+				else if (j == sy - 1) TAKE(idx - d.Y, 1, 0)
+				if (d.is3d) {
+					if (k == 0) TAKE(idx + d.Z, 2, 1)
+					else if (k == sz - 1) TAKE(idx - d.Z, 2, 0)
+				}
+#undef TAKE
+				if (c > 0) {
+					vel[idx] = v[0] / (float)c;
+					vel[n + idx] = v[1] / (float)c;
+					vel[2 * n + idx] = v[2] / (float)c;
+				}
+			}
+	return 0;
+}
+/* extrapolateMACFromWeight, fastmarch.cpp:378-430 */
+int mf_extrapolate_mac_from_weight(int sx, int sy, int sz, float* vel, float* weight, int distance, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	const int dim = d.is3d ? 3 : 2;
+	const int64_t nb[6] = {1, -1, d.Y, -d.Y, d.Z, -d.Z};
+	for (int c = 0; c < dim; c++) {
+		float *vc = vel + c * n, *wc = weight + c * n;
+		for (int k = K0(d, 1); k < K1(d, 1); k++)
+			for (int j = 1; j < sy - 1; j++)
+				for (int i = 1; i < sx - 1; i++) {
+					int64_t idx = IDX(d, i, j, k);
+					if (wc[idx] > 0.) wc[idx] = 1.0;
+				}
+		for (int dd = 1; dd < 1 + distance; dd++) {
+#pragma omp parallel for
+			for (int k = K0(d, 1); k < K1(d, 1); k++)
+				for (int j = 1; j < sy - 1; j++)
+					for (int i = 1; i < sx - 1; i++) {
+						int64_t idx = IDX(d, i, j, k);
+						if (wc[idx] != 0) continue;
+						int nbs = 0;
+						float avg = 0.;
+						for (int q = 0; q < 2 * dim; q++)
+							if (wc[idx + nb[q]] == dd) {
+								avg += vc[idx + nb[q]];
+								nbs++;
+							}
+						if (nbs > 0) {
+							wc[idx] = dd + 1;
+							vc[idx] = avg / nbs;
+						}
+					}
+		}
+	}
+	return 0;
+}
+/* markFluidCells, plugin/flip.cpp:142-188 */
+int mf_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
+                        const int32_t* ptype, int exclude, const float* phiObs, int32_t* ftmp, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int64_t idx = 0; idx < d.n; idx++)
+		if (flags[idx] & MF_FLUID) flags[idx] = (flags[idx] | MF_EMPTY) & ~MF_FLUID;
+	for (int64_t p = 0; p < np; p++) {
+		if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) continue;
+		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+		if (!in_bounds(&d, i, j, k)) continue;
+		int64_t idx = IDX(d, i, j, k);
+		if (flags[idx] & MF_EMPTY) flags[idx] = (flags[idx] | MF_FLUID) & ~MF_EMPTY;
+	}
+	if (phiObs) {
+		memcpy(ftmp, flags, sizeof(int32_t) * d.n);
+		for (int k = K0(d, 1); k < K1(d, 1); k++)
+			for (int j = 1; j < sy - 1; j++)
+				for (int i = 1; i < sx - 1; i++) {
+					int64_t idx = IDX(d, i, j, k);
+					if (phiObs[idx] > 0.) continue;
+					if (!(flags[idx] & MF_EMPTY)) continue;
+					int set = 0;
+					if ((flags[idx - 1] & MF_FLUID) && (phiObs[idx + 1] <= 0.)) set = 1;
+					if ((flags[idx + 1] & MF_FLUID) && (phiObs[idx - 1] <= 0.)) set = 1;
+					if ((flags[idx - d.Y] & MF_FLUID) && (phiObs[idx + d.Y] <= 0.)) set = 1;
+					if ((flags[idx + d.Y] & MF_FLUID) && (phiObs[idx - d.Y] <= 0.)) set = 1;
+					if (d.is3d) {
+						if ((flags[idx - d.Z] & MF_FLUID) && (phiObs[idx + d.Z] <= 0.)) set = 1;
+						if ((flags[idx + d.Z] & MF_FLUID) && (phiObs[idx - d.Z] <= 0.)) set = 1;
+					}
+					if (set) ftmp[idx] = (flags[idx] | MF_FLUID) & ~MF_EMPTY;
+				}
+		memcpy(flags, ftmp, sizeof(int32_t) * d.n);
+	}
+	return 0;
+}
+
 int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
                          const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* st) {
 	(void)sx; (void)sy; (void)sz; (void)flags; (void)dst; (void)src; (void)A0; (void)Ai; (void)Aj; (void)Ak; (void)reps;

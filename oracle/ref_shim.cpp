@@ -65,6 +65,12 @@ void setWallBcs(const FlagGrid& flags, MACGrid& vel, const MACGrid* obvel, const
 void addBuoyancy(const FlagGrid& flags, const Grid<Real>& density, MACGrid& vel, Vec3 gravity, Real coefficient,
                  bool scale);                                                                    // extforces.cpp:84
 void addGravity(const FlagGrid& flags, MACGrid& vel, Vec3 gravity, const Grid<Real>* exclude, bool scale);  // extforces.cpp:62
+void extrapolateMACSimple(FlagGrid& flags, MACGrid& vel, int distance, LevelsetGrid* phiObs, bool intoObs);  // fastmarch.cpp:337
+void extrapolateMACFromWeight(MACGrid& vel, Grid<Vec3>& weight, int distance);                           // fastmarch.cpp:415
+void markFluidCells(const BasicParticleSystem& parts, FlagGrid& flags, const Grid<Real>* phiObs,
+                    const ParticleDataImpl<int>* ptype, const int exclude);                              // flip.cpp:166
+void sampleFlagsWithParticles(const FlagGrid& flags, BasicParticleSystem& parts, const int discretization,
+                              const Real randomness);                                                   // flip.cpp:33
 }  // namespace Manta
 
 using namespace Manta;
@@ -480,6 +486,59 @@ int ref_add_gravity(int sx, int sy, int sz, float dt, const int32_t* flags, floa
 	RealRef e(c, exclude);
 	MacIO v(c, vel, true);
 	addGravity(fl, v.g, Vec3(gx, gy, gz), e.ptr(), scale != 0);
+	SHIM_CATCH
+}
+
+/* extrapolateMACSimple, fastmarch.cpp:337-376 */
+int ref_extrapolate_mac_simple(int sx, int sy, int sz, int32_t* flags, float* vel, int distance, int intoObs) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, flags);
+	MacIO v(c, vel, true);
+	extrapolateMACSimple(fl, v.g, distance, nullptr, intoObs != 0);
+	SHIM_CATCH
+}
+/* extrapolateMACFromWeight, fastmarch.cpp:415-430 */
+int ref_extrapolate_mac_from_weight(int sx, int sy, int sz, float* vel, float* weight, int distance) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	MacIO v(c, vel, true);
+	Vec3IO w(c, weight, true);
+	extrapolateMACFromWeight(v.g, w.g, distance);
+	SHIM_CATCH
+}
+/* markFluidCells, flip.cpp:166-188 */
+int ref_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int64_t pstride, const float* pos,
+                         const int32_t* pflag, const int32_t* ptype, int exclude, const float* phiObs) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver);   // pool grid: the plugin swaps data pointers when phiObs is given (grid.cpp:99-111)
+	memcpy(&fl[0], flags, sizeof(int32_t) * c.n);
+	RealRef ph(c, phiObs);
+	Parts P(c, np, pstride, pos, pflag);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	markFluidCells(P.sys, fl, ph.ptr(), pt ? &pt->pd : nullptr, exclude);
+	memcpy(flags, &fl[0], sizeof(int32_t) * c.n);
+	SHIM_CATCH
+}
+/* sampleFlagsWithParticles, flip.cpp:33-58: returns the particle count; pos (SoA, stride cap) filled up to cap */
+int ref_sample_flags_with_particles(int sx, int sy, int sz, const int32_t* flags, int discretization, float randomness,
+                                    int64_t cap, float* pos, int64_t* count) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	BasicParticleSystem sys(&c.solver);
+	sampleFlagsWithParticles(fl, sys, discretization, randomness);
+	*count = sys.size();
+	for (int64_t i = 0; i < sys.size() && i < cap; i++) {
+		pos[i] = sys[i].pos.x;
+		pos[cap + i] = sys[i].pos.y;
+		pos[2 * cap + i] = sys[i].pos.z;
+	}
 	SHIM_CATCH
 }
 

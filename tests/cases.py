@@ -323,6 +323,61 @@ def run_advect_parts_ref(dims, dt, flags, vel, pos, pflag, mode, deleteInObstacl
     return p, f
 
 
+def flipglue_inputs(dims, seed):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=True)
+    pos, pflag, pvel = util.make_particles(flags, 2, seed + 1)
+    # liquid-style flags: everything non-obstacle starts empty; particles mark the fluid
+    fl0 = np.where(flags & util.OBS, flags, util.EMPTY).astype(np.int32)
+    vel = util.rand_vel(sx, sy, sz, seed + 2)
+    return fl0, pos, pflag, pvel, vel
+
+
+def run_flipglue_pkg(dims, fl0, pos, pflag, pvel, vel, phiObs=None):
+    """mapPartsToMAC -> extrapolateMACFromWeight -> markFluidCells -> extrapolateMACSimple (flip01_simple.py:49-63)"""
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims)
+    plugins.setDeterministicP2G(True)
+    fl = soa_to_grid(core.FlagGrid(s), fl0)
+    pp = _mk_parts(s, pos, pflag)
+    pv = _pd_vec3(s, pp, pvel)
+    v, vo, w = core.MACGrid(s), core.MACGrid(s), core.VecGrid(s)
+    plugins.mapPartsToMAC(fl, v, vo, pp, pv, w)
+    plugins.extrapolateMACFromWeight(v, w, distance=2)
+    out = {"efw_vel": grid_to_soa(v), "efw_weight": grid_to_soa(w)}
+    ph = soa_to_grid(core.Grid(s), phiObs) if phiObs is not None else None
+    plugins.markFluidCells(pp, fl, phiObs=ph)
+    out["flags"] = grid_to_soa(fl)
+    v2 = soa_to_grid(core.MACGrid(s), vel)
+    plugins.extrapolateMACSimple(fl, v2, distance=3)
+    out["ems_vel"] = grid_to_soa(v2)
+    v3 = soa_to_grid(core.MACGrid(s), vel)
+    plugins.extrapolateMACSimple(fl, v3, distance=2, intoObs=True)
+    out["ems_into"] = grid_to_soa(v3)
+    s.sync()
+    plugins.setDeterministicP2G(False)
+    return out
+
+
+def run_flipglue_ref(dims, fl0, pos, pflag, pvel, vel, phiObs=None):
+    sx, sy, sz = dims
+    n = pos.shape[1]
+    v, vo, w = np.zeros((3, sz, sy, sx), np.float32), np.zeros((3, sz, sy, sx), np.float32), np.zeros((3, sz, sy, sx), np.float32)
+    refcall("ref_map_parts_to_mac", sx, sy, sz, fl0, v, vo, w, n, n, pos, pflag, pvel, None, 0)
+    refcall("ref_extrapolate_mac_from_weight", sx, sy, sz, v, w, 2)
+    out = {"efw_vel": v, "efw_weight": w}
+    fl = fl0.copy()
+    refcall("ref_mark_fluid_cells", sx, sy, sz, fl, n, n, pos, pflag, None, 0, phiObs)
+    out["flags"] = fl
+    v2 = vel.copy()
+    refcall("ref_extrapolate_mac_simple", sx, sy, sz, fl, v2, 3, 0)
+    out["ems_vel"] = v2
+    v3 = vel.copy()
+    refcall("ref_extrapolate_mac_simple", sx, sy, sz, fl, v3, 2, 1)
+    out["ems_into"] = v3
+    return out
+
+
 def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims, dt)

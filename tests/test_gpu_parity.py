@@ -208,6 +208,20 @@ def test_glue(hip_backend, dims):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 18, 9)])
+def test_flip_glue(hip_backend, dims):
+    from mantaflow_amd import _lib
+    fl0, pos, pflag, pvel, vel = cases.flipglue_inputs(dims, 31)
+    phi = util.rand_real((dims[2], dims[1], dims[0]), 35)
+    for ph in (None, phi):
+        a = cases.run_flipglue_pkg(dims, fl0, pos, pflag, pvel, vel, ph)
+        _lib.use_library(util.build_oracle(), "cpu")
+        b = cases.run_flipglue_pkg(dims, fl0, pos, pflag, pvel, vel, ph)
+        _lib.reset()
+        for k in b:
+            assert_bitexact(a[k], b[k], k)
+
+
 def test_reductions_and_elementwise(hip, oracle):
     n = 1 << 20
     a, b = util.rand_real((n + 3,), 30, 3.0), util.rand_real((n + 3,), 31, 2.0)

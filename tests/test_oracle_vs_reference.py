@@ -171,6 +171,18 @@ def test_glue(oracle_backend, dims):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
+@pytest.mark.parametrize("with_phi", [False, True])
+def test_flip_glue(oracle_backend, dims, with_phi):
+    fl0, pos, pflag, pvel, vel = cases.flipglue_inputs(dims, 31)
+    phi = util.rand_real((dims[2], dims[1], dims[0]), 35) if with_phi else None
+    a = cases.run_flipglue_pkg(dims, fl0, pos, pflag, pvel, vel, phi)
+    b = cases.run_flipglue_ref(dims, fl0, pos, pflag, pvel, vel, phi)
+    assert (b["flags"] & 1).sum() > 50
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 def test_init_domain_matches_reference(oracle_backend):
     from mantaflow_amd import core
     for dims, bw, kw in [((10, 9, 8), 0, {}), ((12, 10, 9), 1, dict(open="xY", outflow="z")), ((16, 12, 1), 0, dict(inflow="y"))]:
@@ -199,3 +211,21 @@ def test_reductions(oracle):
     dd = np.zeros(1, np.float64)
     util.refcall("ref_grid_sum_sqr", n, a, dd)
     assert abs(d.value - dd[0]) <= 1e-12 * dd[0]
+
+
+def test_sample_flags_with_particles_matches_reference_stream(oracle_backend):
+    """MT19937 seed 9832 + the reference's fp32 arithmetic reproduced host-side (flip.cpp:33-58)"""
+    from mantaflow_amd import core, scene
+    for dims, disc in [((10, 9, 8), 2), ((16, 12, 1), 3)]:
+        s = cases._mk_solver(dims)
+        flags = util.make_flags(*dims, 61, empty_top=True)
+        fl = cases.soa_to_grid(core.FlagGrid(s), flags)
+        pp = core.BasicParticleSystem(s)
+        scene.sampleFlagsWithParticles(fl, pp, disc, 0.2)
+        cap = 200000
+        pos = np.zeros((3, cap), np.float32)
+        import ctypes
+        cnt = ctypes.c_int64(0)
+        util.refcall("ref_sample_flags_with_particles", dims[0], dims[1], dims[2], flags, disc, ctypes.c_float(0.2), cap, pos, ctypes.byref(cnt))
+        assert cnt.value == pp.np and pp.np > 100
+        assert_bitexact(pp.get_positions().T, pos[:, :cnt.value], "sampled positions")

@@ -47,6 +47,10 @@ REF_PROTOS = {
     "ref_add_gravity": [c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_f, c_f, c_p, c_i],
     "ref_grid_max_abs": [c_l, c_p, c_p],
     "ref_grid_sum_sqr": [c_l, c_p, c_p],
+    "ref_extrapolate_mac_simple": [c_i, c_i, c_i, c_p, c_p, c_i, c_i],
+    "ref_extrapolate_mac_from_weight": [c_i, c_i, c_i, c_p, c_p, c_i],
+    "ref_mark_fluid_cells": [c_i, c_i, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_i, c_p],
+    "ref_sample_flags_with_particles": [c_i, c_i, c_i, c_p, c_i, c_f, c_l, c_p, c_p],
     "ref_init_domain": [c_i, c_i, c_i, c_p, c_i, c_s, c_s, c_s, c_s, c_i],
 }
 

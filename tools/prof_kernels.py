@@ -58,6 +58,43 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print("mic_apply avg %.1f us" % (e0.elapsed_time(e1) * 1e3 / reps))
+    elif what == "flip":
+        # S-flip: fluid block = lower 0.4 x 0.6 x 1.0 of the box, 8 particles per cell, pvel ~ N(0, 0.5^2)
+        from mantaflow_amd import scene
+        s.timestep = 0.5
+        flags.initDomain(boundaryWidth=0)
+        box = scene.Box(parent=s, p0=core.vec3(0, 0, 0), p1=core.vec3(0.4 * n, 0.6 * n, n))
+        flags.updateFromLevelset(box.computeLevelset())
+        pp = core.BasicParticleSystem(s)
+        scene.sampleFlagsWithParticles(flags, pp, 2, 0.2)
+        pv = pp.create(core.PdataVec3)
+        pv.from_numpy(np.random.default_rng(9832).normal(0, 0.5, (pp.np, 3)).astype(np.float32))
+        vel, velOld, w, pres = core.MACGrid(s), core.MACGrid(s), core.VecGrid(s), core.Grid(s)
+        ops = [
+            ("advectInGrid(RK4)", lambda: pp.advectInGrid(flags, vel, 2, deleteInObstacle=False)),
+            ("mapPartsToMAC", lambda: plugins.mapPartsToMAC(flags, vel, velOld, pp, pv, w)),
+            ("extrapolateMACFromWeight", lambda: plugins.extrapolateMACFromWeight(vel, w, distance=2)),
+            ("markFluidCells", lambda: plugins.markFluidCells(pp, flags)),
+            ("addGravity", lambda: plugins.addGravity(flags, vel, core.vec3(0, -0.002, 0))),
+            ("setWallBcs", lambda: plugins.setWallBcs(flags, vel)),
+            ("solvePressure", lambda: plugins.solvePressure(vel, pres, flags)),
+            ("extrapolateMACSimple", lambda: plugins.extrapolateMACSimple(flags, vel)),
+            ("flipVelocityUpdate", lambda: plugins.flipVelocityUpdate(flags, vel, velOld, pp, pv, 0.97)),
+        ]
+        tot = {k: 0.0 for k, _ in ops}
+        for it in range(reps + 1):
+            for k, f in ops:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); f(); e1.record(); torch.cuda.synchronize()
+                if it > 0:
+                    tot[k] += e0.elapsed_time(e1)
+            s.step()
+        npart = pp.np
+        print("S-flip %d^3, %d particles, %d steps: CG iterations last %s" % (n, npart, reps, plugins.lastCgStats()))
+        for k, _ in ops:
+            ms = tot[k] / reps
+            print("  %-26s %8.3f ms   %8.1f Mparticles/s" % (k, ms, npart / ms / 1e3))
+        print("  whole FLIP step            %8.3f ms   %8.2f Mcells/s" % (sum(tot.values()) / reps, n ** 3 / (sum(tot.values()) / reps) / 1e3))
     elif what == "advect":
         vel, dens = core.MACGrid(s), core.Grid(s)
         vel.from_numpy(np.ascontiguousarray(bench.synthetic_velocity(n, n, n).transpose(1, 2, 3, 0)))
