@@ -98,6 +98,140 @@ k_apply_matrix_v4(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	}
 }
 
+// v5: every load is issued before anything depends on it (no flags -> operand round trip), each thread owns R
+// consecutive y-rows of one x-quad so src[j+-1] / Aj[j-1] are reused from registers, and the +-X neighbours come
+// from the adjacent lanes (DPP wave shift) instead of three extra 4-byte-per-lane loads.  Same arithmetic, same
+// order per cell as v4.
+__device__ __forceinline__ float wave_shr1(float v) {  // lane l gets lane l-1 (lane 0: unchanged)
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v) {  // lane l gets lane l+1 (lane 63: unchanged)
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+template <bool DOT, bool IS3D, int R>
+__global__ void __launch_bounds__(BLOCK)
+k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
+                  const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
+                  const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb) {
+	if (DOT && sc->done) return;
+	const int qx = d.sx >> 2;
+	const int64_t nthr = (int64_t)qx * jgroups * d.sz;
+	const int vb0 = xcd_swizzle(blockIdx.x, gridDim.x) * tpb;
+	double acc = 0.0;
+#pragma unroll 1
+	for (int t = 0; t < tpb; t++) {
+	const int64_t T0 = (int64_t)(vb0 + t) * BLOCK + threadIdx.x;
+	const bool live = T0 < nthr;
+	const int64_t T = live ? T0 : nthr - 1;
+	const int qi = (int)(T % qx);
+	const int64_t rg = T / qx;
+	const int j0 = (int)(rg % jgroups) * R;
+	const int k = (int)(rg / jgroups);
+	const int lane = threadIdx.x & 63;
+	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	const int64_t Y = d.Y, Z = d.Z;
+	const int64_t row0 = ((int64_t)k * d.sy + j0) * d.sx + 4 * qi;  // flat index of this thread's first quad
+	int4 f[R];
+	float4 sv[R + 2], ajv[R + 1], a0[R], ai[R], ak[R], akm[R], szm[R], szp[R];
+	float sl[R], al[R], sr[R];
+	// ---- loads (addresses clamped into the grid; out-of-domain neighbours are zeroed afterwards) ----
+	{
+		const int jm = (j0 > 0) ? -1 : 0;
+		sv[0] = *(const float4*)(src + row0 + jm * Y);
+		ajv[0] = *(const float4*)(Aj + row0 + jm * Y);
+	}
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
+		const int64_t idx = row0 + jr * Y;
+		f[r] = *(const int4*)(flags + idx);
+		sv[r + 1] = *(const float4*)(src + idx);
+		ajv[r + 1] = *(const float4*)(Aj + idx);
+		a0[r] = *(const float4*)(A0 + idx);
+		ai[r] = *(const float4*)(Ai + idx);
+		if (IS3D) {
+			ak[r] = *(const float4*)(Ak + idx);
+			const int64_t im = (k > 0) ? idx - Z : idx, ip = (k < d.sz - 1) ? idx + Z : idx;
+			akm[r] = *(const float4*)(Ak + im);
+			szm[r] = *(const float4*)(src + im);
+			szp[r] = *(const float4*)(src + ip);
+		}
+	}
+	{
+		const int jr = (j0 + R < d.sy) ? R : (d.sy - 1 - j0);
+		sv[R + 1] = *(const float4*)(src + row0 + jr * Y);
+	}
+	// ---- +-X neighbours: adjacent lanes hold the adjacent quads of the same row, except at row / wave edges ----
+	const bool edge_l = (lane == 0) || (qi == 0), edge_r = (lane == 63) || (qi == qx - 1);
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
+		const int64_t idx = row0 + jr * Y;
+		sl[r] = wave_shr1(sv[r + 1].w);
+		al[r] = wave_shr1(ai[r].w);
+		sr[r] = wave_shl1(sv[r + 1].x);
+		if (edge_l) {
+			sl[r] = (idx > 0) ? src[idx - 1] : 0.f;
+			al[r] = (idx > 0) ? Ai[idx - 1] : 0.f;
+		}
+		if (edge_r) sr[r] = (idx + 4 < d.n) ? src[idx + 4] : 0.f;
+	}
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const int j = j0 + r;
+		if (j >= d.sy) break;
+		const int4 fl = f[r];
+		const float4 s = sv[r + 1];
+		float4 res = s;
+		if ((fl.x | fl.y | fl.z | fl.w) & MF_FLUID) {
+			const float4 sym = (j > 0) ? sv[r] : z4, ajm = (j > 0) ? ajv[r] : z4;
+			const float4 syp = (j < d.sy - 1) ? sv[r + 2] : z4, aj = ajv[r + 1];
+			float4 zm = z4, am = z4, zp = z4, akc = z4;
+			if (IS3D) {
+				akc = ak[r];
+				if (k > 0) {
+					zm = szm[r];
+					am = akm[r];
+				}
+				if (k < d.sz - 1) zp = szp[r];
+			}
+#define CELL5(c, SL, AL, SR)                                                                      \
+	if (fl.c & MF_FLUID) {                                                                        \
+		float v = s.c * a0[r].c;                                                                  \
+		v = v + (SL) * (AL);                                                                      \
+		v = v + (SR) * ai[r].c;                                                                   \
+		v = v + sym.c * ajm.c;                                                                    \
+		v = v + syp.c * aj.c;                                                                     \
+		if (IS3D) {                                                                               \
+			v = v + zm.c * am.c;                                                                  \
+			v = v + zp.c * akc.c;                                                                 \
+		}                                                                                         \
+		res.c = v;                                                                                \
+	}
+			CELL5(x, sl[r], al[r], s.y)
+			CELL5(y, s.x, ai[r].x, s.z)
+			CELL5(z, s.y, ai[r].y, s.w)
+			CELL5(w, s.z, ai[r].z, sr[r])
+#undef CELL5
+		}
+		if (live) {
+			*(float4*)(dst + row0 + r * Y) = res;
+			if (DOT) {
+				const float p0 = res.x * s.x, p1 = res.y * s.y, p2 = res.z * s.z, p3 = res.w * s.w;
+				acc += (double)p0;
+				acc += (double)p1;
+				acc += (double)p2;
+				acc += (double)p3;
+			}
+		}
+	}
+	}
+	if (DOT) {
+		acc = block_sum(acc);
+		if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+	}
+}
+
 // generic fallback (sx % 4 != 0 or unaligned views): one cell per thread
 template <bool DOT>
 __global__ void __launch_bounds__(BLOCK)
@@ -142,7 +276,24 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
                                const CgScalars* sc, hipStream_t st, int* nblocks) {
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
-	if (vec) {
+	static const int am_rows = [] {
+		const char* e = getenv("MF_AM_ROWS");
+		return e ? atoi(e) : 2;
+	}();
+	if (vec && am_rows > 0) {
+		const int R = am_rows >= 4 ? 4 : (am_rows >= 2 ? 2 : 1);
+		const int jgroups = (d.sy + R - 1) / R;
+		const int64_t vblocks = ((int64_t)(d.sx >> 2) * jgroups * d.sz + BLOCK - 1) / BLOCK;
+		const int tpb = (int)((vblocks + MAX_BLOCKS - 1) / MAX_BLOCKS);
+		nb = (int)((vblocks + tpb - 1) / tpb);
+#define AM5(RR)                                                                                                                                   \
+	if (d.is3d)                                                                                                                                   \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb); \
+	else                                                                                                                                          \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb);
+		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
+#undef AM5
+	} else if (vec) {
 		const int64_t nq = d.n >> 2;
 		const int qpt = (int)((nq + (int64_t)BLOCK * MAX_BLOCKS - 1) / ((int64_t)BLOCK * MAX_BLOCKS));
 		nb = (int)((nq + (int64_t)BLOCK * qpt - 1) / ((int64_t)BLOCK * qpt));
@@ -897,283 +1048,192 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// MIC apply, streaming form: one workgroup of 4 waves owns a 16x16 block of x-rows (2x2 "pencils" of 8x8 rows) and
-// streams along x.  Lane (B,C) of the block works on cell a = h - B - C at step h, so the i-dependency stays in a
-// register, the j/k dependencies inside a wave move by DPP / ds_bpermute, between the 4 waves through LDS (one
-// s_barrier per step), and only the two outer faces of a block cross workgroups -- as tagged 8-byte sc1 granules,
-// fetched in batches of 8 x-positions.  A block never re-loads operands per tile: its rows are fetched once in
-// 8-cell chunks, two chunks ahead, through a 3-slot LDS ring.  256^3: 256 blocks = one per CU, 30 block hops per
-// sweep instead of 94 tile hops.  Per-cell arithmetic is identical to k_mic_tiles / the reference.
+// MIC apply, row-streaming form ("rows"): ONE wave owns an 8x8 bundle of x-rows (tj,tk) and streams along the whole
+// x extent.  Lane (b,c) works on cell x' = h - b - c at step h, so
+//   * the i-dependency never leaves the lane's registers (no i-faces, no 14-step fill/drain per 8 cells: a lane is
+//     busy 8 steps out of 8 instead of 8 out of 22),
+//   * the j/k dependencies inside the bundle move by DPP / ds_bpermute exactly as in the tile kernel,
+//   * only the two outer faces of a bundle cross waves -- as tagged 8-byte sc1 granules, one per (x', face lane),
+//     fetched 8 steps at a time in a lane-relative window so a consumer bundle runs 15 steps behind its producer.
+// Operands are fetched once per 8-cell chunk, one chunk ahead, into a 3-slot LDS ring that is private per lane (a lane
+// only ever reads what it wrote itself: no barrier anywhere).  Memory operations are issued for the whole wave at
+// h = 8m-2, when chunk m-3 is complete for every lane and chunk m is needed next.  Bundles are ticketed in
+// anti-diagonal order (tj+tk), so a wave only ever waits for bundles drawn before its own.  256^3: 1024 bundles,
+// 62 bundle hops per sweep instead of 94 tile hops with 22 steps each.  Per-cell arithmetic = k_mic_tiles.
 // ---------------------------------------------------------------------------------------------------------
-template <bool VEC, bool REV>
-__device__ __forceinline__ void load_chunk8(const float* __restrict__ base, int64_t rowidx0, bool row_in, int q, int sx, float out[8]) {
-	const int xs = REV ? sx - 8 * q - 8 : 8 * q;  // physical x of the chunk's first element (may be < 0 / partly >= sx)
-	float t[8];
-	if (VEC) {
-		const bool v0 = row_in && xs >= 0 && xs < sx, v1 = row_in && xs + 4 >= 0 && xs + 4 < sx;
-		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-		float4 lo = *(const float4*)(base + (v0 ? rowidx0 + xs : 0)), hi = *(const float4*)(base + (v1 ? rowidx0 + xs + 4 : 0));
-		if (!v0) lo = z;
-		if (!v1) hi = z;
-		t[0] = lo.x; t[1] = lo.y; t[2] = lo.z; t[3] = lo.w;
-		t[4] = hi.x; t[5] = hi.y; t[6] = hi.z; t[7] = hi.w;
-	} else {
-#pragma unroll
-		for (int e = 0; e < 8; e++) {
-			const int x = xs + e;
-			const bool v = row_in && x >= 0 && x < sx;
-			const float val = base[v ? rowidx0 + x : 0];
-			t[e] = v ? val : 0.f;
-		}
-	}
-#pragma unroll
-	for (int a = 0; a < 8; a++) out[a] = t[REV ? 7 - a : a];
-}
-struct ChunkRegs {
-	float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
-	int F[8];
-};
-
+constexpr int ROWS_SLOTS = 3;
 template <int MODE, bool VEC>
-__global__ void __launch_bounds__(256, 1)
-k_mic_stream(Dim d, int nbj, int nbk, int nblocks, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
-             unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
-             float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
-             const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-             const CgScalars* __restrict__ sc, int dbg) {
-	static_assert(MODE == 1 || MODE == 2, "streaming kernel implements the apply sweeps");
+__global__ void __launch_bounds__(64)
+k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
+           unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
+           float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
+           const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
+           const CgScalars* __restrict__ sc) {
+	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
-	const int tidx = threadIdx.x, wave = tidx >> 6, lane = tidx & 63;
-	const int b = lane & 7, c = lane >> 3, wj = wave & 1, wk = wave >> 1;
-	const int B = b + 8 * wj, C = c + 8 * wk;  // position inside the 16x16 block
-	const int woff = 8 * (wj + wk);            // this wave's step offset
-	const int NXL = 8 * nchunks;
-	const int HTOT = (NXL + 32 + 15) & ~15;
+	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	const int skew = b + c;
+	__shared__ float4 sA[ROWS_SLOTS * 512];   // {V, Ai, Aj, Ak}        index = (x' mod 24) * 64 + lane
+	__shared__ float4 sB[ROWS_SLOTS * 512];   // {Aprecond, dst, fluid, -}
+	const unsigned long long fresh0 = (unsigned long long)gen << 32;
+	const int X8 = nchunks * 8;
+	int spins = 0;
 
-	// operand ring: [wave][slot 0..2][cell 0..7][lane]; cell-major so that a wave's accesses are lane-contiguous
-	__shared__ float4 sA[4 * 3 * 8 * 64];   // {V, Ai, Aj, Ak}
-	__shared__ float2 sB[4 * 3 * 8 * 64];   // {Aprecond, dst}
-	__shared__ unsigned char sF[4 * 3 * 64]; // fluid bit per cell of the chunk
-	__shared__ float hxj[2][2][8], hxk[2][2][8];  // [step parity][wk | wj][c | b] faces handed between the 4 waves
-	__shared__ int sTicket;
-	float4* mA = sA + wave * (3 * 8 * 64);
-	float2* mB = sB + wave * (3 * 8 * 64);
-	unsigned char* mF = sF + wave * (3 * 64);
-
+	struct ChunkRegs {
+		int F[8];
+		float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+	};
 	for (;;) {
-		if (tidx == 0) sTicket = atomicAdd(&ctl->ticket, 1);
-		__syncthreads();
-		const int t = sTicket;
-		__syncthreads();
-		if (t >= nblocks) break;
-		const int packed = order[t];
-		const int Bjl = packed & 0xffff, Bkl = packed >> 16;  // logical block coordinates
-		const int Jl = 16 * Bjl + B, Kl = 16 * Bkl + C;       // logical row
-		const bool row_in = (Jl < d.sy) && (Kl < d.sz);
-		const int j = REV ? d.sy - 1 - Jl : Jl, k = REV ? d.sz - 1 - Kl : Kl;
-		const int64_t rowidx0 = row_in ? (d.Y * j + d.Z * k) : 0;
-		const int64_t blk = (int64_t)Bkl * nbj + Bjl;
-		const bool pred_j = (Bjl > 0) && (wj == 0) && (b == 0), pred_k = (Bkl > 0) && (wk == 0) && (c == 0);
-		const bool succ_j = (Bjl + 1 < nbj) && (wj == 1) && (b == 7), succ_k = (Bkl + 1 < nbk) && (wk == 1) && (c == 7);
-		unsigned long long* out_j = xj + (blk * 16 + C) * NXL;
-		unsigned long long* out_k = xk + (blk * 16 + B) * NXL;
-		const unsigned long long* in_j = xj + ((blk - 1) * 16 + C) * NXL;
-		const unsigned long long* in_k = xk + ((blk - nbj) * 16 + B) * NXL;
+		int t = 0;
+		if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
+		t = __builtin_amdgcn_readfirstlane(t);
+		if (t >= nstreams) break;
+		const int pk = order[t];
+		const int tjl = pk & 0xffff, tkl = pk >> 16;
+		const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
+		const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
+		const bool row_in = (j < d.sy) && (k < d.sz);
+		const int64_t rowbase = d.Y * j + d.Z * k;
+		const bool has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
+		const bool has_sj = (tjl + 1 < nbj) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
+		const int64_t sid = (int64_t)tkl * nbj + tjl;
+		unsigned long long* out_j = xj + sid * X8 * 8 + c;          // + x' * 8
+		unsigned long long* out_k = xk + sid * X8 * 8 + b;
+		const unsigned long long* in_j = xj + (sid - 1) * X8 * 8 + c;
+		const unsigned long long* in_k = xk + (sid - nbj) * X8 * 8 + b;
 
-		ChunkRegs st0, st1;  // staging sets for chunks with even / odd index
-		auto issue = [&](ChunkRegs& r, int q) {
-			load_chunk8<VEC, REV>((const float*)flags, rowidx0, row_in, q, d.sx, (float*)r.F);
-			load_chunk8<VEC, REV>(var1, rowidx0, row_in, q, d.sx, r.V);
-			load_chunk8<VEC, REV>(Ai, rowidx0, row_in, q, d.sx, r.Ai);
-			load_chunk8<VEC, REV>(Aj, rowidx0, row_in, q, d.sx, r.Aj);
-			load_chunk8<VEC, REV>(Ak, rowidx0, row_in, q, d.sx, r.Ak);
-			load_chunk8<VEC, REV>(Ap, rowidx0, row_in, q, d.sx, r.P);
-			load_chunk8<VEC, REV>(dst, rowidx0, row_in, q, d.sx, r.D);
+		auto chunk_geom = [&](int m, int64_t& rowidx, int& nv) {
+			const int x0 = (REV ? nchunks - 1 - m : m) * 8;
+			const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+			nv = row_in ? nvx : 0;
+			rowidx = rowbase + x0;
 		};
-		auto commit = [&](const ChunkRegs& r, int q) {  // staged registers -> LDS ring slot q % 3
-			const int slot = q % 3;
-			unsigned fm = 0;
+		auto issue = [&](ChunkRegs& r, int m) {
+			int64_t rowidx;
+			int nv;
+			chunk_geom(m, rowidx, nv);
+			load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
+			if (MODE == 1) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
+			load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
+			load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
+			load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
+			load_row8<VEC, REV>(Ap, rowidx, nv, r.P);
+			load_row8<VEC, REV>(dst, rowidx, nv, r.D);
+		};
+		auto commit = [&](const ChunkRegs& r, int m) {
+			int64_t rowidx;
+			int nv;
+			chunk_geom(m, rowidx, nv);
+			const int slot = m % ROWS_SLOTS;
 #pragma unroll
 			for (int a = 0; a < 8; a++) {
-				const int x = REV ? d.sx - 1 - (8 * q + a) : 8 * q + a;
-				const bool fl = row_in && x >= 0 && x < d.sx && (r.F[a] & MF_FLUID);
-				fm |= fl ? (1u << a) : 0u;
-				mA[(slot * 8 + a) * 64 + lane] = make_float4(fl ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
-				mB[(slot * 8 + a) * 64 + lane] = make_float2(r.P[a], r.D[a]);
+				const bool in = ((REV ? 7 - a : a) < nv);
+				const bool fl = in && (r.F[a] & MF_FLUID);
+				sA[slot * 512 + a * 64 + lane] = make_float4((MODE == 1 && fl) ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
+				sB[slot * 512 + a * 64 + lane] = make_float4(r.P[a], r.D[a], fl ? 1.f : 0.f, 0.f);
 			}
-			mF[slot * 64 + lane] = (unsigned char)fm;
 		};
-		auto writeback = [&](int q) {  // finished chunk q: LDS ring -> dst (non-fluid cells carry their loaded value)
-			const int slot = q % 3;
+		auto flush = [&](int m) {
+			int64_t rowidx;
+			int nv;
+			chunk_geom(m, rowidx, nv);
+			const int slot = m % ROWS_SLOTS;
 			float w[8];
 #pragma unroll
-			for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = mB[(slot * 8 + a) * 64 + lane].y;
-			const int xs = REV ? d.sx - 8 * q - 8 : 8 * q;
+			for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sB[slot * 512 + e * 64 + lane].y;
 			if (VEC) {
-				if (row_in && xs >= 0 && xs < d.sx) *(float4*)(dst + rowidx0 + xs) = make_float4(w[0], w[1], w[2], w[3]);
-				if (row_in && xs + 4 >= 0 && xs + 4 < d.sx) *(float4*)(dst + rowidx0 + xs + 4) = make_float4(w[4], w[5], w[6], w[7]);
+				if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
+				if (nv > 4) *(float4*)(dst + rowidx + 4) = make_float4(w[4], w[5], w[6], w[7]);
 			} else {
 #pragma unroll
 				for (int e = 0; e < 8; e++)
-					if (row_in && xs + e >= 0 && xs + e < d.sx) dst[rowidx0 + xs + e] = w[e];
+					if (e < nv) dst[rowidx + e] = w[e];
 			}
 		};
 
-		// ---- prologue: chunk 0 straight into the ring, chunks 1 and 2 in flight in the staging registers ----
-		issue(st0, 0);
-		commit(st0, 0);
-		if (nchunks > 1) issue(st1, 1);
-		if (nchunks > 2) issue(st0, 2);
-
-		// face granules of the predecessor blocks: two register sets, the batch for steps [h+8, h+16) is requested
-		// while the batch for [h, h+8) is consumed
-		const unsigned long long fresh0 = (unsigned long long)gen << 32;
-		unsigned long long gjA[8], gjB[8], gkA[8], gkB[8];
-#pragma unroll
-		for (int e = 0; e < 8; e++) gjA[e] = gjB[e] = gkA[e] = gkB[e] = fresh0;
-		auto request = [&](unsigned long long* g, const unsigned long long* src, int a0, bool on) {
-			if (on) {
-#pragma unroll
-				for (int e = 0; e < 8; e++) {
-					const int ae = a0 + e;
-					g[e] = (ae >= 0 && ae < NXL) ? granule_load(src + ae) : fresh0;
-				}
-			}
-		};
-		int spins = 0;
-		auto settle = [&](unsigned long long* g, const unsigned long long* src, int a0, bool on) {
-			if (on) {
-				for (;;) {
-					bool ok = true;
-#pragma unroll
-					for (int e = 0; e < 8; e++) ok = ok && ((unsigned)(g[e] >> 32) == gen);
-					if (ok || ++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(1);
-#pragma unroll
-					for (int e = 0; e < 8; e++) {
-						const int ae = a0 + e;
-						if (ae >= 0 && ae < NXL && (unsigned)(g[e] >> 32) != gen) g[e] = granule_load(src + ae);
-					}
-				}
-			}
-		};
-		// first batch (steps 0..7 of this wave's timeline start at hw = -woff)
-		request(gjA, in_j, -woff - c, pred_j);
-		request(gkA, in_k, -woff - b, pred_k);
-
+		// operands are fetched two chunks ahead into two register sets; the loads of chunk m+2 are issued right AFTER the
+		// face wait of block m, so that a polling load (vmcnt is in-order) never queues behind an HBM fetch for long
+		ChunkRegs R0, R1;
+		issue(R0, 0);
+		if (nchunks > 1) issue(R1, 1);
 		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
-		// lane-constant selectors
-		const bool dppJ = (b != 0), granJ = (b == 0) && (wj == 0);
-		const bool shfK = (c != 0), granK = (c == 0) && (wk == 0);
-		const bool wrJ = (b == 7) && (wj == 0), wrK = (c == 7) && (wk == 0);
-		const float* rdJ = &hxj[0][wk][c];
-		const float* rdK = &hxk[0][wj][b];
-		float* wtJ = &hxj[0][wk][c];
-		float* wtK = &hxk[0][wj][b];
-		unsigned mbits = 0;     // fluid bits of the 24 ring cells of my row
-		{   // chunk 0 was committed above: recover its mask
-			mbits = mF[lane];
-		}
-		int a = -woff - b - c;               // my cell at step h = 0
-		int cidx = ((a % 24) + 24) % 24;     // ring cell of `a`
-		float4 nA = mA[cidx * 64 + lane];
-		float2 nB = mB[cidx * 64 + lane];
-		if (tidx < 32) ((float*)hxj)[tidx] = 0.f;
-		else if (tidx < 64) ((float*)hxk)[tidx - 32] = 0.f;
-		__syncthreads();
-
-		for (int h0 = 0; h0 < HTOT; h0 += 16) {
+		int xq = -2 - skew;                                   // this lane's x' at the first step of the block
+		int ring = (xq + 24) % 24;                            // ring position of x' (xq >= -16)
+		float4 nA = sA[ring * 64 + lane], nB = sB[ring * 64 + lane];   // (stale data: x' < 0 is never valid)
+#pragma unroll 1
+		for (int m2 = 0; m2 <= nchunks + 1; m2 += 2) {
 #pragma unroll
-			for (int s = 0; s < 16; s++) {
-				const int hw = h0 + s - woff;
-				if ((s & 7) == 0) {
-					// batch boundary: the batch requested 8 steps ago must be complete; request the next one
-					if (s == 0) {
-						settle(gjA, in_j, hw - c, pred_j);
-						settle(gkA, in_k, hw - b, pred_k);
-						request(gjB, in_j, hw + 8 - c, pred_j);
-						request(gkB, in_k, hw + 8 - b, pred_k);
-					} else {
-						settle(gjB, in_j, hw - c, pred_j);
-						settle(gkB, in_k, hw - b, pred_k);
-						request(gjA, in_j, hw + 8 - c, pred_j);
-						request(gkA, in_k, hw + 8 - b, pred_k);
-					}
+		for (int par = 0; par < 2; par++) {
+			const int m = m2 + par;
+			if (m > nchunks + 1) break;
+			ChunkRegs& R = par ? R1 : R0;
+			// ---- wave-uniform memory phase at h = 8m-2 ----
+			unsigned long long gj[8], gk[8];
+#pragma unroll
+			for (int a = 0; a < 8; a++) {
+				const int xa = xq + a;
+				const bool in = (unsigned)xa < (unsigned)X8;
+				gj[a] = (has_pj && in) ? granule_load(in_j + (int64_t)xa * 8) : fresh0;
+				gk[a] = (has_pk && in) ? granule_load(in_k + (int64_t)xa * 8) : fresh0;
+			}
+			if (m >= 3) flush(m - 3);
+			if (m < nchunks) commit(R, m);
+			for (;;) {
+				bool ok = true;
+#pragma unroll
+				for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(gj[a] >> 32) == gen) && ((unsigned)(gk[a] >> 32) == gen);
+				if (ok || ++spins > FLOW_SPIN_LIMIT) break;
+				__builtin_amdgcn_s_sleep(1);
+#pragma unroll
+				for (int a = 0; a < 8; a++) {
+					if ((unsigned)(gj[a] >> 32) != gen) gj[a] = granule_load(in_j + (int64_t)(xq + a) * 8);
+					if ((unsigned)(gk[a] >> 32) != gen) gk[a] = granule_load(in_k + (int64_t)(xq + a) * 8);
 				}
-				if ((s & 7) == 6) {
-					// retire the finished chunk, land the staged one, start the loads two chunks ahead
-					const int qd = (hw - 22) >> 3;
-					if (hw >= 22 && qd < nchunks) writeback(qd);
-					const int qc = (hw + 2) >> 3;
-					if (hw + 2 >= 8 && qc < nchunks) {
-						if (qc & 1) {
-							commit(st1, qc);
-							if (qc + 2 < nchunks) issue(st1, qc + 2);
-						} else {
-							commit(st0, qc);
-							if (qc + 2 < nchunks) issue(st0, qc + 2);
-						}
-						const int slot = qc % 3;
-						mbits = (mbits & ~(0xffu << (8 * slot))) | ((unsigned)mF[slot * 64 + lane] << (8 * slot));
-					}
-				}
-				const float4 cA = nA;
-				const float2 cB = nB;
-				const int ccell = cidx;
-				// next step's operands
-				cidx = (cidx == 23) ? 0 : cidx + 1;
-				if (!(dbg & 4)) {
-					nA = mA[cidx * 64 + lane];
-					nB = mB[cidx * 64 + lane];
-				}
-				const int par = s & 1;
-				const float hj = rdJ[(par ^ 1) * 16], hk = rdK[(par ^ 1) * 16];
+			}
+			if (m + 2 < nchunks) issue(R, m + 2);
+			// ---- 8 steps (chunk m is first read at x' = 8m, i.e. prefetched at s >= 1: after the commit above) ----
+#pragma unroll
+			for (int s = 0; s < 8; s++) {
+				const float4 cA = nA, cB = nB;
+				const int cring = ring;
+				ring = (ring == 23) ? 0 : ring + 1;
+				nA = sA[ring * 64 + lane];
+				nB = sB[ring * 64 + lane];
+				const int x = xq + s;
 				const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
-				const float sk = (dbg & 2) ? dj : __shfl_up(ok0, 8, 64);
-				const float gjv = __uint_as_float((unsigned)((s < 8) ? gjA[s & 7] : gjB[s & 7]));
-				const float gkv = __uint_as_float((unsigned)((s < 8) ? gkA[s & 7] : gkB[s & 7]));
-				const float ij0 = dppJ ? dj : (granJ ? gjv : hj);
-				const float ik0 = shfK ? sk : (granK ? gkv : hk);
-				const float ii0 = (a == 0) ? 0.f : oi0;
-				const bool valid = (unsigned)a < (unsigned)NXL;
-				const bool fl = valid && ((mbits >> ccell) & 1u);
+				const float sk = __shfl_up(ok0, 8, 64);
+				const float ij0 = (b == 0) ? __uint_as_float((unsigned)gj[s]) : dj;
+				const float ik0 = (c == 0) ? __uint_as_float((unsigned)gk[s]) : sk;
+				const float ii0 = oi0;
+				const bool valid = (unsigned)x < (unsigned)X8;
 				const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+				const bool fl = cB.z != 0.f;
 				float val = cB.y;
 				if (MODE == 1) {
 					const float nv = p * (cA.x - ii0 - ij0 - ik0);
 					val = fl ? nv : val;
-					oi0 = (val * ai) * p;
-					oj0 = (val * aj) * p;
-					ok0 = (val * ak) * p;
+					oi0 = valid ? (val * ai) * p : 0.f;
+					oj0 = valid ? (val * aj) * p : 0.f;
+					ok0 = valid ? (val * ak) * p : 0.f;
 				} else {
 					const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
 					val = fl ? nv : val;
-					oi0 = oj0 = ok0 = val;
+					oi0 = oj0 = ok0 = valid ? val : 0.f;
 				}
-				if (!(dbg & 8)) mB[ccell * 64 + lane].y = val;   // unchanged value for non-fluid / not-yet-started cells
-				if (dbg & 8) {
-				} else if (wj == 1) {
-					if (succ_j && valid) granule_store(out_j + a, oj0, gen);
-				} else if (wrJ) {
-					wtJ[par * 16] = oj0;
+				if (valid) {
+					sB[cring * 64 + lane].y = val;
+					if (has_sj) granule_store(out_j + (int64_t)x * 8, oj0, gen);
+					if (has_sk) granule_store(out_k + (int64_t)x * 8, ok0, gen);
 				}
-				if (dbg & 8) {
-				} else if (wk == 1) {
-					if (succ_k && valid) granule_store(out_k + a, ok0, gen);
-				} else if (wrK) {
-					wtK[par * 16] = ok0;
-				}
-				a++;
-				// LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait every step for the write-through
-				// granule stores and for the chunk loads that are meant to stay in flight
-				if (!(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 			}
+			xq += 8;
 		}
-		if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
-		__syncthreads();
-	}  // ticket loop
-	if (tidx == 0) {
+		}
+		flush(nchunks - 1);
+	}
+	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+	if (lane == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
 		if (f == (int)gridDim.x - 1) {
 			ctl->ticket = 0;
@@ -1249,12 +1309,12 @@ static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st, bool need
 	*out = &f;
 	return 0;
 }
-static int stream_prepare(const Dim& d, FlowState** out, hipStream_t st) {
+static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
-	const int nbj = (d.sy + 15) / 16, nbk = (d.sz + 15) / 16, nchunks = (d.sx + 7) / 8;
-	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC block order table");
+	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8, nchunks = (d.sx + 7) / 8;
+	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC bundle order table");
 	if (!f.ctl) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
@@ -1273,7 +1333,8 @@ static int stream_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * nb));
 		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * nb, hipMemcpyHostToDevice));
 		free(h);
-		const size_t need = (size_t)nb * 16 * (8 * nchunks) * sizeof(unsigned long long);
+		// one granule per (bundle, x', face lane) and face
+		const size_t need = (size_t)nb * 8 * (8 * (size_t)nchunks) * sizeof(unsigned long long);
 		if (need > f.sx_cap) {
 			if (f.sxj) MF_HIP(hipFree(f.sxj));
 			if (f.sxk) MF_HIP(hipFree(f.sxk));
@@ -1296,12 +1357,12 @@ static int stream_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 // 1 "tiles" : one launch per sweep, ticketed 8^3 tiles + tagged sc1 granules, operands of the next tile prefetched
 //              (default: 1.7x faster than "levels" at 256^3 on MI355X, bit-identical results)
 // 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback)
-// 2 "stream": one launch per sweep, 4-wave blocks streaming along x (experimental, bit-identical, not faster yet)
+// 2 "rows"  : one launch per sweep, one wave per 8x8 bundle of x-rows streaming along x (3D grids; 2D uses "tiles")
 static int g_mic_mode = -1;
 static int mic_mode() {
 	if (g_mic_mode < 0) {
 		const char* e = getenv("MF_MIC_MODE");
-		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "stream")) ? 2 : 1);
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && (!strcmp(e, "rows") || !strcmp(e, "stream"))) ? 2 : 1);
 	}
 	return g_mic_mode;
 }
@@ -1313,30 +1374,30 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 	const int levels = nti + ntj + ntk - 2;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
 	if constexpr (MODE != 0) {
-		if (mic_mode() == 2) {
+		if (mic_mode() == 2 && d.is3d) {
 			FlowState* f;
-			MF_TRY(stream_prepare(d, &f, st));
+			MF_TRY(rows_prepare(d, &f, st));
 			f->sgen++;
 			if (f->sgen == 0) {
 				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
 				MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
 				f->sgen = 1;
 			}
-			int ncu = 256;
-			const int grid = f->nblocks < ncu ? f->nblocks : ncu;
-			static int dbgflags = -1;
-			if (dbgflags < 0) {
-				const char* e = getenv("MF_STREAM_DBG");   // timing experiments only (results are wrong when non-zero)
-				dbgflags = e ? atoi(e) : 0;
+			static int rwgs = -1;
+			if (rwgs < 0) {
+				const char* e = getenv("MF_ROWS_WGS");
+				rwgs = e ? atoi(e) : 768;   // 48 KB of LDS per single-wave workgroup: three per CU
+				if (rwgs < 1) rwgs = 1;
 			}
+			const int grid = f->nblocks < rwgs ? f->nblocks : rwgs;
 			if (vec)
-				hipLaunchKernelGGL((k_mic_stream<MODE, true>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dbgflags);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(64), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
 			else
-				hipLaunchKernelGGL((k_mic_stream<MODE, false>), dim3(grid), dim3(256), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dbgflags);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(64), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
-		if (mic_mode() == 1) {
+		if (mic_mode() >= 1) {
 			FlowState* f;
 			MF_TRY(flow_prepare(d, &f, st, true));
 			f->gen++;
