@@ -191,7 +191,7 @@ def main():
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        result["roofline"] = {"kernel": "k_apply_matrix_v4 (ApplyMatrix, conjugategrad.h:118-133)", "bound": "hbm",
+        result["roofline"] = {"kernel": "k_apply_matrix_v5 (ApplyMatrix, conjugategrad.h:118-133)", "bound": "hbm",
                               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "avg_launch_us": round(us.value, 2),
                               "algorithmic_bytes_per_launch": APPLY_MATRIX_BYTES_PER_CELL * n ** 3}

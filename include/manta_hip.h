@@ -53,6 +53,12 @@ const char* mf_backend(void);
  * coordinates, so a slab reproduces the undivided domain bit for bit.  (0, 0) restores the default (whole domain). */
 int mf_set_slab_window(int zoff, int gsz);
 
+/* How the MIC(0) substitution sweeps are parallelised on the GPU (no reference counterpart; every mode gives the same
+ * bits as the serial sweep of ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:88-128):
+ * "rows" (default for 3D), "tiles", "levels"; NULL or "" = back to the default / MF_MIC_MODE.  Returns 0, or -1 for an
+ * unknown name.  The oracle accepts and ignores it. */
+int mf_set_mic_mode(const char* name);
+
 /* ------------------------------------------------------------------------------------------------
  * Element-wise grid ops used inside the CG loop and by scenes
  * ---------------------------------------------------------------------------------------------- */

@@ -4,6 +4,8 @@
 #include "common.h"
 #include <float.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <type_traits>
 
 using namespace mf;
 
@@ -1048,46 +1050,62 @@ k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// MIC apply, row-streaming form ("rows"): ONE wave owns an 8x8 bundle of x-rows (tj,tk) and streams along the whole
-// x extent.  Lane (b,c) works on cell x' = h - b - c at step h, so
-//   * the i-dependency never leaves the lane's registers (no i-faces, no 14-step fill/drain per 8 cells: a lane is
-//     busy 8 steps out of 8 instead of 8 out of 22),
-//   * the j/k dependencies inside the bundle move by DPP / ds_bpermute exactly as in the tile kernel,
-//   * only the two outer faces of a bundle cross waves -- as tagged 8-byte sc1 granules, one per (x', face lane),
-//     fetched 8 steps at a time in a lane-relative window so a consumer bundle runs 15 steps behind its producer.
-// Operands are fetched once per 8-cell chunk, one chunk ahead, into a 3-slot LDS ring that is private per lane (a lane
-// only ever reads what it wrote itself: no barrier anywhere).  Memory operations are issued for the whole wave at
-// h = 8m-2, when chunk m-3 is complete for every lane and chunk m is needed next.  Bundles are ticketed in
-// anti-diagonal order (tj+tk), so a wave only ever waits for bundles drawn before its own.  256^3: 1024 bundles,
-// 62 bundle hops per sweep instead of 94 tile hops with 22 steps each.  Per-cell arithmetic = k_mic_tiles.
+// MIC apply, row-streaming form ("rows"): a workgroup of TWO waves owns an 8x8 bundle of x-rows (tj,tk) and streams
+// along the whole x extent.
+//   compute wave: lane (b,c) works on cell x' = h - b - c at step h.  The i-dependency never leaves the lane's
+//     registers (no i-faces, no 14-step fill/drain per 8 cells), the j/k dependencies inside the bundle move by DPP /
+//     ds_bpermute as in the tile kernel, and only the two outer faces of the bundle cross workgroups -- as tagged
+//     8-byte sc1 granules, one per (x', face lane), polled 8 steps at a time in a lane-relative window (a consumer
+//     bundle runs 15 steps behind its producer).  Its only vector-memory traffic is those granules: vmcnt is in-order,
+//     so a polling load must never queue behind an HBM fetch.
+//   memory wave: fetches the operands of the bundle's rows in 8-cell chunks, three chunks ahead, commits them to a
+//     32-step LDS ring and writes finished chunks back to dst.  The ring is indexed by the STEP at which a lane
+//     consumes the cell ((h+2) & 31), i.e. the skew b+c is applied when the memory wave stores, and every lane of the
+//     compute wave reads the same ring row at a given step: immediate LDS offsets, no per-lane address arithmetic.
+//   The two waves meet only through two LDS counters (chunks committed / blocks finished).
+// Bundles are ticketed in anti-diagonal order (tj+tk): a workgroup only ever waits for bundles drawn before its own.
+// 256^3: 1024 bundles, 62 bundle hops per sweep.  Per-cell arithmetic = k_mic_tiles = the reference's.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int ROWS_SLOTS = 3;
+constexpr int ROWS_PAD = 16;
+struct RowsChunk {
+	int F[8];
+	float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+};
+constexpr int ROWS_THREADS = 384;   // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the faces
 template <int MODE, bool VEC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(ROWS_THREADS)
 k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-           const CgScalars* __restrict__ sc) {
+           const CgScalars* __restrict__ sc, long long* trace, int trace_ticket) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
-	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
 	const int skew = b + c;
-	__shared__ float4 sA[ROWS_SLOTS * 512];   // {V, Ai, Aj, Ak}        index = (x' mod 24) * 64 + lane
-	__shared__ float4 sB[ROWS_SLOTS * 512];   // {Aprecond, dst, fluid, -}
+	// the compute wave is the critical path: everything else yields to it
+	if (wave == 0) __builtin_amdgcn_s_setprio(3);
+	else __builtin_amdgcn_s_setprio(0);
+	__shared__ float4 sA[32 * 64];   // {fluid ? rhs : dst  (-> result), Ai, Aj, Ak}     index = ((h + 2) & 31) * 64 + lane
+	__shared__ float2 sB[32 * 64];   // {Aprecond, fluid}
+	__shared__ __attribute__((aligned(16))) float sFj[2][8][8];
+	__shared__ __attribute__((aligned(16))) float sFk[2][8][8];   // face values of a block [block parity][face lane][step]
+	__shared__ int s_ready[3], s_done, s_flushed, s_faces, s_ticket;
 	const unsigned long long fresh0 = (unsigned long long)gen << 32;
 	const int X8 = nchunks * 8;
 	int spins = 0;
 
-	struct ChunkRegs {
-		int F[8];
-		float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
-	};
 	for (;;) {
-		int t = 0;
-		if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
-		t = __builtin_amdgcn_readfirstlane(t);
+		if (threadIdx.x == 0) {
+			s_ticket = atomicAdd(&ctl->ticket, 1);
+			s_ready[0] = s_ready[1] = s_ready[2] = 0;
+			s_done = 0;
+			s_flushed = 0;
+			s_faces = 0;
+		}
+		__syncthreads();
+		const int t = s_ticket;
 		if (t >= nstreams) break;
 		const int pk = order[t];
 		const int tjl = pk & 0xffff, tkl = pk >> 16;
@@ -1095,145 +1113,236 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 		const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
 		const bool row_in = (j < d.sy) && (k < d.sz);
 		const int64_t rowbase = d.Y * j + d.Z * k;
+
+		// face granules: per bundle and face an array [x'][face lane] (ROWS_PAD x' of padding on both sides so that the
+		// windows of the first / last blocks stay inside the allocation); the 8 lanes of one x' fill one 64-byte line
 		const bool has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
 		const bool has_sj = (tjl + 1 < nbj) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
 		const int64_t sid = (int64_t)tkl * nbj + tjl;
-		unsigned long long* out_j = xj + sid * X8 * 8 + c;          // + x' * 8
-		unsigned long long* out_k = xk + sid * X8 * 8 + b;
-		const unsigned long long* in_j = xj + (sid - 1) * X8 * 8 + c;
-		const unsigned long long* in_k = xk + (sid - nbj) * X8 * 8 + b;
-
-		auto chunk_geom = [&](int m, int64_t& rowidx, int& nv) {
-			const int x0 = (REV ? nchunks - 1 - m : m) * 8;
-			const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
-			nv = row_in ? nvx : 0;
-			rowidx = rowbase + x0;
-		};
-		auto issue = [&](ChunkRegs& r, int m) {
-			int64_t rowidx;
-			int nv;
-			chunk_geom(m, rowidx, nv);
-			load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
-			if (MODE == 1) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
-			load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
-			load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
-			load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
-			load_row8<VEC, REV>(Ap, rowidx, nv, r.P);
-			load_row8<VEC, REV>(dst, rowidx, nv, r.D);
-		};
-		auto commit = [&](const ChunkRegs& r, int m) {
-			int64_t rowidx;
-			int nv;
-			chunk_geom(m, rowidx, nv);
-			const int slot = m % ROWS_SLOTS;
-#pragma unroll
-			for (int a = 0; a < 8; a++) {
-				const bool in = ((REV ? 7 - a : a) < nv);
-				const bool fl = in && (r.F[a] & MF_FLUID);
-				sA[slot * 512 + a * 64 + lane] = make_float4((MODE == 1 && fl) ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
-				sB[slot * 512 + a * 64 + lane] = make_float4(r.P[a], r.D[a], fl ? 1.f : 0.f, 0.f);
-			}
-		};
-		auto flush = [&](int m) {
-			int64_t rowidx;
-			int nv;
-			chunk_geom(m, rowidx, nv);
-			const int slot = m % ROWS_SLOTS;
-			float w[8];
-#pragma unroll
-			for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sB[slot * 512 + e * 64 + lane].y;
-			if (VEC) {
-				if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
-				if (nv > 4) *(float4*)(dst + rowidx + 4) = make_float4(w[4], w[5], w[6], w[7]);
-			} else {
-#pragma unroll
-				for (int e = 0; e < 8; e++)
-					if (e < nv) dst[rowidx + e] = w[e];
-			}
-		};
-
-		// operands are fetched two chunks ahead into two register sets; the loads of chunk m+2 are issued right AFTER the
-		// face wait of block m, so that a polling load (vmcnt is in-order) never queues behind an HBM fetch for long
-		ChunkRegs R0, R1;
-		issue(R0, 0);
-		if (nchunks > 1) issue(R1, 1);
-		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
-		int xq = -2 - skew;                                   // this lane's x' at the first step of the block
-		int ring = (xq + 24) % 24;                            // ring position of x' (xq >= -16)
-		float4 nA = sA[ring * 64 + lane], nB = sB[ring * 64 + lane];   // (stale data: x' < 0 is never valid)
+		const int64_t XP = X8 + 2 * ROWS_PAD;
+		if (wave == 5) {
+			// ================= face poller: the only wave that loads granules (and it never stores to global memory) =====
+			const unsigned long long* in_j = xj + ((sid - 1) * XP + ROWS_PAD) * 8 + c;          // + x' * 8
+			const unsigned long long* in_k = xk + ((sid - nbj) * XP + ROWS_PAD) * 8 + b;
 #pragma unroll 1
-		for (int m2 = 0; m2 <= nchunks + 1; m2 += 2) {
+			for (int m = 0; m <= nchunks + 1; m++) {
+				const int xq = 8 * m - 2 - skew;
+				unsigned long long gj[8], gk[8];
 #pragma unroll
-		for (int par = 0; par < 2; par++) {
-			const int m = m2 + par;
-			if (m > nchunks + 1) break;
-			ChunkRegs& R = par ? R1 : R0;
-			// ---- wave-uniform memory phase at h = 8m-2 ----
-			unsigned long long gj[8], gk[8];
+				for (int a = 0; a < 8; a++) gj[a] = gk[a] = fresh0;
+				for (;;) {
+					if (has_pj) {
 #pragma unroll
-			for (int a = 0; a < 8; a++) {
-				const int xa = xq + a;
-				const bool in = (unsigned)xa < (unsigned)X8;
-				gj[a] = (has_pj && in) ? granule_load(in_j + (int64_t)xa * 8) : fresh0;
-				gk[a] = (has_pk && in) ? granule_load(in_k + (int64_t)xa * 8) : fresh0;
+						for (int a = 0; a < 8; a++) gj[a] = granule_load(in_j + (int64_t)(xq + a) * 8);
+					}
+					if (has_pk) {
+#pragma unroll
+						for (int a = 0; a < 8; a++) gk[a] = granule_load(in_k + (int64_t)(xq + a) * 8);
+					}
+					// tags only grow: the window is complete when its smallest tag is this sweep's generation
+					unsigned tmin = gen;
+#pragma unroll
+					for (int a = 0; a < 8; a++) {
+						const bool in = (unsigned)(xq + a) < (unsigned)X8;
+						const unsigned tj_ = (unsigned)(gj[a] >> 32), tk_ = (unsigned)(gk[a] >> 32);
+						tmin = min(tmin, in ? min(tj_, tk_) : gen);
+					}
+					if (__all(tmin == gen) || ++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				// the buffer of this parity was read by block m-2
+				if (m >= 2) {
+					while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m - 1) {
+						if (++spins > FLOW_SPIN_LIMIT) break;
+						__builtin_amdgcn_s_sleep(8);
+					}
+				}
+				if (b == 0) {
+#pragma unroll
+					for (int a = 0; a < 8; a++) sFj[m & 1][c][a] = __uint_as_float((unsigned)gj[a]);
+				}
+				if (c == 0) {
+#pragma unroll
+					for (int a = 0; a < 8; a++) sFk[m & 1][b][a] = __uint_as_float((unsigned)gk[a]);
+				}
+				__hip_atomic_store(&s_faces, m + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
-			if (m >= 3) flush(m - 3);
-			if (m < nchunks) commit(R, m);
-			for (;;) {
-				bool ok = true;
+		} else if (wave != 0) {
+			// ================= memory waves: waves 1-3 load + commit, wave 4 writes finished chunks back =================
+			// (separate waves because vmcnt is one in-order counter per wave: a wave that has loads of several chunks or
+			// loads and stores in flight ends up waiting for all of them)
+			auto chunk_geom = [&](int m, int64_t& rowidx, int& nv) {
+				const int x0 = (REV ? nchunks - 1 - m : m) * 8;
+				const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+				nv = row_in ? nvx : 0;
+				rowidx = rowbase + x0;
+			};
+			auto wait_for = [&](int* flag, int need) {
+				while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(8);
+				}
+			};
+			if (wave <= 3) {
+				auto issue = [&](RowsChunk& r, int m) {
+					int64_t rowidx;
+					int nv;
+					chunk_geom(m, rowidx, nv);
+					load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
+					if (MODE == 1) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
+					load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
+					load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
+					load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
+					load_row8<VEC, REV>(Ap, rowidx, nv, r.P);
+					load_row8<VEC, REV>(dst, rowidx, nv, r.D);
+				};
+				auto commit = [&](const RowsChunk& r, int m) {
+					int64_t rowidx;
+					int nv;
+					chunk_geom(m, rowidx, nv);
+					const int p0 = 8 * m + skew + 2;
 #pragma unroll
-				for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(gj[a] >> 32) == gen) && ((unsigned)(gk[a] >> 32) == gen);
-				if (ok || ++spins > FLOW_SPIN_LIMIT) break;
-				__builtin_amdgcn_s_sleep(1);
+					for (int a = 0; a < 8; a++) {
+						const bool in = ((REV ? 7 - a : a) < nv);
+						const bool fl = in && (r.F[a] & MF_FLUID);
+						const int idx = ((p0 + a) & 31) * 64 + lane;
+						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], r.Ai[a], r.Aj[a], r.Ak[a]);
+						sB[idx] = make_float2(r.P[a], fl ? 1.f : 0.f);
+					}
+				};
+				// one chunk in flight per loader wave: its loads are issued as soon as the previous chunk of this wave is
+				// committed (three blocks before the compute wave needs them), then the wave waits for the ring rows
+				RowsChunk R;
+				const int w = wave - 1;
+#pragma unroll 1
+				for (int n = w; n < nchunks; n += 3) {
+					issue(R, n);
+					// the ring rows of chunk n were last used by chunk n-4: it must have been written back
+					if (n >= 4) wait_for(&s_flushed, n - 3);
+					commit(R, n);
+					__hip_atomic_store(&s_ready[w], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			} else {
+#pragma unroll 1
+				for (int q = 0; q < nchunks; q++) {
+					wait_for(&s_done, q + 3);   // chunk q is complete once block q+2 is finished
+					int64_t rowidx;
+					int nv;
+					chunk_geom(q, rowidx, nv);
+					const int p0 = 8 * q + skew + 2;
+					float w[8];
 #pragma unroll
-				for (int a = 0; a < 8; a++) {
-					if ((unsigned)(gj[a] >> 32) != gen) gj[a] = granule_load(in_j + (int64_t)(xq + a) * 8);
-					if ((unsigned)(gk[a] >> 32) != gen) gk[a] = granule_load(in_k + (int64_t)(xq + a) * 8);
+					for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sA[((p0 + e) & 31) * 64 + lane].x;
+					__hip_atomic_store(&s_flushed, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (VEC) {
+						if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
+						if (nv > 4) *(float4*)(dst + rowidx + 4) = make_float4(w[4], w[5], w[6], w[7]);
+					} else {
+#pragma unroll
+						for (int e = 0; e < 8; e++)
+							if (e < nv) dst[rowidx + e] = w[e];
+					}
 				}
 			}
-			if (m + 2 < nchunks) issue(R, m + 2);
-			// ---- 8 steps (chunk m is first read at x' = 8m, i.e. prefetched at s >= 1: after the commit above) ----
-#pragma unroll
-			for (int s = 0; s < 8; s++) {
-				const float4 cA = nA, cB = nB;
-				const int cring = ring;
-				ring = (ring == 23) ? 0 : ring + 1;
-				nA = sA[ring * 64 + lane];
-				nB = sB[ring * 64 + lane];
-				const int x = xq + s;
-				const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
-				const float sk = __shfl_up(ok0, 8, 64);
-				const float ij0 = (b == 0) ? __uint_as_float((unsigned)gj[s]) : dj;
-				const float ik0 = (c == 0) ? __uint_as_float((unsigned)gk[s]) : sk;
-				const float ii0 = oi0;
-				const bool valid = (unsigned)x < (unsigned)X8;
-				const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
-				const bool fl = cB.z != 0.f;
-				float val = cB.y;
-				if (MODE == 1) {
-					const float nv = p * (cA.x - ii0 - ij0 - ik0);
-					val = fl ? nv : val;
-					oi0 = valid ? (val * ai) * p : 0.f;
-					oj0 = valid ? (val * aj) * p : 0.f;
-					ok0 = valid ? (val * ak) * p : 0.f;
-				} else {
-					const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
-					val = fl ? nv : val;
-					oi0 = oj0 = ok0 = valid ? val : 0.f;
-				}
-				if (valid) {
-					sB[cring * 64 + lane].y = val;
-					if (has_sj) granule_store(out_j + (int64_t)x * 8, oj0, gen);
-					if (has_sk) granule_store(out_k + (int64_t)x * 8, ok0, gen);
-				}
+		} else {
+			// ================= compute wave: LDS in, LDS + face granules out =================
+			// + x' * 8: the 8 face lanes of one x' share a line.  Lane 0 stands in for lane 63's k face: its x' runs 14 ahead
+			const bool corner_proxy = (lane == 0) && (tkl + 1 < nbk);
+			const bool face_lane = has_sj || (has_sk && lane != 63) || corner_proxy;
+			const int fskew = corner_proxy ? -14 : 0;
+			unsigned long long* out_f = has_sj ? xj + (sid * XP + ROWS_PAD) * 8 + c
+			                                   : (corner_proxy ? xk + (sid * XP + ROWS_PAD - 14) * 8 + 7 : xk + (sid * XP + ROWS_PAD) * 8 + b);
+			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+			float4 nA = sA[lane];                  // ring row of h = -2 (never valid)
+			float2 nB = sB[lane];
+			const bool tr = trace && (t == trace_ticket) && lane == 0;
+			if (trace && lane == 0 && t < 4096) {
+				trace[4 * 4096 + 2 * t] = wall_clock64();
+				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
 			}
-			xq += 8;
+#define ROWS_TRACE(i) if (tr) trace[m * 4 + (i)] = wall_clock64();
+			auto block = [&](int m, auto edge_tag) {
+				constexpr bool EDGE = decltype(edge_tag)::value;
+				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
+				ROWS_TRACE(0)
+				if (m < nchunks) {
+					int* flag = &s_ready[m % 3];
+					while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m + 1) {
+						if (++spins > FLOW_SPIN_LIMIT) break;
+						__builtin_amdgcn_s_sleep(1);
+					}
+				}
+				ROWS_TRACE(1)
+				while (__hip_atomic_load(&s_faces, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m + 1) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				float gj[8], gk[8];
+				{
+					const float4 j0 = *(const float4*)&sFj[m & 1][c][0], j1 = *(const float4*)&sFj[m & 1][c][4];
+					const float4 k0 = *(const float4*)&sFk[m & 1][b][0], k1 = *(const float4*)&sFk[m & 1][b][4];
+					gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
+					gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
+				}
+				ROWS_TRACE(2)
+				const int base = (8 * m) & 31;
+				unsigned long long* pf = out_f + (int64_t)xq * 8;
+#pragma unroll
+				for (int s = 0; s < 8; s++) {
+					const float4 cA = nA;
+					const float2 cB = nB;
+					const int row = ((base + s) & 31) * 64 + lane;
+					const int nrow = ((base + s + 1) & 31) * 64 + lane;
+					nA = sA[nrow];
+					nB = sB[nrow];
+					const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+					const float sk = __shfl_up(ok0, 8, 64);
+					const float ij0 = (b == 0) ? gj[s] : dj;
+					const float ik0 = (c == 0) ? gk[s] : sk;
+					const float ii0 = oi0;
+					const bool valid = !EDGE || ((unsigned)(xq + s) < (unsigned)X8);
+					const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+					const bool fl = cB.y != 0.f;
+					float val = cA.x;
+					if (MODE == 1) {
+						const float nv = p * (val - ii0 - ij0 - ik0);
+						val = fl ? nv : val;
+						oi0 = valid ? (val * ai) * p : 0.f;
+						oj0 = valid ? (val * aj) * p : 0.f;
+						ok0 = valid ? (val * ak) * p : 0.f;
+					} else {
+						const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+						val = fl ? nv : val;
+						oi0 = oj0 = ok0 = valid ? val : 0.f;
+					}
+					// one face store per step: lanes b == 7 publish the j face, lanes c == 7 the k face, and lane 0 (never a
+					// face lane) publishes the k value of the corner lane 63, which is busy with its j value
+					const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), 63));
+					const float fv = (lane == 0) ? corner : ((b == 7) ? oj0 : ok0);
+					if (valid) sA[row].x = val;
+					if (face_lane) {
+						const bool fvalid = !EDGE || ((unsigned)(xq + s + fskew) < (unsigned)X8);
+						if (fvalid) granule_store(pf + s * 8, fv, gen);
+					}
+				}
+				// LDS-only release: the block's granule stores need not have been acknowledged before the next block starts
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+				__hip_atomic_store(&s_done, m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				ROWS_TRACE(3)
+			};
+#pragma unroll 1
+			for (int m = 0; m <= nchunks + 1; m++) {
+				// interior: every lane's x' is inside [0, X8) for all 8 steps of the block
+				if (m >= 2 && m <= nchunks - 1) block(m, std::false_type{});
+				else block(m, std::true_type{});
+			}
+			if (trace && lane == 0 && t < 4096) trace[4 * 4096 + 2 * t + 1] = wall_clock64();
+#undef ROWS_TRACE
 		}
-		}
-		flush(nchunks - 1);
+		__syncthreads();
 	}
 	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
-	if (lane == 0) {
+	if (threadIdx.x == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
 		if (f == (int)gridDim.x - 1) {
 			ctl->ticket = 0;
@@ -1334,7 +1443,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * nb, hipMemcpyHostToDevice));
 		free(h);
 		// one granule per (bundle, x', face lane) and face
-		const size_t need = (size_t)nb * 8 * (8 * (size_t)nchunks) * sizeof(unsigned long long);
+		const size_t need = (size_t)nb * 8 * (8 * (size_t)nchunks + 2 * ROWS_PAD) * sizeof(unsigned long long);
 		if (need > f.sx_cap) {
 			if (f.sxj) MF_HIP(hipFree(f.sxj));
 			if (f.sxk) MF_HIP(hipFree(f.sxk));
@@ -1354,15 +1463,25 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	*out = &f;
 	return 0;
 }
+// MF_MIC_MODE selects how the two apply sweeps are parallelised (all three give bit-identical results):
+// 2 "rows"  : one launch per sweep, a 6-wave workgroup per 8x8 bundle of x-rows streaming along x (default for 3D grids:
+//              256^3 apply 0.83 ms; 2D grids fall through to "tiles")
 // 1 "tiles" : one launch per sweep, ticketed 8^3 tiles + tagged sc1 granules, operands of the next tile prefetched
-//              (default: 1.7x faster than "levels" at 256^3 on MI355X, bit-identical results)
-// 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback)
-// 2 "rows"  : one launch per sweep, one wave per 8x8 bundle of x-rows streaming along x (3D grids; 2D uses "tiles")
+//              (256^3 apply 1.32 ms)
+// 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback, 2.2 ms)
 static int g_mic_mode = -1;
+extern "C" int mf_set_mic_mode(const char* name) {
+	if (!name || !*name) g_mic_mode = -1;
+	else if (!strcmp(name, "levels")) g_mic_mode = 0;
+	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
+	else if (!strcmp(name, "rows")) g_mic_mode = 2;
+	else return fail("mf_set_mic_mode: unknown mode (rows | tiles | levels)");
+	return 0;
+}
 static int mic_mode() {
 	if (g_mic_mode < 0) {
 		const char* e = getenv("MF_MIC_MODE");
-		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && (!strcmp(e, "rows") || !strcmp(e, "stream"))) ? 2 : 1);
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : 2);
 	}
 	return g_mic_mode;
 }
@@ -1386,15 +1505,64 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			static int rwgs = -1;
 			if (rwgs < 0) {
 				const char* e = getenv("MF_ROWS_WGS");
-				rwgs = e ? atoi(e) : 768;   // 48 KB of LDS per single-wave workgroup: three per CU
+				int dev = 0, ncu = 256;
+				(void)hipGetDevice(&dev);
+				(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+				// one bundle per CU measured best (256^3: 834 us per apply with 256 workgroups, 1040 us with 512): the
+				// sweep is bound by the chain of face hand-offs, and a second bundle per CU slows both
+				rwgs = e ? atoi(e) : ncu;
 				if (rwgs < 1) rwgs = 1;
 			}
 			const int grid = f->nblocks < rwgs ? f->nblocks : rwgs;
+			// MF_ROWS_TRACE=<ticket>: per-block wall-clock stamps (100 MHz) of that bundle's compute wave, printed per launch
+			static long long* trace = nullptr;
+			static int trace_ticket = -2;
+			if (trace_ticket == -2) {
+				const char* e = getenv("MF_ROWS_TRACE");
+				trace_ticket = e ? atoi(e) : -1;
+				if (trace_ticket >= 0) {
+					MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 8 * 4096));
+					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 8 * 4096));
+				}
+			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(64), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(64), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket);
 			MF_LAUNCH_CHECK();
+			if (trace) {
+				static int printed = 0;
+				MF_HIP(hipStreamSynchronize(st));
+				if (printed++ < 4) {
+					const int nb = f->nchunks + 2;
+					long long* h = (long long*)malloc(sizeof(long long) * 4 * nb);
+					MF_HIP(hipMemcpy(h, trace, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
+					fprintf(stderr, "[rows trace] mode %d ticket %d: block: gap ready poll steps (us)\n", MODE, trace_ticket);
+					for (int m = 0; m < nb; m++)
+						fprintf(stderr, "  m=%2d  %6.2f %6.2f %6.2f %6.2f   t=%.2f\n", m, m ? (h[m * 4] - h[m * 4 - 1]) * 0.01 : 0.0, (h[m * 4 + 1] - h[m * 4]) * 0.01,
+						        (h[m * 4 + 2] - h[m * 4 + 1]) * 0.01, (h[m * 4 + 3] - h[m * 4 + 2]) * 0.01, (h[m * 4 + 3] - h[0]) * 0.01);
+					free(h);
+					const int ns = f->nblocks < 4096 ? f->nblocks : 4096;
+					long long* g = (long long*)malloc(sizeof(long long) * 2 * ns);
+					MF_HIP(hipMemcpy(g, trace + 4 * 4096, sizeof(long long) * 2 * ns, hipMemcpyDeviceToHost));
+					long long t0 = g[0];
+					for (int i = 0; i < ns; i++) if (g[2 * i] < t0) t0 = g[2 * i];
+					fprintf(stderr, "[rows trace] bundles: ticket start end (us since first start)\n");
+					for (int i = 0, L = 0; i < ns; L++, i += (L < f->nbj ? L : 1) + 0) {
+						fprintf(stderr, "  t=%4d  %8.2f %8.2f\n", i, (g[2 * i] - t0) * 0.01, (g[2 * i + 1] - t0) * 0.01);
+						if (L > 200) break;
+					}
+					free(g);
+					long long* hw = (long long*)malloc(sizeof(long long) * ns);
+					MF_HIP(hipMemcpy(hw, trace + 6 * 4096, sizeof(long long) * ns, hipMemcpyDeviceToHost));
+					fprintf(stderr, "[rows trace] compute wave placement: ticket block simd cu sh se\n");
+					for (int i = 0; i < ns && i < 1024; i += 37) {
+						const unsigned v = (unsigned)hw[i];
+						fprintf(stderr, "  t=%4d blk=%4d simd=%u cu=%u sh=%u se=%u wave=%u\n", i, (int)(hw[i] >> 32), (v >> 4) & 3, (v >> 8) & 15, (v >> 12) & 1, (v >> 13) & 7, v & 15);
+					}
+					free(hw);
+				}
+			}
 			return 0;
 		}
 		if (mic_mode() >= 1) {

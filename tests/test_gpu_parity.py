@@ -93,6 +93,33 @@ def test_mic(hip, oracle, dims):
         assert_bitexact(dst, dst_o, "mic apply")
 
 
+@pytest.mark.parametrize("mode", ["rows", "tiles", "levels"])
+@pytest.mark.parametrize("dims", [(32, 24, 40), (37, 21, 19), (64, 64, 64), (24, 40, 9), (16, 8, 136)])
+def test_mic_every_sweep_mode(hip, oracle, dims, mode):
+    """the three ways the MIC sweeps are parallelised (mf_set_mic_mode) give the serial sweep's bits, and a CG solve
+    takes the same number of iterations in each"""
+    flags, A, src = cases.system_inputs(dims, 3)
+    rhs = cases.cg_rhs(dims, flags, 3)
+    ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
+    xo, sto = cases.run_cg_impl(oracle, dims, flags, A, rhs, 2, 1e-4, 50, 0)
+    assert hip.lib.cdll.mf_set_mic_mode(mode.encode()) == 0
+    try:
+        ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
+        x, st = cases.run_cg_impl(hip, dims, flags, A, rhs, 2, 1e-4, 50, 0)
+    finally:
+        assert hip.lib.cdll.mf_set_mic_mode(None) == 0
+    assert_bitexact(ap, ap_o, "Aprecond " + mode)
+    assert_bitexact(dst, dst_o, "mic apply " + mode)
+    assert st[0] == sto[0], (mode, st, sto)
+    _close(x, xo, "cg solution " + mode)
+
+
+def test_mic_mode_rejects_unknown_name(hip):
+    assert hip.lib.cdll.mf_set_mic_mode(b"diagonal") != 0
+    assert b"unknown mode" in hip.lib.cdll.mf_last_error()
+    assert hip.lib.cdll.mf_set_mic_mode(None) == 0
+
+
 @pytest.mark.parametrize("dims", DIMS)
 @pytest.mark.parametrize("pc,acc,iters,l2", [(2, 1e-3, 60, 0), (2, 1e-9, 3, 0), (0, 1e-3, 80, 0), (2, 1e-4, 60, 1)])
 def test_cg_solve(hip, oracle, dims, pc, acc, iters, l2):
