@@ -1078,7 +1078,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-           const CgScalars* __restrict__ sc, long long* trace, int trace_ticket) {
+           const CgScalars* __restrict__ sc, long long* trace, int trace_ticket, int trace_ticket2) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
@@ -1114,16 +1114,17 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 		const bool row_in = (j < d.sy) && (k < d.sz);
 		const int64_t rowbase = d.Y * j + d.Z * k;
 
-		// face granules: per bundle and face an array [x'][face lane] (ROWS_PAD x' of padding on both sides so that the
-		// windows of the first / last blocks stay inside the allocation); the 8 lanes of one x' fill one 64-byte line
+		// face granules: per bundle and face an array [producer step h + 2][face lane]: the 8 face lanes of one step (one
+		// store instruction) fill exactly one 64-byte line, and a consumer lane's 8-step window maps to 8 consecutive lines
+		// (lane (7,c) publishes x' at step x'+7+c, lane (b,7) at x'+b+7: the same steps 8m+5 .. 8m+12 for every face lane)
 		const bool has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
 		const bool has_sj = (tjl + 1 < nbj) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
 		const int64_t sid = (int64_t)tkl * nbj + tjl;
 		const int64_t XP = X8 + 2 * ROWS_PAD;
 		if (wave == 5) {
 			// ================= face poller: the only wave that loads granules (and it never stores to global memory) =====
-			const unsigned long long* in_j = xj + ((sid - 1) * XP + ROWS_PAD) * 8 + c;          // + x' * 8
-			const unsigned long long* in_k = xk + ((sid - nbj) * XP + ROWS_PAD) * 8 + b;
+			const unsigned long long* in_j = xj + (sid - 1) * XP * 8 + c;          // + (h + 2) * 8
+			const unsigned long long* in_k = xk + (sid - nbj) * XP * 8 + b;
 #pragma unroll 1
 			for (int m = 0; m <= nchunks + 1; m++) {
 				const int xq = 8 * m - 2 - skew;
@@ -1133,11 +1134,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 				for (;;) {
 					if (has_pj) {
 #pragma unroll
-						for (int a = 0; a < 8; a++) gj[a] = granule_load(in_j + (int64_t)(xq + a) * 8);
+						for (int a = 0; a < 8; a++) gj[a] = granule_load(in_j + (int64_t)(8 * m + 7 + a) * 8);
 					}
 					if (has_pk) {
 #pragma unroll
-						for (int a = 0; a < 8; a++) gk[a] = granule_load(in_k + (int64_t)(xq + a) * 8);
+						for (int a = 0; a < 8; a++) gk[a] = granule_load(in_k + (int64_t)(8 * m + 7 + a) * 8);
 					}
 					// tags only grow: the window is complete when its smallest tag is this sweep's generation
 					unsigned tmin = gen;
@@ -1246,21 +1247,21 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 			}
 		} else {
 			// ================= compute wave: LDS in, LDS + face granules out =================
-			// + x' * 8: the 8 face lanes of one x' share a line.  Lane 0 stands in for lane 63's k face: its x' runs 14 ahead
+			// Lane 0 stands in for lane 63's k face (same step, but its own x' runs 14 ahead of lane 63's)
 			const bool corner_proxy = (lane == 0) && (tkl + 1 < nbk);
 			const bool face_lane = has_sj || (has_sk && lane != 63) || corner_proxy;
 			const int fskew = corner_proxy ? -14 : 0;
-			unsigned long long* out_f = has_sj ? xj + (sid * XP + ROWS_PAD) * 8 + c
-			                                   : (corner_proxy ? xk + (sid * XP + ROWS_PAD - 14) * 8 + 7 : xk + (sid * XP + ROWS_PAD) * 8 + b);
+			unsigned long long* out_f = has_sj ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
 			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
 			float4 nA = sA[lane];                  // ring row of h = -2 (never valid)
 			float2 nB = sB[lane];
-			const bool tr = trace && (t == trace_ticket) && lane == 0;
+			const bool tr = trace && (t == trace_ticket || t == trace_ticket2) && lane == 0;
+			long long* trb = trace + (t == trace_ticket2 ? 8 * 4096 : 0);
 			if (trace && lane == 0 && t < 4096) {
 				trace[4 * 4096 + 2 * t] = wall_clock64();
 				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
 			}
-#define ROWS_TRACE(i) if (tr) trace[m * 4 + (i)] = wall_clock64();
+#define ROWS_TRACE(i) if (tr) trb[m * 4 + (i)] = wall_clock64();
 			auto block = [&](int m, auto edge_tag) {
 				constexpr bool EDGE = decltype(edge_tag)::value;
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
@@ -1286,7 +1287,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 				}
 				ROWS_TRACE(2)
 				const int base = (8 * m) & 31;
-				unsigned long long* pf = out_f + (int64_t)xq * 8;
+				unsigned long long* pf = out_f + (int64_t)(8 * m) * 8;   // row h + 2 = 8m + s
 #pragma unroll
 				for (int s = 0; s < 8; s++) {
 					const float4 cA = nA;
@@ -1517,18 +1518,19 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			// MF_ROWS_TRACE=<ticket>: per-block wall-clock stamps (100 MHz) of that bundle's compute wave, printed per launch
 			static long long* trace = nullptr;
 			static int trace_ticket = -2;
+			static const int trace_ticket2 = getenv("MF_ROWS_TRACE2") ? atoi(getenv("MF_ROWS_TRACE2")) : -1;
 			if (trace_ticket == -2) {
 				const char* e = getenv("MF_ROWS_TRACE");
 				trace_ticket = e ? atoi(e) : -1;
 				if (trace_ticket >= 0) {
-					MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 8 * 4096));
-					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 8 * 4096));
+					MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 12 * 4096));
+					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 12 * 4096));
 				}
 			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
 			MF_LAUNCH_CHECK();
 			if (trace) {
 				static int printed = 0;
@@ -1541,6 +1543,16 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 					for (int m = 0; m < nb; m++)
 						fprintf(stderr, "  m=%2d  %6.2f %6.2f %6.2f %6.2f   t=%.2f\n", m, m ? (h[m * 4] - h[m * 4 - 1]) * 0.01 : 0.0, (h[m * 4 + 1] - h[m * 4]) * 0.01,
 						        (h[m * 4 + 2] - h[m * 4 + 1]) * 0.01, (h[m * 4 + 3] - h[m * 4 + 2]) * 0.01, (h[m * 4 + 3] - h[0]) * 0.01);
+					if (trace_ticket2 >= 0) {
+						// producer (ticket) vs consumer (ticket2): consumer block m needs the producer's step 8m+12 (its block m+1)
+						long long* h2 = (long long*)malloc(sizeof(long long) * 4 * nb);
+						MF_HIP(hipMemcpy(h2, trace + 8 * 4096, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
+						fprintf(stderr, "[rows trace] hand-off %d -> %d: m  producer_end(m+1)  consumer_faces_ready(m)  delta   consumer_block_start(m)\n", trace_ticket, trace_ticket2);
+						for (int m = 0; m + 1 < nb; m++)
+							fprintf(stderr, "  m=%2d  %8.2f  %8.2f  %6.2f   %8.2f\n", m, (h[(m + 1) * 4 + 3] - h[0]) * 0.01, (h2[m * 4 + 2] - h[0]) * 0.01,
+							        (h2[m * 4 + 2] - h[(m + 1) * 4 + 3]) * 0.01, (h2[m * 4] - h[0]) * 0.01);
+						free(h2);
+					}
 					free(h);
 					const int ns = f->nblocks < 4096 ? f->nblocks : 4096;
 					long long* g = (long long*)malloc(sizeof(long long) * 2 * ns);
