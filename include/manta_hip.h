@@ -236,6 +236,53 @@ int mf_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int6
                         const int32_t* pflag, const int32_t* ptype, int exclude, const float* phiObs, int32_t* ftmp,
                         void* stream);
 
+/* ParticleSystem::projectOutOfBnd -> KnProjectOutOfBnd, particle.h:579-604.  axis: bit0 'x', bit1 'X', bit2 'y',
+ * bit3 'Y', bit4 'z', bit5 'Z' (the letters of the reference's `plane` string) */
+int mf_project_out_of_bnd(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag,
+                          float bnd, int axis, const int32_t* ptype, int exclude, void* stream);
+/* pushOutofObs -> knPushOutofObs, plugin/flip.cpp:584-602 (getInterpolated grid.h:134, getGradient grid.h:556-573,
+ * normalize vectorbase.h:421-434) */
+int mf_push_out_of_obs(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag,
+                       const float* phiObs, float shift, float thresh, const int32_t* ptype, int exclude, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * "next" rows: free-surface pieces of scenes/benchmark_dam.py
+ * ---------------------------------------------------------------------------------------------- */
+/* gridParticleIndex, plugin/flip.cpp:273-320: index(cell) = first slot of the cell in indexSys, indexSys = particle
+ * indices ordered by (cell, particle index) -- the order the reference's serial counting sort produces.  Particles that
+ * are inactive or outside the grid are skipped.  counter: Int scratch grid; keys/vals: int32[2*np] scratch each;
+ * *n_indexed_host (nullable) receives the size the reference gives indexSys. */
+int mf_grid_particle_index(int sx, int sy, int sz, int64_t np, int64_t pstride, const float* pos, const int32_t* pflag,
+                           int32_t* indexSys, int32_t* index, int32_t* counter, int32_t* keys, int32_t* vals,
+                           int64_t* n_indexed_host, void* stream);
+/* unionParticleLevelset -> ComputeUnionLevelsetPindex + phi.setBound(0.5, 0), plugin/flip.cpp:322-363;
+ * n_indexed = indexSys.size() */
+int mf_union_particle_levelset(int sx, int sy, int sz, int64_t np, int64_t pstride, const float* pos,
+                               const int32_t* indexSys, int64_t n_indexed, const int32_t* index, float* phi,
+                               float radiusFactor, const int32_t* ptype, int exclude, void* stream);
+/* extrapolateLsSimple, fastmarch.cpp:432-522 (knExtrapolateLsSimple, knSetRemaining).  tmp: Int scratch grid */
+int mf_extrapolate_ls_simple(int sx, int sy, int sz, float* phi, int distance, int inside, int include_walls,
+                             int32_t* tmp, void* stream);
+/* setPartType -> KnSetPartType, plugin/ptsplugins.cpp:56-65 */
+int mf_set_part_type(int sx, int sy, int sz, const int32_t* flags, int64_t np, int64_t pstride, const float* pos,
+                     int32_t* ptype, int mark, int stype, int cflag, void* stream);
+/* markIsolatedFluidCell -> knMarkIsolatedFluidCell, grid.cpp:987-1011 */
+int mf_mark_isolated_fluid_cell(int sx, int sy, int sz, int32_t* flags, int mark, void* stream);
+/* addForcePvel -> KnAddForcePvel (da = a*dt formed in fp32), plugin/ptsplugins.cpp:20-29 */
+int mf_add_force_pvel(int64_t np, int64_t pstride, float* pvel, float ax, float ay, float az, float dt,
+                      const int32_t* ptype, int exclude, void* stream);
+/* updateVelocityFromDeltaPos -> KnUpdateVelocityFromDeltaPos (over_dt = 1.0/dt in double, rounded), ptsplugins.cpp:31-41 */
+int mf_update_velocity_from_delta_pos(int64_t np, int64_t pstride, const float* pos, float* pvel, const float* xprev,
+                                      float dt, const int32_t* ptype, int exclude, void* stream);
+/* eulerStep -> KnStepEuler, ptsplugins.cpp:43-53 */
+int mf_euler_step(int64_t np, int64_t pstride, float* pos, const float* pvel, float dt, const int32_t* ptype,
+                  int exclude, void* stream);
+/* LevelsetGrid::join -> KnJoin (min) / subtract -> KnSubtract (phi = -other where other < 0; flags nullable: only in
+ * cells with flags & subtractType), levelset.cpp:107-118; Grid::setBound -> knSetBoundary grid.cpp:629-637 */
+int mf_levelset_join(int64_t n, float* phi, const float* other, void* stream);
+int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_t* flags, int subtractType, void* stream);
+int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boundaryWidth, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * HIP-only helpers (return an error in the CPU libraries)
  * ---------------------------------------------------------------------------------------------- */

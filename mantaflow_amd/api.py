@@ -2,15 +2,16 @@
 495-608, plus the constants of source/python/defines.py)."""
 import sys
 
-from .core import (BasicParticleSystem, FlagGrid, FluidSolver, Grid, IntGrid, LevelsetGrid, MACGrid, PdataInt, PdataReal,
-                   PdataVec3, RealGrid, Solver, Vec3Grid, VecGrid, vec3)
+from .core import (BasicParticleSystem, FlagGrid, FluidSolver, Grid, IntGrid, LevelsetGrid, MACGrid, Mesh, ParticleIndexSystem,
+                   PdataInt, PdataReal, PdataVec3, RealGrid, Solver, Vec3Grid, VecGrid, vec3)
 from .plugins import (Timings, extrapolateMACFromWeight, extrapolateMACSimple, markFluidCells, addBuoyancy, addGravity, addGravityNoScale, advectSemiLagrange, computePressureRhs,
                       correctVelocity, flipVelocityUpdate, lastCgStats, mapGridToParts, mapGridToPartsVec3, mapMACToParts,
                       mapPartsToGrid, mapPartsToGridVec3, mapPartsToMAC, setDeterministicP2G, setWallBcs, solvePressure,
-                      solvePressureSystem)
+                      solvePressureSystem, pushOutofObs, gridParticleIndex, unionParticleLevelset, extrapolateLsSimple,
+                      setPartType, markIsolatedFluidCell, addForcePvel, updateVelocityFromDeltaPos, eulerStep)
 
-from .scene import (Box, Cylinder, NoiseField, Shape, Sphere, densityInflow, sampleFlagsWithParticles,
-                    sampleLevelsetWithParticles)
+from .scene import (Box, Cylinder, Gui, NoiseField, Shape, Sphere, densityInflow, sampleFlagsWithParticles,
+                    sampleLevelsetWithParticles, sampleShapeWithParticles)
 
 # module constants, registry.cpp:390-421
 GUI = False

@@ -307,6 +307,10 @@ class Grid(GridBase):
     def safeDivide(self, a): self._check_same(a); self._call("mf_grid_safe_divide", self.n, self.ptr, a.ptr, self.parent.stream)
     def stomp(self, th): self._call("mf_grid_stomp", self.n, self.ptr, float(th), self.parent.stream)
 
+    def setBound(self, value, boundaryWidth=1):
+        """Grid::setBound -> knSetBoundary, grid.cpp:629-637"""
+        self._call("mf_grid_set_bound", self.sx, self.sy, self.sz, self.ptr, float(value), int(boundaryWidth), self.parent.stream)
+
     def getMaxAbs(self):
         r = ctypes.c_float()
         self._call("mf_grid_max_abs", self.n, self.ptr, ctypes.byref(r), self.parent.stream)
@@ -382,9 +386,20 @@ class LevelsetGrid(Grid):
     @staticmethod
     def invalidTimeValue(): return -1000.0   # levelset.h:45
 
-    # join = min, subtract = max(a, -b)  (levelset.cpp:127-147); scene setup only -> torch ops
-    def join(self, o): self.data.copy_(torch.minimum(self.data, o.data))
-    def subtract(self, o): self.data.copy_(torch.where(self.data < -o.data, -o.data, self.data))
+    def join(self, o):
+        """LevelsetGrid::join -> KnJoin, levelset.cpp:107-111"""
+        self._check_same(o)
+        self._call("mf_levelset_join", self.n, self.ptr, o.ptr, self.parent.stream)
+
+    def subtract(self, o, flags=None, subtractType=0):
+        """LevelsetGrid::subtract -> KnSubtract, levelset.cpp:113-118 (this = -o where o < 0)"""
+        self._check_same(o)
+        self._call("mf_levelset_subtract", self.n, self.ptr, o.ptr, None if flags is None else flags.ptr,
+                   int(subtractType), self.parent.stream)
+
+    def createMesh(self, mesh):
+        """marching-cubes surface extraction is GUI/mesh output, outside the solver hot path: accepted and ignored"""
+        return None
 
 
 class FlagGrid(IntGrid):
@@ -530,6 +545,10 @@ class PdataInt(ParticleDataImpl):
     _cname_py, _cname_cpp, _T = "PdataInt", "ParticleDataImpl", "int"
     def setConst(self, v): self.data.fill_(int(v))
 
+    def setConstRange(self, s, begin, end):
+        """ParticleDataImpl::setConstRange, particle.cpp: [begin, end)"""
+        self.data[int(begin):int(end)] = int(s)
+
 
 class PdataVec3(ParticleDataImpl):
     _ncomp = 3
@@ -539,6 +558,29 @@ class PdataVec3(ParticleDataImpl):
         v = _to_vec3(v)
         for c, x in enumerate((v.x, v.y, v.z)):
             self.data[c * self.cap:(c + 1) * self.cap] = float(x)
+
+
+class ParticleIndexSystem(PbClass):
+    """ParticleSystem<ParticleIndexData> (particle.h:228-240): sourceIndex per slot, filled by gridParticleIndex"""
+    _cname_py, _cname_cpp, _T = "ParticleIndexSystem", "ParticleIndexSystem", ""
+
+    def __init__(self, parent, name="", **kw):
+        PbClass.__init__(self, parent, name)
+        self.data = torch.zeros(0, dtype=torch.int32, device=parent.device)
+        self.np = 0
+
+    def size(self): return self.np
+    pySize = size
+
+    def to_numpy(self): return self.data[:self.np].detach().cpu().numpy().copy()
+
+
+class Mesh(PbClass):
+    """placeholder so that scenes which create a Mesh for the GUI keep running; meshes are outside the hot path"""
+    _cname_py, _cname_cpp, _T = "Mesh", "Mesh", ""
+
+    def __init__(self, parent, name="", **kw):
+        PbClass.__init__(self, parent, name)
 
 
 class BasicParticleSystem(PbClass):
@@ -602,6 +644,15 @@ class BasicParticleSystem(PbClass):
 
     def getPosPdata(self, target): target.data.copy_(self.pos)
     def setPosPdata(self, source): self.pos.copy_(source.data)
+
+    def projectOutOfBnd(self, flags, bnd, plane="xXyYzZ", ptype=None, exclude=0):
+        """ParticleSystem::projectOutOfBnd, particle.h:592-604"""
+        if self.np == 0:
+            return
+        axis = sum(1 << i for i, ch in enumerate("xXyYzZ") if ch in plane)
+        s = self.parent
+        s.lib.call("mf_project_out_of_bnd", flags.sx, flags.sy, flags.sz, self.np, self.cap, _ptr(self.pos), _ptr(self.flag),
+                   float(bnd), axis, None if ptype is None else ptype.ptr, int(exclude), s.stream)
 
     def addParticle(self, pos):
         p = _to_vec3(pos)

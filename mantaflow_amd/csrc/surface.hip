@@ -1,0 +1,434 @@
+// surface.hip -- the free-surface / particle-maintenance pieces that scenes/benchmark_dam.py runs between the FLIP
+// transfers (SURVEY 8f-2 leftovers and 8f-3): projectOutOfBnd, pushOutofObs, gridParticleIndex, unionParticleLevelset,
+// extrapolateLsSimple, setPartType, markIsolatedFluidCell, the three ptsplugins one-liners and the levelset set ops.
+// Reference: source/plugin/flip.cpp, plugin/ptsplugins.cpp, fastmarch.cpp, particle.h, grid.cpp, levelset.cpp.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+using namespace mf;
+
+static inline unsigned nblk_n(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK > 0 ? (n + BLOCK - 1) / BLOCK : 1); }
+__device__ __forceinline__ bool in_bounds(const Dim& d, int i, int j, int k) {
+	return i >= 0 && j >= 0 && k >= 0 && i < d.sx && j < d.sy && k < d.sz;
+}
+__device__ __forceinline__ int64_t cidx(const Dim& d, int i, int j, int k) { return (int64_t)i + d.Y * j + d.Z * k; }
+#define CELL_IJK(d)                                                               \
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;                \
+	if (idx >= (d).n) return;                                                     \
+	const int i = (int)(idx % (d).sx);                                            \
+	const int j = (int)((idx / (d).sx) % (d).sy);                                 \
+	const int k = (int)(idx / ((int64_t)(d).sx * (d).sy));                        \
+	(void)i; (void)j; (void)k;
+#define INTERIOR_B(d, b) (i >= (b) && i < (d).sx - (b) && j >= (b) && j < (d).sy - (b) && (!(d).is3d || (k >= (b) && k < (d).sz - (b))))
+
+// KnProjectOutOfBnd, particle.h:579-590 (std::max(pos, bnd) / std::min(pos, size - bnd))
+__global__ void __launch_bounds__(BLOCK)
+k_project_out_of_bnd(Dim d, int64_t np, int64_t ps, float* __restrict__ pos, const int32_t* __restrict__ pflag, float bnd, int axis,
+                     const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) return;
+	float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+	if (axis & 1) x = x > bnd ? x : bnd;
+	if (axis & 2) { const float hi = (float)d.sx - bnd; x = hi < x ? hi : x; }
+	if (axis & 4) y = y > bnd ? y : bnd;
+	if (axis & 8) { const float hi = (float)d.sy - bnd; y = hi < y ? hi : y; }
+	if (d.is3d) {
+		if (axis & 16) z = z > bnd ? z : bnd;
+		if (axis & 32) { const float hi = (float)d.sz - bnd; z = hi < z ? hi : z; }
+	}
+	pos[p] = x;
+	pos[ps + p] = y;
+	pos[2 * ps + p] = z;
+}
+
+// knPushOutofObs, plugin/flip.cpp:584-596; getGradient grid.h:556-573; normalize vectorbase.h:421-434
+__global__ void __launch_bounds__(BLOCK)
+k_push_out_of_obs(Dim d, int64_t np, int64_t ps, float* __restrict__ pos, const int32_t* __restrict__ pflag, const float* __restrict__ phi,
+                  float shift, float thresh, const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) return;
+	const float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+	int i = (int)x, j = (int)y, k = (int)z;
+	if (!in_bounds(d, i, j, k)) return;
+	const float v = interpol1(d, phi, x, y, z);
+	if (!(v < thresh)) return;
+	if (i > d.sx - 2) i = d.sx - 2;
+	if (j > d.sy - 2) j = d.sy - 2;
+	if (i < 1) i = 1;
+	if (j < 1) j = 1;
+	float gx = phi[cidx(d, i + 1, j, k)] - phi[cidx(d, i - 1, j, k)];
+	float gy = phi[cidx(d, i, j + 1, k)] - phi[cidx(d, i, j - 1, k)];
+	float gz = 0.f;
+	if (d.is3d) {
+		if (k > d.sz - 2) k = d.sz - 2;
+		if (k < 1) k = 1;
+		gz = phi[cidx(d, i, j, k + 1)] - phi[cidx(d, i, j, k - 1)];
+	}
+	const float l = gx * gx + gy * gy + gz * gz;
+	const float eps2 = 1e-6f * 1e-6f;
+	float nrm;
+	if (fabs((double)l - 1.) < (double)eps2) {
+		nrm = 1.f;
+	} else if (l > eps2) {
+		nrm = sqrtf(l);
+		const float fac = (float)(1. / (double)nrm);
+		gx *= fac;
+		gy *= fac;
+		gz *= fac;
+	} else {
+		gx = gy = gz = 0.f;
+		nrm = 0.f;
+	}
+	if (nrm < 1e-6f) return;
+	const float f = thresh - v + shift;
+	pos[p] = x + gx * f;
+	pos[ps + p] = y + gy * f;
+	pos[2 * ps + p] = z + gz * f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gridParticleIndex, plugin/flip.cpp:273-320.  The reference's serial counting sort orders indexSys by (cell, particle
+// index); here: per-cell histogram (integer atomics: exact), exclusive scan -> index, stable radix sort of
+// (cell key, particle index) pairs -> indexSys.  Skipped particles get the key n (sorted to the end).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK)
+k_gpi_keys(Dim d, int64_t np, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ pflag, int32_t* __restrict__ keys,
+           int32_t* __restrict__ vals, int32_t* __restrict__ counter) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	int key = (int)d.n;
+	if (!(pflag[p] & MF_PDELETE)) {
+		const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+		if (in_bounds(d, i, j, k)) {
+			key = (int)cidx(d, i, j, k);
+			atomicAdd(&counter[key], 1);
+		}
+	}
+	keys[p] = key;
+	vals[p] = (int)p;
+}
+struct SortScratch {
+	void* tmp = nullptr;
+	size_t cap = 0;
+};
+static SortScratch g_sort[16];
+static int sort_scratch(size_t need, void** out) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	SortScratch& s = g_sort[dev];
+	if (need > s.cap) {
+		MF_HIP(hipDeviceSynchronize());
+		if (s.tmp) MF_HIP(hipFree(s.tmp));
+		MF_HIP(hipMalloc(&s.tmp, need));
+		s.cap = need;
+	}
+	*out = s.tmp;
+	return 0;
+}
+
+// ComputeUnionLevelsetPindex, plugin/flip.cpp:322-353 (+ setBound(0.5, 0) fused: the boundary test of knSetBoundary with w=0)
+__global__ void __launch_bounds__(BLOCK)
+k_union_levelset(Dim d, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ isys, int64_t n_indexed,
+                 const int32_t* __restrict__ index, float* __restrict__ phi, float radius, const int32_t* __restrict__ ptype, int exclude) {
+	CELL_IJK(d)
+	const bool bnd = (i <= 0 || i >= d.sx - 1 || j <= 0 || j >= d.sy - 1 || (d.is3d && (k <= 0 || k >= d.sz - 1)));
+	if (bnd) {
+		phi[idx] = 0.5f;
+		return;
+	}
+	const float gx = (float)i + 0.5f, gy = (float)j + 0.5f, gz = (float)k + 0.5f;
+	float phiv = (float)((double)radius * 1.0);
+	const int r = (int)radius + 1, rZ = d.is3d ? r : 0;
+	const float eps2 = 1e-6f * 1e-6f;
+	for (int zj = k - rZ; zj <= k + rZ; zj++)
+		for (int yj = j - r; yj <= j + r; yj++)
+			for (int xj = i - r; xj <= i + r; xj++) {
+				if (!in_bounds(d, xj, yj, zj)) continue;
+				const int64_t c = cidx(d, xj, yj, zj);
+				const int64_t pStart = index[c];
+				const int64_t pEnd = (c + 1 < d.n) ? (int64_t)index[c + 1] : n_indexed;
+				for (int64_t q = pStart; q < pEnd; q++) {
+					const int psrc = isys[q];
+					if (ptype && (ptype[psrc] & exclude)) continue;
+					const float dx = gx - pos[psrc], dy = gy - pos[ps + psrc], dz = gz - pos[2 * ps + psrc];
+					const float l = dx * dx + dy * dy + dz * dz;
+					float nr;   // norm(), vectorbase.h:385-389
+					if (l <= eps2) nr = 0.f;
+					else nr = (fabs((double)l - 1.) < (double)eps2) ? 1.f : sqrtf(l);
+					const float cand = fabsf(nr) - radius;
+					phiv = cand < phiv ? cand : phiv;
+				}
+			}
+	phi[idx] = phiv;
+}
+
+// knSetBoundary, grid.cpp:629-633
+__global__ void __launch_bounds__(BLOCK) k_set_bound(Dim d, float* __restrict__ g, float value, int w) {
+	CELL_IJK(d)
+	const bool bnd = (i <= w || i >= d.sx - 1 - w || j <= w || j >= d.sy - 1 - w || (d.is3d && (k <= w || k >= d.sz - 1 - w)));
+	if (bnd) g[idx] = value;
+}
+
+// extrapolateLsSimple, fastmarch.cpp:472-522
+__global__ void __launch_bounds__(BLOCK) k_els_mark(Dim d, const float* __restrict__ phi, int32_t* __restrict__ tmp, int inside, int b) {
+	CELL_IJK(d)
+	int t = 0;
+	if (INTERIOR_B(d, b)) {
+		if (!inside) t = (phi[idx] < 0.) ? 1 : 0;
+		else t = (phi[idx] > 0.) ? 1 : 0;
+	}
+	tmp[idx] = t;
+}
+// first layer: the reference sweeps serially in place, but it only tests for the value 1 and only writes 2
+__global__ void __launch_bounds__(BLOCK) k_els_first(Dim d, int32_t* __restrict__ tmp) {
+	CELL_IJK(d)
+	if (!INTERIOR_B(d, 1)) return;
+	if (tmp[idx]) return;
+	bool hit = tmp[idx + 1] == 1 || tmp[idx - 1] == 1 || tmp[idx + d.Y] == 1 || tmp[idx - d.Y] == 1;
+	if (d.is3d) hit = hit || tmp[idx + d.Z] == 1 || tmp[idx - d.Z] == 1;
+	if (hit) tmp[idx] = 2;
+}
+// knExtrapolateLsSimple: cells written in pass dd get dd+1 and a new value; the pass only reads cells marked dd
+__global__ void __launch_bounds__(BLOCK) k_els_pass(Dim d, float* __restrict__ phi, int32_t* __restrict__ tmp, int dd, float direction) {
+	CELL_IJK(d)
+	if (!INTERIOR_B(d, 1)) return;
+	if (tmp[idx] != 0) return;
+	const int64_t nb[6] = {1, -1, d.Y, -d.Y, d.Z, -d.Z};
+	const int cnt = d.is3d ? 6 : 4;
+	int nbs = 0;
+	float avg = 0.f;
+	for (int n = 0; n < cnt; n++)
+		if (tmp[idx + nb[n]] == dd) {
+			avg += phi[idx + nb[n]];
+			nbs++;
+		}
+	if (nbs > 0) {
+		tmp[idx] = dd + 1;
+		phi[idx] = avg / nbs + direction;
+	}
+}
+__global__ void __launch_bounds__(BLOCK) k_els_rest(Dim d, float* __restrict__ phi, const int32_t* __restrict__ tmp, float value) {
+	CELL_IJK(d)
+	if (!INTERIOR_B(d, 1)) return;
+	if (tmp[idx] == 0) phi[idx] = value;
+}
+
+// KnSetPartType, ptsplugins.cpp:56-59
+__global__ void __launch_bounds__(BLOCK)
+k_set_part_type(Dim d, const int32_t* __restrict__ flags, int64_t np, int64_t ps, const float* __restrict__ pos, int32_t* __restrict__ ptype,
+                int mark, int stype, int cflag) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+	bool in = i >= 0 && j >= 0 && i < d.sx && j < d.sy;
+	in = in && (d.is3d ? (k >= 0 && k < d.sz) : (k == 0));
+	if (!in) return;
+	if ((flags[cidx(d, i, j, k)] & cflag) && (ptype[p] & stype)) ptype[p] = mark;
+}
+
+// knMarkIsolatedFluidCell, grid.cpp:987-1005.  In place like the reference: a cell that gets marked has no fluid
+// neighbour, so no other cell's decision depends on it.
+__global__ void __launch_bounds__(BLOCK) k_mark_isolated(Dim d, int32_t* __restrict__ flags, int mark) {
+	CELL_IJK(d)
+	if (!(flags[idx] & MF_FLUID)) return;
+	auto fl = [&](int64_t o) { return (idx + o >= 0 && idx + o < d.n) ? (flags[idx + o] & MF_FLUID) : 0; };
+	if (fl(-1) || fl(1) || fl(-d.Y) || fl(d.Y)) return;
+	if (d.is3d && (fl(-d.Z) || fl(d.Z))) return;
+	flags[idx] = mark;
+}
+
+// ptsplugins.cpp:20-53
+__global__ void __launch_bounds__(BLOCK)
+k_add_force_pvel(int64_t np, int64_t ps, float* __restrict__ v, float dx, float dy, float dz, const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if (ptype && (ptype[p] & exclude)) return;
+	v[p] += dx;
+	v[ps + p] += dy;
+	v[2 * ps + p] += dz;
+}
+__global__ void __launch_bounds__(BLOCK)
+k_vel_from_delta_pos(int64_t np, int64_t ps, const float* __restrict__ pos, float* __restrict__ v, const float* __restrict__ xp, float over_dt,
+                     const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if (ptype && (ptype[p] & exclude)) return;
+#pragma unroll
+	for (int c = 0; c < 3; c++) v[c * ps + p] = (pos[c * ps + p] - xp[c * ps + p]) * over_dt;
+}
+__global__ void __launch_bounds__(BLOCK)
+k_euler_step(int64_t np, int64_t ps, float* __restrict__ pos, const float* __restrict__ v, float dt, const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if (ptype && (ptype[p] & exclude)) return;
+#pragma unroll
+	for (int c = 0; c < 3; c++) pos[c * ps + p] += v[c * ps + p] * dt;
+}
+// KnJoin / KnSubtract, levelset.cpp:107-118
+__global__ void __launch_bounds__(BLOCK) k_ls_join(int64_t n, float* __restrict__ a, const float* __restrict__ b) {
+	const int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (i < n) a[i] = b[i] < a[i] ? b[i] : a[i];
+}
+__global__ void __launch_bounds__(BLOCK)
+k_ls_subtract(int64_t n, float* __restrict__ a, const float* __restrict__ b, const int32_t* __restrict__ flags, int stype) {
+	const int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (i >= n) return;
+	if (flags && (flags[i] & stype) == 0) return;
+	if (b[i] < 0.) a[i] = b[i] * -1.f;
+}
+
+extern "C" {
+
+int mf_project_out_of_bnd(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag, float bnd, int axis,
+                          const int32_t* ptype, int exclude, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (np <= 0) return 0;
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_project_out_of_bnd, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, d, np, pstride, pos, pflag, bnd, axis, ptype, exclude);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_push_out_of_obs(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag, const float* phiObs,
+                       float shift, float thresh, const int32_t* ptype, int exclude, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (np <= 0) return 0;
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_push_out_of_obs, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, d, np, pstride, pos, pflag, phiObs, shift, thresh, ptype, exclude);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_grid_particle_index(int sx, int sy, int sz, int64_t np, int64_t pstride, const float* pos, const int32_t* pflag,
+                           int32_t* indexSys, int32_t* index, int32_t* counter, int32_t* keys, int32_t* vals,
+                           int64_t* n_indexed_host, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (np >= ((int64_t)1 << 31)) return fail("gridParticleIndex: too many particles for 32-bit slots");
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	MF_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t) * d.n, st));
+	if (np > 0) {
+		hipLaunchKernelGGL(k_gpi_keys, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, np, pstride, pos, pflag, keys, vals, counter);
+		MF_LAUNCH_CHECK();
+	}
+	// index = exclusive prefix sum of the per-cell counts
+	size_t scan_bytes = 0, sort_bytes = 0;
+	MF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, counter, index, (int)d.n, st));
+	int end_bit = 1;
+	while (end_bit < 31 && (((int64_t)1 << end_bit) <= d.n)) end_bit++;
+	if (np > 0) MF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys + np, vals, vals + np, (int)np, 0, end_bit, st));
+	void* tmp = nullptr;
+	MF_TRY(sort_scratch((scan_bytes > sort_bytes ? scan_bytes : sort_bytes) + 256, &tmp));
+	MF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, scan_bytes, counter, index, (int)d.n, st));
+	if (np > 0) {
+		MF_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, keys, keys + np, vals, vals + np, (int)np, 0, end_bit, st));
+		// the skipped particles (key n) sort to the tail; indexSys takes the whole array, only [0, n_indexed) is meaningful
+		MF_HIP(hipMemcpyAsync(indexSys, vals + np, sizeof(int32_t) * np, hipMemcpyDeviceToDevice, st));
+	}
+	if (n_indexed_host) {
+		int32_t last_idx = 0, last_cnt = 0;
+		MF_HIP(hipMemcpyAsync(&last_idx, index + d.n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipMemcpyAsync(&last_cnt, counter + d.n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipStreamSynchronize(st));
+		*n_indexed_host = (int64_t)last_idx + last_cnt;
+	}
+	return 0;
+}
+
+int mf_union_particle_levelset(int sx, int sy, int sz, int64_t np, int64_t pstride, const float* pos, const int32_t* indexSys,
+                               int64_t n_indexed, const int32_t* index, float* phi, float radiusFactor, const int32_t* ptype,
+                               int exclude, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	(void)np;
+	const Dim d = mkdim(sx, sy, sz);
+	// calculateRadiusFactor (flip.cpp:198-200) in double, returned as Real; radius = 0.5 * that, rounded to Real
+	const float rf = (float)((d.is3d ? sqrt(3.) : sqrt(2.)) * ((double)radiusFactor + .01));
+	const float radius = (float)(0.5 * (double)rf);
+	hipLaunchKernelGGL(k_union_levelset, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, pstride, pos, indexSys, n_indexed, index, phi, radius, ptype, exclude);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boundaryWidth, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_set_bound, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, grid, value, boundaryWidth);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_extrapolate_ls_simple(int sx, int sy, int sz, float* phi, int distance, int inside, int include_walls, int32_t* tmp,
+                             void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	const unsigned nb = nblk_n(d.n);
+	const float direction = inside ? -1.f : 1.f;
+	hipLaunchKernelGGL(k_els_mark, dim3(nb), dim3(BLOCK), 0, st, d, phi, tmp, inside, (inside && include_walls) ? 0 : 1);
+	hipLaunchKernelGGL(k_els_first, dim3(nb), dim3(BLOCK), 0, st, d, tmp);
+	for (int dd = 2; dd < 1 + distance; dd++) hipLaunchKernelGGL(k_els_pass, dim3(nb), dim3(BLOCK), 0, st, d, phi, tmp, dd, direction);
+	hipLaunchKernelGGL(k_els_rest, dim3(nb), dim3(BLOCK), 0, st, d, phi, tmp, (float)(direction * (distance + 2)));
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_set_part_type(int sx, int sy, int sz, const int32_t* flags, int64_t np, int64_t pstride, const float* pos, int32_t* ptype,
+                     int mark, int stype, int cflag, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (np <= 0) return 0;
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_set_part_type, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, np, pstride, pos, ptype, mark, stype, cflag);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_mark_isolated_fluid_cell(int sx, int sy, int sz, int32_t* flags, int mark, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_mark_isolated, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, mark);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_add_force_pvel(int64_t np, int64_t pstride, float* pvel, float ax, float ay, float az, float dt, const int32_t* ptype,
+                      int exclude, void* stream) {
+	if (np <= 0) return 0;
+	const float dx = ax * dt, dy = ay * dt, dz = az * dt;
+	hipLaunchKernelGGL(k_add_force_pvel, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, np, pstride, pvel, dx, dy, dz, ptype, exclude);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_update_velocity_from_delta_pos(int64_t np, int64_t pstride, const float* pos, float* pvel, const float* xprev, float dt,
+                                      const int32_t* ptype, int exclude, void* stream) {
+	if (np <= 0) return 0;
+	const float over_dt = (float)(1.0 / (double)dt);
+	hipLaunchKernelGGL(k_vel_from_delta_pos, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, np, pstride, pos, pvel, xprev, over_dt, ptype, exclude);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_euler_step(int64_t np, int64_t pstride, float* pos, const float* pvel, float dt, const int32_t* ptype, int exclude,
+                  void* stream) {
+	if (np <= 0) return 0;
+	hipLaunchKernelGGL(k_euler_step, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, np, pstride, pos, pvel, dt, ptype, exclude);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_levelset_join(int64_t n, float* phi, const float* other, void* stream) {
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_ls_join, dim3(nblk_n(n)), dim3(BLOCK), 0, (hipStream_t)stream, n, phi, other);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_t* flags, int subtractType, void* stream) {
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_ls_subtract, dim3(nblk_n(n)), dim3(BLOCK), 0, (hipStream_t)stream, n, phi, other, flags, subtractType);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+}  // extern "C"

@@ -369,6 +369,98 @@ def markFluidCells(parts, flags, phiObs=None, ptype=None, exclude=0):
                None if phiObs is None else phiObs.ptr, None if ftmp is None else ftmp.ptr, s.stream)
 
 
+@plugin
+def pushOutofObs(parts, flags, phiObs, shift=0, thresh=0, ptype=None, exclude=0):
+    """flip.cpp:584-602"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(phiObs, Grid, "Grid<Real>")
+    s = flags.parent
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_push_out_of_obs", flags.sx, flags.sy, flags.sz, np_, cap, pos, pfl, phiObs.ptr, float(shift), float(thresh),
+               pt, int(exclude), s.stream)
+
+
+# =========================================================================================================
+# free-surface pieces of scenes/benchmark_dam.py (SURVEY 8f-3)
+# =========================================================================================================
+@plugin
+def gridParticleIndex(parts, indexSys, flags, index, counter=None):
+    """flip.cpp:273-320: index = first slot per cell, indexSys = particle indices ordered by (cell, particle)"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(index, core.IntGrid, "Grid<int>")
+    s = flags.parent
+    cnt = counter if counter is not None else core.IntGrid(s)
+    np_ = parts.np
+    if indexSys.data.numel() < max(np_, 1):
+        indexSys.data = torch.zeros(max(parts.cap, np_, 1), dtype=torch.int32, device=s.device)
+    keys = torch.empty(2 * max(np_, 1), dtype=torch.int32, device=s.device)
+    vals = torch.empty(2 * max(np_, 1), dtype=torch.int32, device=s.device)
+    n_idx = ctypes.c_int64(0)
+    s.lib.call("mf_grid_particle_index", flags.sx, flags.sy, flags.sz, np_, parts.cap, _ptr(parts.pos), _ptr(parts.flag),
+               _ptr(indexSys.data), index.ptr, cnt.ptr, _ptr(keys), _ptr(vals), ctypes.byref(n_idx), s.stream)
+    indexSys.np = int(n_idx.value)
+
+
+@plugin
+def unionParticleLevelset(parts, indexSys, flags, index, phi, radiusFactor=1., ptype=None, exclude=0):
+    """flip.cpp:322-363"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(phi, Grid, "LevelsetGrid")
+    s = flags.parent
+    s.lib.call("mf_union_particle_levelset", flags.sx, flags.sy, flags.sz, parts.np, parts.cap, _ptr(parts.pos),
+               _ptr(indexSys.data), int(indexSys.np), index.ptr, phi.ptr, float(radiusFactor),
+               None if ptype is None else ptype.ptr, int(exclude), s.stream)
+
+
+@plugin
+def extrapolateLsSimple(phi, distance=4, inside=False, include_walls=False):
+    """fastmarch.cpp:472-522"""
+    _chk(phi, Grid, "Grid<Real>")
+    s = phi.parent
+    tmp = core.IntGrid(s)
+    s.lib.call("mf_extrapolate_ls_simple", phi.sx, phi.sy, phi.sz, phi.ptr, int(distance), int(bool(inside)),
+               int(bool(include_walls)), tmp.ptr, s.stream)
+
+
+@plugin
+def setPartType(parts, ptype, mark, stype, flags, cflag):
+    """ptsplugins.cpp:56-65"""
+    _chk(flags, FlagGrid, "FlagGrid")
+    s = flags.parent
+    s.lib.call("mf_set_part_type", flags.sx, flags.sy, flags.sz, flags.ptr, parts.np, parts.cap, _ptr(parts.pos), ptype.ptr,
+               int(mark), int(stype), int(cflag), s.stream)
+
+
+@plugin
+def markIsolatedFluidCell(flags, mark):
+    """grid.cpp:987-1011"""
+    _chk(flags, FlagGrid, "FlagGrid")
+    s = flags.parent
+    s.lib.call("mf_mark_isolated_fluid_cell", flags.sx, flags.sy, flags.sz, flags.ptr, int(mark), s.stream)
+
+
+@plugin
+def addForcePvel(vel, a, dt, ptype, exclude):
+    """ptsplugins.cpp:20-29"""
+    a = core._to_vec3(a)
+    s = vel.parent
+    s.lib.call("mf_add_force_pvel", vel.size(), vel.cap, vel.ptr, float(a.x), float(a.y), float(a.z), float(dt),
+               None if ptype is None else ptype.ptr, int(exclude), s.stream)
+
+
+@plugin
+def updateVelocityFromDeltaPos(parts, vel, x_prev, dt, ptype, exclude):
+    """ptsplugins.cpp:31-41"""
+    s = vel.parent
+    s.lib.call("mf_update_velocity_from_delta_pos", parts.np, parts.cap, _ptr(parts.pos), vel.ptr, x_prev.ptr, float(dt),
+               None if ptype is None else ptype.ptr, int(exclude), s.stream)
+
+
+@plugin
+def eulerStep(parts, vel, ptype, exclude):
+    """ptsplugins.cpp:43-53"""
+    s = vel.parent
+    s.lib.call("mf_euler_step", parts.np, parts.cap, _ptr(parts.pos), vel.ptr, s.getDt(), None if ptype is None else ptype.ptr,
+               int(exclude), s.stream)
+
+
 # =========================================================================================================
 # glue (SURVEY 8f-1)
 # =========================================================================================================

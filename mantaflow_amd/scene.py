@@ -251,6 +251,49 @@ def sampleFlagsWithParticles(flags, parts, discretization, randomness):
 
 
 @plugin
+def sampleShapeWithParticles(shape, flags, parts, discretization, randomness, reset=False, refillEmpty=False, exclude=None):
+    """plugin/flip.cpp:109-140: every non-obstacle cell is visited (and draws its random numbers), sub-positions inside
+    the shape are kept"""
+    _chk(flags, FlagGrid, "FlagGrid")
+    if exclude is not None:
+        raise RuntimeError("sampleShapeWithParticles: the exclude levelset is outside the hot path")
+    s = flags.parent
+    if reset:
+        parts.clear()
+    f = flags.to_numpy()
+    m = (f & core.TypeObstacle) == 0
+    if refillEmpty:
+        m &= (f & core.TypeFluid) == 0
+    kk, jj, ii = np.nonzero(m)
+    cells = np.stack([ii, jj, kk], axis=1)
+    pos = _sample_cells(s, cells, discretization, randomness, RandomStream(9832))
+    if pos.shape[0]:
+        pos = pos[shape._inside(pos[:, 0], pos[:, 1], pos[:, 2])]
+    old = parts.get_positions() if parts.np else np.zeros((0, 3), f32)
+    oldf = parts.get_flags() if parts.np else np.zeros(0, np.int32)
+    parts.set_positions(np.concatenate([old, pos]), np.concatenate([oldf, np.full(pos.shape[0], core.PNEW, np.int32)]))
+
+
+class Gui(object):
+    """no-op stand-in for the Qt GUI (gui/*): scenes that open a window when `guion` is set keep running headless"""
+    def __init__(self, *a, **kw): pass
+    def show(self, *a, **kw): pass
+    def pause(self, *a, **kw): pass
+    def update(self, *a, **kw): pass
+    def screenshot(self, *a, **kw): pass
+    def setBackgroundMesh(self, *a, **kw): pass
+    def setCamPos(self, *a, **kw): pass
+    def setCamRot(self, *a, **kw): pass
+    def nextRealGrid(self, *a, **kw): pass
+    def nextVec3Grid(self, *a, **kw): pass
+    def nextMeshDisplay(self, *a, **kw): pass
+    def nextPartDisplay(self, *a, **kw): pass
+    def nextParts(self, *a, **kw): pass
+    def toggleHideGrids(self, *a, **kw): pass
+    def windowSize(self, *a, **kw): pass
+
+
+@plugin
 def sampleLevelsetWithParticles(phi, flags, parts, discretization, randomness, reset=False, refillEmpty=False, particleFlag=-1):
     """plugin/flip.cpp:64-110"""
     s = flags.parent

@@ -1713,6 +1713,311 @@ int mf_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int6
 	return 0;
 }
 
+/* KnProjectOutOfBnd, particle.h:579-590 */
+int mf_project_out_of_bnd(int sx, int sy, int sz, int64_t np, int64_t ps, float* pos, const int32_t* pflag, float bnd,
+                          int axis, const int32_t* ptype, int exclude, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int64_t p = 0; p < np; p++) {
+		if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) continue;
+		float* x = pos + p;
+		float* y = pos + ps + p;
+		float* z = pos + 2 * ps + p;
+		if (axis & 1) *x = *x > bnd ? *x : bnd;                           /* std::max(pos.x, bnd) */
+		if (axis & 2) { float hi = (float)sx - bnd; *x = hi < *x ? hi : *x; } /* std::min(pos.x, X - bnd) */
+		if (axis & 4) *y = *y > bnd ? *y : bnd;
+		if (axis & 8) { float hi = (float)sy - bnd; *y = hi < *y ? hi : *y; }
+		if (d.is3d) {
+			if (axis & 16) *z = *z > bnd ? *z : bnd;
+			if (axis & 32) { float hi = (float)sz - bnd; *z = hi < *z ? hi : *z; }
+		}
+	}
+	return 0;
+}
+
+/* getGradient, grid.h:556-573 */
+static void get_gradient(const Dim* d, const float* data, int i, int j, int k, float g[3]) {
+	if (i > d->sx - 2) i = d->sx - 2;
+	if (j > d->sy - 2) j = d->sy - 2;
+	if (i < 1) i = 1;
+	if (j < 1) j = 1;
+	g[0] = data[IDX(*d, i + 1, j, k)] - data[IDX(*d, i - 1, j, k)];
+	g[1] = data[IDX(*d, i, j + 1, k)] - data[IDX(*d, i, j - 1, k)];
+	g[2] = 0.f;
+	if (d->is3d) {
+		if (k > d->sz - 2) k = d->sz - 2;
+		if (k < 1) k = 1;
+		g[2] = data[IDX(*d, i, j, k + 1)] - data[IDX(*d, i, j, k - 1)];
+	}
+}
+/* normalize(Vector3D<float>&), vectorbase.h:421-434: returns the norm */
+static float normalize3(float v[3]) {
+	float l = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+	const float eps2 = 1e-6f * 1e-6f;
+	float nrm;
+	if (fabs((double)l - 1.) < eps2) {
+		nrm = 1.f;
+	} else if (l > eps2) {
+		nrm = sqrtf(l);
+		float fac = (float)(1. / (double)nrm);
+		v[0] *= fac;
+		v[1] *= fac;
+		v[2] *= fac;
+	} else {
+		v[0] = v[1] = v[2] = 0.f;
+		nrm = 0.f;
+	}
+	return nrm;
+}
+/* knPushOutofObs, plugin/flip.cpp:584-596 */
+int mf_push_out_of_obs(int sx, int sy, int sz, int64_t np, int64_t ps, float* pos, const int32_t* pflag, const float* phiObs,
+                       float shift, float thresh, const int32_t* ptype, int exclude, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int64_t p = 0; p < np; p++) {
+		if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) continue;
+		float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+		int i = (int)x, j = (int)y, k = (int)z;
+		if (!in_bounds(&d, i, j, k)) continue;
+		float v = interpol1(&d, phiObs, x, y, z);
+		if (v < thresh) {
+			float g[3];
+			get_gradient(&d, phiObs, i, j, k, g);
+			if (normalize3(g) < 1e-6f) continue;
+			float f = thresh - v + shift;
+			pos[p] = x + g[0] * f;
+			pos[ps + p] = y + g[1] * f;
+			pos[2 * ps + p] = z + g[2] * f;
+		}
+	}
+	return 0;
+}
+
+/* gridParticleIndex, plugin/flip.cpp:273-320 */
+int mf_grid_particle_index(int sx, int sy, int sz, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
+                           int32_t* indexSys, int32_t* index, int32_t* counter, int32_t* keys, int32_t* vals,
+                           int64_t* n_indexed_host, void* st) {
+	(void)st;
+	(void)keys;
+	(void)vals;
+	Dim d = mkdim(sx, sy, sz);
+	memset(counter, 0, sizeof(int32_t) * d.n);
+	memset(index, 0, sizeof(int32_t) * d.n);
+	int64_t inactive = 0;
+	for (int64_t p = 0; p < np; p++) {
+		if (pflag[p] & MF_PDELETE) { inactive++; continue; }
+		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+		if (!in_bounds(&d, i, j, k)) { inactive++; continue; }
+		index[IDX(d, i, j, k)]++;
+	}
+	int64_t run = 0;
+	for (int64_t c = 0; c < d.n; c++) {
+		int num = index[c];
+		index[c] = (int32_t)run;
+		run += num;
+	}
+	for (int64_t p = 0; p < np; p++) {
+		if (pflag[p] & MF_PDELETE) continue;
+		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+		if (!in_bounds(&d, i, j, k)) continue;
+		int64_t c = IDX(d, i, j, k);
+		indexSys[index[c] + counter[c]] = (int32_t)p;
+		counter[c]++;
+	}
+	if (n_indexed_host) *n_indexed_host = np - inactive;
+	return 0;
+}
+
+/* ComputeUnionLevelsetPindex + setBound(0.5, 0), plugin/flip.cpp:322-363 */
+int mf_union_particle_levelset(int sx, int sy, int sz, int64_t np, int64_t ps, const float* pos, const int32_t* indexSys,
+                               int64_t n_indexed, const int32_t* index, float* phi, float radiusFactor, const int32_t* ptype,
+                               int exclude, void* st) {
+	(void)st;
+	(void)np;
+	Dim d = mkdim(sx, sy, sz);
+	/* calculateRadiusFactor, flip.cpp:198-200 (double arithmetic, returned as Real), then 0.5 * it */
+	const float rf = (float)((d.is3d ? sqrt(3.) : sqrt(2.)) * ((double)radiusFactor + .01));
+	const float radius = (float)(0.5 * (double)rf);
+	const int r = (int)radius + 1, rZ = d.is3d ? r : 0;
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				const float gx = (float)i + 0.5f, gy = (float)j + 0.5f, gz = (float)k + 0.5f;
+				float phiv = (float)((double)radius * 1.0);
+				for (int zj = k - rZ; zj <= k + rZ; zj++)
+					for (int yj = j - r; yj <= j + r; yj++)
+						for (int xj = i - r; xj <= i + r; xj++) {
+							if (!in_bounds(&d, xj, yj, zj)) continue;
+							const int64_t c = IDX(d, xj, yj, zj);
+							const int64_t pStart = index[c];
+							const int64_t pEnd = (c + 1 < d.n) ? index[c + 1] : n_indexed;
+							for (int64_t q = pStart; q < pEnd; q++) {
+								const int psrc = indexSys[q];
+								if (ptype && (ptype[psrc] & exclude)) continue;
+								const float dx = gx - pos[psrc], dy = gy - pos[ps + psrc], dz = gz - pos[2 * ps + psrc];
+								/* norm(), vectorbase.h:385-389 */
+								const float l = dx * dx + dy * dy + dz * dz;
+								const float eps2 = 1e-6f * 1e-6f;
+								float nr;
+								if (l <= eps2) nr = 0.f;
+								else nr = (fabs((double)l - 1.) < eps2) ? 1.f : sqrtf(l);
+								const float cand = fabsf(nr) - radius;
+								phiv = cand < phiv ? cand : phiv;   /* std::min(phiv, cand) */
+							}
+						}
+				phi[IDX(d, i, j, k)] = phiv;
+			}
+	return mf_grid_set_bound(sx, sy, sz, phi, 0.5f, 0, st);
+}
+
+/* knSetBoundary, grid.cpp:629-637 */
+int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int w, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				int bnd = (i <= w || i >= sx - 1 - w || j <= w || j >= sy - 1 - w || (d.is3d && (k <= w || k >= sz - 1 - w)));
+				if (bnd) grid[IDX(d, i, j, k)] = value;
+			}
+	return 0;
+}
+
+/* extrapolateLsSimple, fastmarch.cpp:432-522 */
+int mf_extrapolate_ls_simple(int sx, int sy, int sz, float* phi, int distance, int inside, int include_walls, int32_t* tmp,
+                             void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int dim = d.is3d ? 3 : 2;
+	const int64_t nb[6] = {1, -1, d.Y, -d.Y, d.Z, -d.Z};
+	memset(tmp, 0, sizeof(int32_t) * d.n);
+	float direction = 1.f;
+	if (!inside) {
+		for (int k = K0(d, 1); k < K1(d, 1); k++)
+			for (int j = 1; j < sy - 1; j++)
+				for (int i = 1; i < sx - 1; i++)
+					if (phi[IDX(d, i, j, k)] < 0.) tmp[IDX(d, i, j, k)] = 1;
+	} else {
+		direction = -1.f;
+		const int b = include_walls ? 0 : 1;
+		for (int k = K0(d, b); k < K1(d, b); k++)
+			for (int j = b; j < sy - b; j++)
+				for (int i = b; i < sx - b; i++)
+					if (phi[IDX(d, i, j, k)] > 0.) tmp[IDX(d, i, j, k)] = 1;
+	}
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				const int64_t idx = IDX(d, i, j, k);
+				if (tmp[idx]) continue;
+				for (int n = 0; n < 2 * dim; n++)
+					if (tmp[idx + nb[n]] == 1) { tmp[idx] = 2; break; }
+			}
+	for (int dd = 2; dd < 1 + distance; dd++) {
+		/* knExtrapolateLsSimple: cells written in this pass get dd+1, which no cell of this pass reads */
+		for (int k = K0(d, 1); k < K1(d, 1); k++)
+			for (int j = 1; j < sy - 1; j++)
+				for (int i = 1; i < sx - 1; i++) {
+					const int64_t idx = IDX(d, i, j, k);
+					if (tmp[idx] != 0) continue;
+					int nbs = 0;
+					float avg = 0.f;
+					for (int n = 0; n < 2 * dim; n++)
+						if (tmp[idx + nb[n]] == dd) {
+							avg += phi[idx + nb[n]];
+							nbs++;
+						}
+					if (nbs > 0) {
+						tmp[idx] = dd + 1;
+						phi[idx] = avg / nbs + direction;
+					}
+				}
+	}
+	const float rest = (float)(direction * (distance + 2));
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++)
+				if (tmp[IDX(d, i, j, k)] == 0) phi[IDX(d, i, j, k)] = rest;
+	return 0;
+}
+
+/* KnSetPartType, plugin/ptsplugins.cpp:56-59 */
+int mf_set_part_type(int sx, int sy, int sz, const int32_t* flags, int64_t np, int64_t ps, const float* pos, int32_t* ptype,
+                     int mark, int stype, int cflag, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int64_t p = 0; p < np; p++) {
+		const float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+		if (in_bounds_pos(&d, x, y, z, 0) && (flag_at(&d, flags, x, y, z) & cflag) && (ptype[p] & stype)) ptype[p] = mark;
+	}
+	return 0;
+}
+
+/* knMarkIsolatedFluidCell, grid.cpp:987-1005 */
+int mf_mark_isolated_fluid_cell(int sx, int sy, int sz, int32_t* flags, int mark, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int64_t idx = 0; idx < d.n; idx++) {
+		if (!(flags[idx] & MF_FLUID)) continue;
+		/* the reference indexes idx+-stride without a bounds check; border cells are never fluid in practice, the
+		 * restatement simply treats out-of-array neighbours as non-fluid */
+#define FL(o) ((idx + (o) >= 0 && idx + (o) < d.n) ? (flags[idx + (o)] & MF_FLUID) : 0)
+		if (FL(-1) || FL(1) || FL(-d.Y) || FL(d.Y)) continue;
+		if (d.is3d && (FL(-d.Z) || FL(d.Z))) continue;
+#undef FL
+		flags[idx] = mark;
+	}
+	return 0;
+}
+
+/* KnAddForcePvel, ptsplugins.cpp:20-29: da = a*dt (fp32 Vec3 * Real) */
+int mf_add_force_pvel(int64_t np, int64_t ps, float* pvel, float ax, float ay, float az, float dt, const int32_t* ptype,
+                      int exclude, void* st) {
+	(void)st;
+	const float dx = ax * dt, dy = ay * dt, dz = az * dt;
+	for (int64_t p = 0; p < np; p++) {
+		if (ptype && (ptype[p] & exclude)) continue;
+		pvel[p] += dx;
+		pvel[ps + p] += dy;
+		pvel[2 * ps + p] += dz;
+	}
+	return 0;
+}
+/* KnUpdateVelocityFromDeltaPos, ptsplugins.cpp:31-41: over_dt = 1.0/dt evaluated in double */
+int mf_update_velocity_from_delta_pos(int64_t np, int64_t ps, const float* pos, float* pvel, const float* xprev, float dt,
+                                      const int32_t* ptype, int exclude, void* st) {
+	(void)st;
+	const float over_dt = (float)(1.0 / (double)dt);
+	for (int64_t p = 0; p < np; p++) {
+		if (ptype && (ptype[p] & exclude)) continue;
+		for (int c = 0; c < 3; c++) pvel[c * ps + p] = (pos[c * ps + p] - xprev[c * ps + p]) * over_dt;
+	}
+	return 0;
+}
+/* KnStepEuler, ptsplugins.cpp:43-53 */
+int mf_euler_step(int64_t np, int64_t ps, float* pos, const float* pvel, float dt, const int32_t* ptype, int exclude, void* st) {
+	(void)st;
+	for (int64_t p = 0; p < np; p++) {
+		if (ptype && (ptype[p] & exclude)) continue;
+		for (int c = 0; c < 3; c++) pos[c * ps + p] += pvel[c * ps + p] * dt;
+	}
+	return 0;
+}
+/* KnJoin / KnSubtract, levelset.cpp:107-118 */
+int mf_levelset_join(int64_t n, float* phi, const float* other, void* st) {
+	(void)st;
+	for (int64_t i = 0; i < n; i++) phi[i] = other[i] < phi[i] ? other[i] : phi[i];   /* min(a, b) = (b < a) ? b : a */
+	return 0;
+}
+int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_t* flags, int subtractType, void* st) {
+	(void)st;
+	for (int64_t i = 0; i < n; i++) {
+		if (flags && (flags[i] & subtractType) == 0) continue;
+		if (other[i] < 0.) phi[i] = other[i] * -1.f;
+	}
+	return 0;
+}
+
 int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
                          const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* st) {
 	(void)sx; (void)sy; (void)sz; (void)flags; (void)dst; (void)src; (void)A0; (void)Ai; (void)Aj; (void)Ak; (void)reps;

@@ -71,6 +71,24 @@ void markFluidCells(const BasicParticleSystem& parts, FlagGrid& flags, const Gri
                     const ParticleDataImpl<int>* ptype, const int exclude);                              // flip.cpp:166
 void sampleFlagsWithParticles(const FlagGrid& flags, BasicParticleSystem& parts, const int discretization,
                               const Real randomness);                                                   // flip.cpp:33
+void pushOutofObs(BasicParticleSystem& parts, const FlagGrid& flags, const Grid<Real>& phiObs, const Real shift,
+                  const Real thresh, const ParticleDataImpl<int>* ptype, const int exclude);               // flip.cpp:598
+void gridParticleIndex(const BasicParticleSystem& parts, ParticleIndexSystem& indexSys, const FlagGrid& flags,
+                       Grid<int>& index, Grid<int>* counter);                                             // flip.cpp:273
+void unionParticleLevelset(const BasicParticleSystem& parts, const ParticleIndexSystem& indexSys, const FlagGrid& flags,
+                           const Grid<int>& index, LevelsetGrid& phi, const Real radiusFactor,
+                           const ParticleDataImpl<int>* ptype, const int exclude);                        // flip.cpp:356
+void extrapolateLsSimple(Grid<Real>& phi, int distance, bool inside, bool include_walls);                 // fastmarch.cpp:472
+void setPartType(const BasicParticleSystem& parts, ParticleDataImpl<int>& ptype, const int mark, const int stype,
+                 const FlagGrid& flags, const int cflag);                                                 // ptsplugins.cpp:62
+void markIsolatedFluidCell(FlagGrid& flags, const int mark);                                              // grid.cpp:1008
+void addForcePvel(ParticleDataImpl<Vec3>& vel, const Vec3& a, const Real dt, const ParticleDataImpl<int>* ptype,
+                  const int exclude);                                                                     // ptsplugins.cpp:26
+void updateVelocityFromDeltaPos(const BasicParticleSystem& parts, ParticleDataImpl<Vec3>& vel,
+                                const ParticleDataImpl<Vec3>& x_prev, const Real dt, const ParticleDataImpl<int>* ptype,
+                                const int exclude);                                                       // ptsplugins.cpp:38
+void eulerStep(BasicParticleSystem& parts, const ParticleDataImpl<Vec3>& vel, const ParticleDataImpl<int>* ptype,
+               const int exclude);                                                                        // ptsplugins.cpp:50
 }  // namespace Manta
 
 using namespace Manta;
@@ -539,6 +557,172 @@ int ref_sample_flags_with_particles(int sx, int sy, int sz, const int32_t* flags
 		pos[cap + i] = sys[i].pos.y;
 		pos[2 * cap + i] = sys[i].pos.z;
 	}
+	SHIM_CATCH
+}
+
+struct PtypeIO {   // optional int pdata filled from / written back to a caller array
+	std::unique_ptr<Pdata<int> > pt;
+	int32_t* src;
+	int64_t np;
+	PtypeIO(Ctx& c, Parts& P, const int32_t* ptype) : src(const_cast<int32_t*>(ptype)), np(P.np) {
+		if (ptype) {
+			pt.reset(new Pdata<int>(c, P));
+			for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+		}
+	}
+	ParticleDataImpl<int>* ptr() { return pt ? &pt->pd : nullptr; }
+	void store() {
+		if (pt)
+			for (int64_t i = 0; i < np; i++) src[i] = pt->pd[i];
+	}
+};
+/* ParticleSystem::projectOutOfBnd, particle.h:592-604 */
+int ref_project_out_of_bnd(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag,
+                           float bnd, const char* plane, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	std::vector<int> fdata(c.n, 0);
+	FlagGrid fl(&c.solver, fdata.data());
+	Parts P(c, np, pstride, pos, pflag);
+	PtypeIO pt(c, P, ptype);
+	P.sys.projectOutOfBnd(fl, bnd, std::string(plane), pt.ptr(), exclude);
+	P.store();
+	SHIM_CATCH
+}
+/* pushOutofObs, flip.cpp:584-602 */
+int ref_push_out_of_obs(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag,
+                        const float* phiObs, float shift, float thresh, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	std::vector<int> fdata(c.n, 0);
+	FlagGrid fl(&c.solver, fdata.data());
+	RealRef ph(c, phiObs);
+	Parts P(c, np, pstride, pos, pflag);
+	PtypeIO pt(c, P, ptype);
+	pushOutofObs(P.sys, fl, ph.ref(), shift, thresh, pt.ptr(), exclude);
+	P.store();
+	SHIM_CATCH
+}
+/* gridParticleIndex, flip.cpp:273-320: indexSys (capacity np) receives sourceIndex, *n_indexed its size */
+int ref_grid_particle_index(int sx, int sy, int sz, int64_t np, int64_t pstride, const float* pos, const int32_t* pflag,
+                            int32_t* indexSys, int32_t* index, int64_t* n_indexed) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	std::vector<int> fdata(c.n, 0);
+	FlagGrid fl(&c.solver, fdata.data());
+	Grid<int> idx(&c.solver, index);
+	Parts P(c, np, pstride, pos, pflag);
+	ParticleIndexSystem isys(&c.solver);
+	gridParticleIndex(P.sys, isys, fl, idx, nullptr);
+	*n_indexed = isys.size();
+	for (int64_t i = 0; i < isys.size(); i++) indexSys[i] = isys[i].sourceIndex;
+	SHIM_CATCH
+}
+/* gridParticleIndex + unionParticleLevelset, flip.cpp:322-363 (the index system is rebuilt here with the reference's own
+ * gridParticleIndex so that the call takes plain arrays) */
+int ref_union_particle_levelset(int sx, int sy, int sz, int64_t np, int64_t pstride, const float* pos, const int32_t* pflag,
+                                float* phi, float radiusFactor, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	std::vector<int> fdata(c.n, 0);
+	FlagGrid fl(&c.solver, fdata.data());
+	Grid<int> idx(&c.solver);
+	Parts P(c, np, pstride, pos, pflag);
+	PtypeIO pt(c, P, ptype);
+	ParticleIndexSystem isys(&c.solver);
+	gridParticleIndex(P.sys, isys, fl, idx, nullptr);
+	LevelRef ph(c, phi);
+	unionParticleLevelset(P.sys, isys, fl, idx, *ph.g, radiusFactor, pt.ptr(), exclude);
+	SHIM_CATCH
+}
+/* extrapolateLsSimple, fastmarch.cpp:472-522 */
+int ref_extrapolate_ls_simple(int sx, int sy, int sz, float* phi, int distance, int inside, int include_walls) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	RealRef ph(c, phi);
+	extrapolateLsSimple(ph.ref(), distance, inside != 0, include_walls != 0);
+	SHIM_CATCH
+}
+/* setPartType, ptsplugins.cpp:56-65 */
+int ref_set_part_type(int sx, int sy, int sz, const int32_t* flags, int64_t np, int64_t pstride, const float* pos,
+                      int32_t* ptype, int mark, int stype, int cflag) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	Parts P(c, np, pstride, pos, nullptr);
+	PtypeIO pt(c, P, ptype);
+	setPartType(P.sys, *pt.ptr(), mark, stype, fl, cflag);
+	pt.store();
+	SHIM_CATCH
+}
+/* markIsolatedFluidCell, grid.cpp:987-1011 */
+int ref_mark_isolated_fluid_cell(int sx, int sy, int sz, int32_t* flags, int mark) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, flags);
+	markIsolatedFluidCell(fl, mark);
+	SHIM_CATCH
+}
+/* addForcePvel / updateVelocityFromDeltaPos / eulerStep, ptsplugins.cpp:20-53 */
+int ref_add_force_pvel(int64_t np, int64_t pstride, float* pvel, float ax, float ay, float az, float dt,
+                       const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(4, 4, 4, dt);
+	std::vector<float> zero(3 * (size_t)pstride, 0.f);
+	Parts P(c, np, pstride, zero.data(), nullptr);
+	PtypeIO pt(c, P, ptype);
+	Pdata<Vec3> v(c, P);
+	loadVec3(v.pd, pvel, np, pstride);
+	addForcePvel(v.pd, Vec3(ax, ay, az), dt, pt.ptr(), exclude);
+	storeVec3(v.pd, pvel, np, pstride);
+	SHIM_CATCH
+}
+int ref_update_velocity_from_delta_pos(int64_t np, int64_t pstride, const float* pos, float* pvel, const float* xprev,
+                                       float dt, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(4, 4, 4, dt);
+	Parts P(c, np, pstride, pos, nullptr);
+	PtypeIO pt(c, P, ptype);
+	Pdata<Vec3> v(c, P), xp(c, P);
+	loadVec3(v.pd, pvel, np, pstride);
+	loadVec3(xp.pd, xprev, np, pstride);
+	updateVelocityFromDeltaPos(P.sys, v.pd, xp.pd, dt, pt.ptr(), exclude);
+	storeVec3(v.pd, pvel, np, pstride);
+	SHIM_CATCH
+}
+int ref_euler_step(int64_t np, int64_t pstride, float* pos, const float* pvel, float dt, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(4, 4, 4, dt);
+	Parts P(c, np, pstride, pos, nullptr);
+	PtypeIO pt(c, P, ptype);
+	Pdata<Vec3> v(c, P);
+	loadVec3(v.pd, pvel, np, pstride);
+	eulerStep(P.sys, v.pd, pt.ptr(), exclude);
+	P.store();
+	SHIM_CATCH
+}
+/* LevelsetGrid::join / subtract, levelset.cpp:107-118; Grid::setBound, grid.cpp:629-637 */
+int ref_levelset_join(int64_t n, float* phi, const float* other) {
+	SHIM_TRY
+	Ctx c((int)n, 1, 1, 1.f);
+	LevelRef a(c, phi), b(c, other);
+	a.g->join(*b.g);
+	SHIM_CATCH
+}
+int ref_levelset_subtract(int64_t n, float* phi, const float* other, const int32_t* flags, int subtractType) {
+	SHIM_TRY
+	Ctx c((int)n, 1, 1, 1.f);
+	LevelRef a(c, phi), b(c, other);
+	std::unique_ptr<FlagGrid> fl;
+	if (flags) fl.reset(new FlagGrid(&c.solver, const_cast<int*>(flags)));
+	a.g->subtract(*b.g, fl.get(), subtractType);
+	SHIM_CATCH
+}
+int ref_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int w) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	RealRef g(c, grid);
+	g.ref().setBound(value, w);
 	SHIM_CATCH
 }
 

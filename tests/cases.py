@@ -378,6 +378,172 @@ def run_flipglue_ref(dims, fl0, pos, pflag, pvel, vel, phiObs=None):
     return out
 
 
+# ---- free-surface / particle maintenance pieces of benchmark_dam.py (SURVEY 8f-2 leftovers, 8f-3) ----
+def surface_inputs(dims, seed):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=True)
+    pos, pflag, pvel = util.make_particles(flags, 2, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    n = pos.shape[1]
+    # a few particles outside the grid and near the walls (projectOutOfBnd / gridParticleIndex skip paths)
+    k = max(n // 50, 3)
+    pos[:, :k] = rng.uniform(-1.5, max(dims) + 1.5, (3, k)).astype(np.float32)
+    if sz == 1:
+        pos[2] = 0.5
+    ptype = rng.choice(np.array([1, 4, 1, 1], np.int32), n).astype(np.int32)
+    phiObs = (util.rand_real((sz, sy, sx), seed + 3) * 2).astype(np.float32)
+    phi = (util.rand_real((sz, sy, sx), seed + 4) * 3).astype(np.float32)
+    xprev = (pos + rng.normal(0, 0.3, pos.shape)).astype(np.float32)
+    # a flag field with isolated fluid cells
+    fiso = np.where(flags & util.OBS, flags, util.EMPTY).astype(np.int32)
+    inner = (slice(1, -1) if sz > 1 else slice(None), slice(1, -1), slice(1, -1))
+    m = rng.random(fiso.shape) < 0.3
+    sel = np.zeros_like(m)
+    sel[inner] = m[inner]
+    fiso[sel & (fiso == util.EMPTY)] = util.FLUID
+    return dict(flags=flags, pos=pos, pflag=pflag, pvel=pvel, ptype=ptype, phiObs=phiObs, phi=phi, xprev=xprev, fiso=fiso)
+
+
+def _pd_int(s, pp, arr):
+    from mantaflow_amd import core
+    pd = pp.create(core.PdataInt)
+    pd.data[:pp.np] = torch.from_numpy(arr).to(pd.data.device)
+    return pd
+
+
+def _ppos(pp):
+    a = pp.pos.detach().cpu().numpy()
+    return np.stack([a[c * pp.cap:c * pp.cap + pp.np] for c in range(3)], 0)
+
+
+def run_surface_pkg(dims, I, dt=0.35):
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims, dt)
+    out = {}
+    fl = soa_to_grid(core.FlagGrid(s), I["flags"])
+    # projectOutOfBnd, pushOutofObs
+    pp = _mk_parts(s, I["pos"], I["pflag"])
+    pt = _pd_int(s, pp, I["ptype"])
+    pp.projectOutOfBnd(fl, 1.25, "xXyYzZ", pt, 4)
+    out["project"] = _ppos(pp)
+    pp = _mk_parts(s, I["pos"], I["pflag"])
+    pp.projectOutOfBnd(fl, 2.5, "xYz")
+    out["project_xYz"] = _ppos(pp)
+    pp = _mk_parts(s, I["pos"], I["pflag"])
+    pt = _pd_int(s, pp, I["ptype"])
+    plugins.pushOutofObs(pp, fl, soa_to_grid(core.Grid(s), I["phiObs"]), shift=0.05, thresh=0.25, ptype=pt, exclude=4)
+    out["push"] = _ppos(pp)
+    # gridParticleIndex + unionParticleLevelset + extrapolateLsSimple
+    pp = _mk_parts(s, I["pos"], I["pflag"])
+    pt = _pd_int(s, pp, I["ptype"])
+    isys, idx = core.ParticleIndexSystem(s), core.IntGrid(s)
+    plugins.gridParticleIndex(pp, isys, fl, idx)
+    out["gpi_index"] = grid_to_soa(idx)
+    out["gpi_sys"] = isys.to_numpy()
+    phi = core.LevelsetGrid(s)
+    plugins.unionParticleLevelset(pp, isys, fl, idx, phi, 1.0, pt, 4)
+    out["union"] = grid_to_soa(phi)
+    plugins.extrapolateLsSimple(phi, distance=4, inside=True)
+    out["union_els"] = grid_to_soa(phi)
+    for nm, kw in (("els_out", dict(distance=3)), ("els_in", dict(distance=4, inside=True)),
+                   ("els_walls", dict(distance=2, inside=True, include_walls=True))):
+        g = soa_to_grid(core.LevelsetGrid(s), I["phi"])
+        plugins.extrapolateLsSimple(g, **kw)
+        out[nm] = grid_to_soa(g)
+    # setPartType, markIsolatedFluidCell
+    pt = _pd_int(s, pp, I["ptype"])
+    plugins.setPartType(pp, pt, 4, 1, fl, 4)
+    out["ptype"] = pt.data[:pp.np].cpu().numpy().copy()
+    fi = soa_to_grid(core.FlagGrid(s), I["fiso"])
+    plugins.markIsolatedFluidCell(fi, 4)
+    out["isolated"] = grid_to_soa(fi)
+    # ptsplugins
+    pt = _pd_int(s, pp, I["ptype"])
+    pv = _pd_vec3(s, pp, I["pvel"])
+    plugins.addForcePvel(pv, core.vec3(0.1, -9.8 * 7.3, 0.02), s.getDt(), pt, 1)
+    out["addforce"] = np.ascontiguousarray(pv.to_numpy().T)
+    pv = _pd_vec3(s, pp, I["pvel"])
+    xp = _pd_vec3(s, pp, I["xprev"])
+    plugins.updateVelocityFromDeltaPos(pp, pv, xp, s.getDt(), pt, 4)
+    out["updvel"] = np.ascontiguousarray(pv.to_numpy().T)
+    pv = _pd_vec3(s, pp, I["pvel"])
+    plugins.eulerStep(pp, pv, pt, 1)
+    out["euler"] = _ppos(pp)
+    # levelset set ops, setBound
+    a, b = soa_to_grid(core.LevelsetGrid(s), I["phi"]), soa_to_grid(core.LevelsetGrid(s), I["phiObs"])
+    a.join(b)
+    out["join"] = grid_to_soa(a)
+    a = soa_to_grid(core.LevelsetGrid(s), I["phi"])
+    a.subtract(b)
+    out["subtract"] = grid_to_soa(a)
+    a = soa_to_grid(core.LevelsetGrid(s), I["phi"])
+    a.subtract(b, fl, 1)
+    out["subtract_flags"] = grid_to_soa(a)
+    a = soa_to_grid(core.Grid(s), I["phi"])
+    a.setBound(0.75, 2)
+    out["setbound"] = grid_to_soa(a)
+    s.sync()
+    return out
+
+
+def run_surface_ref(dims, I, dt=0.35):
+    sx, sy, sz = dims
+    cf = ctypes.c_float
+    n = I["pos"].shape[1]
+    out = {}
+    p = I["pos"].copy()
+    refcall("ref_project_out_of_bnd", sx, sy, sz, n, n, p, I["pflag"], cf(1.25), b"xXyYzZ", I["ptype"], 4)
+    out["project"] = p
+    p = I["pos"].copy()
+    refcall("ref_project_out_of_bnd", sx, sy, sz, n, n, p, I["pflag"], cf(2.5), b"xYz", None, 0)
+    out["project_xYz"] = p
+    p = I["pos"].copy()
+    refcall("ref_push_out_of_obs", sx, sy, sz, n, n, p, I["pflag"], I["phiObs"], cf(0.05), cf(0.25), I["ptype"], 4)
+    out["push"] = p
+    isys, idx, cnt = np.zeros(n, np.int32), np.zeros((sz, sy, sx), np.int32), ctypes.c_int64(0)
+    refcall("ref_grid_particle_index", sx, sy, sz, n, n, I["pos"], I["pflag"], isys, idx, ctypes.byref(cnt))
+    out["gpi_index"] = idx
+    out["gpi_sys"] = isys[:cnt.value].copy()
+    phi = np.zeros((sz, sy, sx), np.float32)
+    refcall("ref_union_particle_levelset", sx, sy, sz, n, n, I["pos"], I["pflag"], phi, cf(1.0), I["ptype"], 4)
+    out["union"] = phi.copy()
+    refcall("ref_extrapolate_ls_simple", sx, sy, sz, phi, 4, 1, 0)
+    out["union_els"] = phi
+    for nm, (dist, ins, walls) in (("els_out", (3, 0, 0)), ("els_in", (4, 1, 0)), ("els_walls", (2, 1, 1))):
+        g = I["phi"].copy()
+        refcall("ref_extrapolate_ls_simple", sx, sy, sz, g, dist, ins, walls)
+        out[nm] = g
+    pt = I["ptype"].copy()
+    refcall("ref_set_part_type", sx, sy, sz, I["flags"], n, n, I["pos"], pt, 4, 1, 4)
+    out["ptype"] = pt
+    fi = I["fiso"].copy()
+    refcall("ref_mark_isolated_fluid_cell", sx, sy, sz, fi, 4)
+    out["isolated"] = fi
+    v = I["pvel"].copy()
+    refcall("ref_add_force_pvel", n, n, v, cf(0.1), cf(-9.8 * 7.3), cf(0.02), cf(dt), I["ptype"], 1)
+    out["addforce"] = v
+    v = I["pvel"].copy()
+    refcall("ref_update_velocity_from_delta_pos", n, n, I["pos"], v, I["xprev"], cf(dt), I["ptype"], 4)
+    out["updvel"] = v
+    p = I["pos"].copy()
+    refcall("ref_euler_step", n, n, p, I["pvel"], cf(dt), I["ptype"], 1)
+    out["euler"] = p
+    N = sx * sy * sz
+    a = I["phi"].copy()
+    refcall("ref_levelset_join", N, a, I["phiObs"])
+    out["join"] = a
+    a = I["phi"].copy()
+    refcall("ref_levelset_subtract", N, a, I["phiObs"], None, 0)
+    out["subtract"] = a
+    a = I["phi"].copy()
+    refcall("ref_levelset_subtract", N, a, I["phiObs"], I["flags"], 1)
+    out["subtract_flags"] = a
+    a = I["phi"].copy()
+    refcall("ref_grid_set_bound", sx, sy, sz, a, cf(0.75), 2)
+    out["setbound"] = a
+    return out
+
+
 def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims, dt)

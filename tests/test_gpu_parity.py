@@ -249,6 +249,21 @@ def test_flip_glue(hip_backend, dims):
             assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 18, 9), (64, 48, 40)])
+def test_surface_pieces(hip_backend, dims):
+    """benchmark_dam.py's free-surface / particle maintenance calls: HIP bit-identical to the oracle (which is pinned to
+    the compiled reference by tests/test_oracle_vs_reference.py::test_surface_pieces)"""
+    from mantaflow_amd import _lib
+    I = cases.surface_inputs(dims, 51)
+    a = cases.run_surface_pkg(dims, I)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_surface_pkg(dims, I)
+    _lib.reset()
+    assert b["gpi_sys"].size > 100
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 def test_reductions_and_elementwise(hip, oracle):
     n = 1 << 20
     a, b = util.rand_real((n + 3,), 30, 3.0), util.rand_real((n + 3,), 31, 2.0)

@@ -183,6 +183,18 @@ def test_flip_glue(oracle_backend, dims, with_phi):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), (9, 16, 11), cases.SIZE_2D])
+def test_surface_pieces(oracle_backend, dims):
+    """benchmark_dam.py's free-surface / particle maintenance calls (SURVEY 8f-2 leftovers, 8f-3)"""
+    I = cases.surface_inputs(dims, 51)
+    a = cases.run_surface_pkg(dims, I)
+    b = cases.run_surface_ref(dims, I)
+    assert b["gpi_sys"].size > 100 and (b["isolated"] != I["fiso"]).sum() > 0
+    assert (b["push"] != I["pos"]).any() and (b["project"] != I["pos"]).any()
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 def test_init_domain_matches_reference(oracle_backend):
     from mantaflow_amd import core
     for dims, bw, kw in [((10, 9, 8), 0, {}), ((12, 10, 9), 1, dict(open="xY", outflow="z")), ((16, 12, 1), 0, dict(inflow="y"))]:

@@ -50,6 +50,19 @@ REF_PROTOS = {
     "ref_extrapolate_mac_simple": [c_i, c_i, c_i, c_p, c_p, c_i, c_i],
     "ref_extrapolate_mac_from_weight": [c_i, c_i, c_i, c_p, c_p, c_i],
     "ref_mark_fluid_cells": [c_i, c_i, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_i, c_p],
+    "ref_project_out_of_bnd": [c_i, c_i, c_i, c_l, c_l, c_p, c_p, c_f, ctypes.c_char_p, c_p, c_i],
+    "ref_push_out_of_obs": [c_i, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_f, c_f, c_p, c_i],
+    "ref_grid_particle_index": [c_i, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_p],
+    "ref_union_particle_levelset": [c_i, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_f, c_p, c_i],
+    "ref_extrapolate_ls_simple": [c_i, c_i, c_i, c_p, c_i, c_i, c_i],
+    "ref_set_part_type": [c_i, c_i, c_i, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i],
+    "ref_mark_isolated_fluid_cell": [c_i, c_i, c_i, c_p, c_i],
+    "ref_add_force_pvel": [c_l, c_l, c_p, c_f, c_f, c_f, c_f, c_p, c_i],
+    "ref_update_velocity_from_delta_pos": [c_l, c_l, c_p, c_p, c_p, c_f, c_p, c_i],
+    "ref_euler_step": [c_l, c_l, c_p, c_p, c_f, c_p, c_i],
+    "ref_levelset_join": [c_l, c_p, c_p],
+    "ref_levelset_subtract": [c_l, c_p, c_p, c_p, c_i],
+    "ref_grid_set_bound": [c_i, c_i, c_i, c_p, c_f, c_i],
     "ref_sample_flags_with_particles": [c_i, c_i, c_i, c_p, c_i, c_f, c_l, c_p, c_p],
     "ref_init_domain": [c_i, c_i, c_i, c_p, c_i, c_s, c_s, c_s, c_s, c_i],
 }
