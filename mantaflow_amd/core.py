@@ -13,6 +13,9 @@ vectors are structure-of-arrays ([3][N]); the reference's AoS [z][y][x][3] view 
 import ctypes
 import math
 
+import functools
+import types
+
 import numpy as np
 import torch
 
@@ -88,9 +91,25 @@ def _stream(dev):
     return None
 
 
+def _method_kwargs(fn):
+    """every PYTHON() member accepts the universal `notiming` / `nocheck` keywords (codegen_python.cpp:37, pconvert.cpp:461)"""
+    @functools.wraps(fn)
+    def w(self, *a, **kw):
+        kw.pop("notiming", None)
+        kw.pop("nocheck", None)
+        return fn(self, *a, **kw)
+    return w
+
+
 class PbClass(object):
     """Base of every solver-owned object (pwrapper/pclass.h): parent solver + name."""
     _T = ""
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        for name, attr in list(cls.__dict__.items()):
+            if isinstance(attr, types.FunctionType) and not name.startswith("_"):
+                setattr(cls, name, _method_kwargs(attr))
 
     def __init__(self, parent, name=""):
         if parent is None:

@@ -544,6 +544,67 @@ def run_surface_ref(dims, I, dt=0.35):
     return out
 
 
+def run_dam_pkg(res, steps, deterministic=True):
+    """a ghost-fluid FLIP dam break with the call sequence of scenes/benchmark_dam.py's main loop (own set-up code)"""
+    from mantaflow_amd import core, plugins, scene
+    FF, FE = 1, 4
+    bnd, sres = 3, 2
+    gs = (int(res * 1.6) + 2 * bnd, res + 2 * bnd, res // 2 + 2 * bnd)
+    s = core.Solver(name="dam", gridSize=core.vec3(*gs), dim=3)
+    s.cfl, s.frameLength, s.timestepMin = 1, 1.0 / 30, 0
+    s.timestepMax = s.timestep = s.frameLength
+    plugins.setDeterministicP2G(deterministic)
+    fl, V, Vold, P = s.create(core.FlagGrid), s.create(core.MACGrid), s.create(core.MACGrid), s.create(core.RealGrid)
+    phiS, phi = s.create(core.LevelsetGrid), s.create(core.LevelsetGrid)
+    isys, idx = s.create(core.ParticleIndexSystem), s.create(core.IntGrid)
+    pp = s.create(core.BasicParticleSystem)
+    pT, pV, pX = pp.create(core.PdataInt), pp.create(core.PdataVec3), pp.create(core.PdataVec3)
+    fl.initDomain(bnd - 1)
+    outer = s.create(scene.Box, p0=core.vec3(0), p1=core.vec3(*gs))
+    inner = s.create(scene.Box, p0=core.vec3(bnd), p1=core.vec3(gs[0] - bnd, gs[1] - bnd, gs[2] - bnd))
+    phiS.join(outer.computeLevelset())
+    phiS.subtract(inner.computeLevelset())
+    obs = s.create(scene.Box, center=core.vec3(0.45 * gs[0], bnd + 0.1 * res, 0.5 * gs[2]), size=core.vec3(0.06 * res, 0.1 * res, 0.2 * res))
+    obs.applyToGrid(grid=fl, value=2, respectFlags=fl)
+    phiS.join(obs.computeLevelset())
+    dam = s.create(scene.Box, center=core.vec3(gs[0] - bnd - 0.25 * res, bnd + 0.3 * res, 0.5 * gs[2]), size=core.vec3(0.25 * res, 0.3 * res, 0.25 * res))
+    dam.applyToGrid(grid=fl, value=FF, respectFlags=fl)
+    scene.sampleShapeWithParticles(shape=dam, flags=fl, parts=pp, discretization=sres, randomness=0)
+    pT.setConstRange(FF, 0, pp.pySize())
+    grav = core.vec3(0, -9.8 * res, 0)
+    iters = []
+    for _ in range(steps):
+        plugins.mapPartsToMAC(vel=V, flags=fl, velOld=Vold, parts=pp, partVel=pV, ptype=pT, exclude=FE)
+        s.adaptTimestep(V.getMaxAbs())
+        plugins.addGravityNoScale(flags=fl, vel=V, gravity=grav)
+        plugins.gridParticleIndex(parts=pp, flags=fl, indexSys=isys, index=idx)
+        plugins.unionParticleLevelset(parts=pp, indexSys=isys, flags=fl, index=idx, phi=phi, radiusFactor=1.0)
+        plugins.extrapolateLsSimple(phi=phi, distance=4, inside=True)
+        plugins.setWallBcs(flags=fl, vel=V)
+        plugins.solvePressure(flags=fl, vel=V, pressure=P, cgAccuracy=1e-3, phi=phi)
+        iters.append(plugins.lastCgStats()["iterations"])
+        plugins.setWallBcs(flags=fl, vel=V)
+        plugins.extrapolateMACSimple(flags=fl, vel=V)
+        plugins.flipVelocityUpdate(vel=V, velOld=Vold, flags=fl, parts=pp, partVel=pV, flipRatio=0.97, ptype=pT, exclude=FE)
+        plugins.addForcePvel(vel=pV, a=grav, dt=s.timestep, ptype=pT, exclude=FF)
+        pp.getPosPdata(target=pX)
+        pp.advectInGrid(flags=fl, vel=V, integrationMode=2, deleteInObstacle=False, ptype=pT, exclude=FE)
+        plugins.eulerStep(parts=pp, vel=pV, ptype=pT, exclude=FF)
+        pp.projectOutOfBnd(flags=fl, bnd=bnd + 0.25, plane="xXyYzZ", ptype=pT)
+        plugins.pushOutofObs(parts=pp, flags=fl, phiObs=phiS, thresh=0.25, ptype=pT)
+        plugins.updateVelocityFromDeltaPos(parts=pp, vel=pV, x_prev=pX, dt=s.timestep, ptype=pT, exclude=FF)
+        plugins.markFluidCells(parts=pp, flags=fl, ptype=pT)
+        plugins.setPartType(parts=pp, ptype=pT, mark=FF, stype=FE, flags=fl, cflag=FF)
+        plugins.markIsolatedFluidCell(flags=fl, mark=FE)
+        plugins.setPartType(parts=pp, ptype=pT, mark=FE, stype=FF, flags=fl, cflag=FE)
+        s.step()
+    s.sync()
+    plugins.setDeterministicP2G(False)
+    return dict(pos=_ppos(pp), pvel=np.ascontiguousarray(pV.to_numpy().T), ptype=pT.data[:pp.np].cpu().numpy().copy(),
+                flags=grid_to_soa(fl), phi=grid_to_soa(phi), vel=grid_to_soa(V), pres=grid_to_soa(P), iters=iters, gs=gs,
+                dt=float(s.timestep))
+
+
 def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims, dt)

@@ -5,6 +5,7 @@
 import ctypes
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -95,6 +96,23 @@ def main():
             ms = tot[k] / reps
             print("  %-26s %8.3f ms   %8.1f Mparticles/s" % (k, ms, npart / ms / 1e3))
         print("  whole FLIP step            %8.3f ms   %8.2f Mcells/s" % (sum(tot.values()) / reps, n ** 3 / (sum(tot.values()) / reps) / 1e3))
+    elif what == "dam":
+        # ghost-fluid FLIP dam break with benchmark_dam.py's loop (tests/cases.py:run_dam_pkg), MF_RES = reference resolution
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        import cases
+        res = int(os.environ.get("MF_RES", "160"))
+        cases.run_dam_pkg(res, 2, deterministic=False)      # warm-up (allocations, sort scratch)
+        plugins._timings.clear()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = cases.run_dam_pkg(res, reps, deterministic=False)
+        torch.cuda.synchronize()
+        el = time.time() - t0
+        gs = out["gs"]
+        ncell = gs[0] * gs[1] * gs[2]
+        print("dam break res %d: grid %s (%d cells), %d particles, %d steps: %.2f ms/step incl. set-up amortised, CG iterations %s"
+              % (res, gs, ncell, out["pos"].shape[1], reps, el * 1e3 / reps, out["iters"]))
+        plugins.Timings().display()
     elif what == "advect":
         vel, dens = core.MACGrid(s), core.Grid(s)
         vel.from_numpy(np.ascontiguousarray(bench.synthetic_velocity(n, n, n).transpose(1, 2, 3, 0)))
