@@ -682,6 +682,12 @@ def golden_outputs(impl, deterministic_p2g=True):
         out["padv_m%d_pos" % mode], out["padv_m%d_flag" % mode] = p, f
     p, f = run_advect_parts_pkg(dims, 0.8, flags, v2, pos, pflag, 2, True, True)
     out["padv_del_pos"], out["padv_del_flag"] = p, f
+    gd = (14, 12, 10)
+    fl0, pos, pflag, pvel, vel = flipglue_inputs(gd, 31)
+    for k, v in run_flipglue_pkg(gd, fl0, pos, pflag, pvel, vel, None).items():
+        out["glue_" + k] = v
+    for k, v in run_surface_pkg(gd, surface_inputs(gd, 51)).items():
+        out["surf_" + k] = v
     return out
 
 

@@ -55,6 +55,13 @@ def main():
         out["padv_m%d_pos" % mode], out["padv_m%d_flag" % mode] = p, f
     p, f = cases.run_advect_parts_ref(dims, 0.8, flags, v2, pos, pflag, 2, True, True)
     out["padv_del_pos"], out["padv_del_flag"] = p, f
+    # FLIP glue and the free-surface pieces of benchmark_dam.py (8f-3)
+    gd = (14, 12, 10)
+    fl0, pos, pflag, pvel, vel = cases.flipglue_inputs(gd, 31)
+    for k, v in cases.run_flipglue_ref(gd, fl0, pos, pflag, pvel, vel, None).items():
+        out["glue_" + k] = v
+    for k, v in cases.run_surface_ref(gd, cases.surface_inputs(gd, 51)).items():
+        out["surf_" + k] = v
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote %d arrays, %.1f KiB" % (len(out), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")) / 1024))
 
