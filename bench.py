@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab", action="store_true", help="N=1 only: run the z-slab code path with one rank (overhead check)")
     a = ap.parse_args()
 
     import torch
@@ -144,8 +145,12 @@ def main():
     n = a.grid
     dt = 1.0
 
-    if world > 1:
+    if world > 1 or a.slab:
         from mantaflow_amd import slab
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         result = slab.bench_slab_step(n, dt, a.steps, a.warmup, rank, world)
     else:
         s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
@@ -223,7 +228,7 @@ def main():
         if "notes" in result:
             line["config"]["notes"] = result["notes"]
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

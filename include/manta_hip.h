@@ -284,6 +284,18 @@ int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_
 int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boundaryWidth, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * device-scalar variants for the multi-GPU PCG (no reference counterpart: same arithmetic as mf_grid_dot /
+ * mf_grid_max_abs / mf_grid_scaled_add / mf_update_search_vec, but the scalar results and factors live in device
+ * memory, so a rank never waits for the host between a reduction, its all-gather and the update that uses it)
+ * ---------------------------------------------------------------------------------------------- */
+int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out_dev, void* stream);
+int mf_grid_max_abs_dev(int64_t n, const float* a, float* out_dev, void* stream);
+/* me += (sign * factor_dev[0]) * other, sign = +-1 */
+int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor_dev, float sign, void* stream);
+/* dst = src + factor_dev[0] * dst */
+int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const float* factor_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HIP-only helpers (return an error in the CPU libraries)
  * ---------------------------------------------------------------------------------------------- */
 /* average duration in microseconds of `reps` back-to-back launches of the named kernel on `stream`,

@@ -208,6 +208,27 @@ __global__ void __launch_bounds__(BLOCK) k_count_flag_partials(int64_t n, const 
 	if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
+// device-scalar variants (multi-GPU PCG: no host round trip between a reduction and the vector update that uses it)
+template <int OP>
+__global__ void __launch_bounds__(BLOCK) k_binary_devf(int64_t n, float* a, const float* b, const float* __restrict__ fdev, float sign) {
+	const float f = sign * fdev[0];   // sign is +-1: exact
+	for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+		a[i] = op2<OP>(a[i], b[i], f);
+}
+__global__ void __launch_bounds__(BLOCK) k_maxabs_finish(int nb, const float* __restrict__ partials, float* __restrict__ out) {
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+		lo = fminf(lo, partials[2 * i]);
+		hi = fmaxf(hi, partials[2 * i + 1]);
+	}
+	block_minmax(lo, hi);
+	if (threadIdx.x == 0) {
+		lo = fabsf(lo);
+		hi = fabsf(hi);
+		out[0] = lo > hi ? lo : hi;   // max(fabs(amin), fabs(amax)), grid.cpp:359
+	}
+}
+
 static int read_back(Workspace* ws, const void* dev, size_t bytes, void* host_out, hipStream_t s) {
 	MF_HIP(hipMemcpyAsync(ws->host, dev, bytes, hipMemcpyDeviceToHost, s));
 	MF_HIP(hipStreamSynchronize(s));
@@ -256,6 +277,36 @@ int mf_grid_dot(int64_t n, const float* a, const float* b, double* r, void* s) {
 	hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(BLOCK), 0, (hipStream_t)s, nb, ws->partials, (double*)ws->scalars);
 	MF_LAUNCH_CHECK();
 	return read_back(ws, ws->scalars, sizeof(double), r, (hipStream_t)s);
+}
+int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out_dev, void* s) {
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	const int nb = blocks_for(n, BLOCK * 8, 1024);
+	hipLaunchKernelGGL(k_dot_partials<0>, dim3(nb), dim3(BLOCK), 0, (hipStream_t)s, n, a, b, ws->partials);
+	hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(BLOCK), 0, (hipStream_t)s, nb, ws->partials, out_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_grid_max_abs_dev(int64_t n, const float* a, float* out_dev, void* s) {
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	const int nb = blocks_for(n, BLOCK * 8, 1024);
+	hipLaunchKernelGGL(k_minmax_partials, dim3(nb), dim3(BLOCK), 0, (hipStream_t)s, n, a, ws->fpartials);
+	hipLaunchKernelGGL(k_maxabs_finish, dim3(1), dim3(BLOCK), 0, (hipStream_t)s, nb, ws->fpartials, out_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_grid_scaled_add_dev(int64_t n, float* me, const float* o, const float* factor_dev, float sign, void* s) {
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_binary_devf<OP_AXPY>, dim3(blocks_for(n, BLOCK * 4, 4096)), dim3(BLOCK), 0, (hipStream_t)s, n, me, o, factor_dev, sign);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const float* factor_dev, void* s) {
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL(k_binary_devf<OP_XPAY>, dim3(blocks_for(n, BLOCK * 4, 4096)), dim3(BLOCK), 0, (hipStream_t)s, n, dst, src, factor_dev, 1.f);
+	MF_LAUNCH_CHECK();
+	return 0;
 }
 int mf_grid_sum_sqr(int64_t n, const float* a, double* r, void* s) {
 	Workspace* ws;

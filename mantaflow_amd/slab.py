@@ -81,6 +81,22 @@ class Comm(object):
         return torch.stack(out).cpu().numpy()
 
 
+    def allgather_dev(self, t):
+        """[k] tensor on the compute device -> [world][k] on the same device, without touching the host when the backend
+        moves device memory itself (nccl = RCCL); rows are in rank order on every rank, so reductions over them are
+        bit-identical everywhere"""
+        if not self.on:
+            return t.unsqueeze(0)
+        if self.stage and t.is_cuda:
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(out, h)
+            return torch.stack(out).to(t.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return torch.stack(out)
+
+
 class SlabDomain(object):
     def __init__(self, gsize, ghost, comm=None):
         self.comm = comm or Comm()
@@ -202,44 +218,53 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     gmax = max(dom.NX, dom.NY, dom.NZ)
     maxIter = int(np.float32(cgMaxIterFac) * np.float32(gmax))
 
-    def dot(a, b):
-        d = ctypes.c_double()
-        lib.call("mf_grid_dot", nown, _off(a.data, off), _off(b.data, off), ctypes.byref(d), st)
-        return d.value
+    dev = s.device
+    red = torch.zeros(2, dtype=torch.float64, device=dev)     # [max|residual| (as fp64), dot] of this rank
+    rmax = torch.zeros(1, dtype=torch.float32, device=dev)
+    alpha = torch.zeros(1, dtype=torch.float32, device=dev)
+    beta = torch.zeros(1, dtype=torch.float32, device=dev)
+    zero = torch.zeros((), dtype=torch.float32, device=dev)
+
+    def dot_into(a, b, slot):
+        lib.call("mf_grid_dot_dev", nown, _off(a.data, off), _off(b.data, off), ctypes.c_void_p(red.data_ptr() + 8 * slot), st)
 
     def mic(dst, src):
         lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Ai.ptr, Aj.ptr, Akm.ptr, st)
 
-    f32 = np.float32
+    # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather
+    # whose rows are combined in rank order; the host looks at one number per iteration (the stopping test).
     # doInit, conjugategrad.cpp:210-235
     pressure.clear()
     residual.copyFrom(rhs)
     lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Akm.ptr, st)
     mic(tmp, residual)
     search.copyFrom(tmp)
-    sigma = f32(np.sum(dom.comm.gather_scalars([dot(tmp, residual)], s.device)[:, 0]))
-    iters, resNorm = 0, f32(1e20)
+    dot_into(tmp, residual, 1)
+    sigma = dom.comm.allgather_dev(red)[:, 1].sum().to(torch.float32)
+    iters, resNorm = 0, 1e20
     for _ in range(maxIter):
         iters += 1
         dom.exchange(search, 1)
         lib.call("mf_apply_matrix", sx, sy, sz, flags.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)
-        dp = f32(np.sum(dom.comm.gather_scalars([dot(tmp, search)], s.device)[:, 0]))
-        alpha = f32(0.0) if not abs(float(dp)) > 0. else f32(sigma / dp)
-        lib.call("mf_grid_scaled_add", nown, _off(pressure.data, off), _off(search.data, off), float(alpha), st)
-        lib.call("mf_grid_scaled_add", nown, _off(residual.data, off), _off(tmp.data, off), float(-alpha), st)
+        dot_into(tmp, search, 1)
+        dp = dom.comm.allgather_dev(red)[:, 1].sum().to(torch.float32)
+        alpha[0] = torch.where(dp.abs() > 0, sigma / dp, zero)          # conjugategrad.cpp:252-254
+        lib.call("mf_grid_scaled_add_dev", nown, _off(pressure.data, off), _off(search.data, off), _ptr(alpha), 1.0, st)
+        lib.call("mf_grid_scaled_add_dev", nown, _off(residual.data, off), _off(tmp.data, off), _ptr(alpha), -1.0, st)
         mic(tmp, residual)
-        r = ctypes.c_float()
-        lib.call("mf_grid_max_abs", nown, _off(residual.data, off), ctypes.byref(r), st)
-        g = dom.comm.gather_scalars([r.value, dot(tmp, residual)], s.device)
-        resNorm = f32(np.max(g[:, 0]))
-        if resNorm < f32(cgAccuracy):
-            sigma = resNorm
+        lib.call("mf_grid_max_abs_dev", nown, _off(residual.data, off), _ptr(rmax), st)
+        red[0] = rmax[0].to(torch.float64)
+        dot_into(tmp, residual, 1)
+        g = dom.comm.allgather_dev(red)
+        resT = g[:, 0].max().to(torch.float32)
+        sigmaNew = g[:, 1].sum().to(torch.float32)
+        resNorm = float(resT)                                             # the one host read of the iteration
+        if np.float32(resNorm) < np.float32(cgAccuracy):
             break
-        sigmaNew = f32(np.sum(g[:, 1]))
-        beta = f32(sigmaNew / sigma)
-        lib.call("mf_update_search_vec", nown, _off(search.data, off), _off(tmp.data, off), float(beta), st)
+        beta[0] = sigmaNew / sigma
+        lib.call("mf_update_search_vec_dev", nown, _off(search.data, off), _off(tmp.data, off), _ptr(beta), st)
         sigma = sigmaNew
-        if not (float(resNorm) < 1e35):
+        if not (resNorm < 1e35):
             raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     if stats is not None:
         stats["iterations"], stats["residual"] = iters, float(resNorm)

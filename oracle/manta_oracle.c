@@ -2018,6 +2018,24 @@ int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_
 	return 0;
 }
 
+/* device-scalar variants (here: host pointers) */
+int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out, void* s) {
+	(void)s;
+	*out = dot64(n, a, b);
+	return 0;
+}
+int mf_grid_max_abs_dev(int64_t n, const float* a, float* out, void* s) {
+	(void)s;
+	*out = maxabs(n, a);
+	return 0;
+}
+int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor, float sign, void* s) {
+	return mf_grid_scaled_add(n, me, other, sign * factor[0], s);
+}
+int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const float* factor, void* s) {
+	return mf_update_search_vec(n, dst, src, factor[0], s);
+}
+
 int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
                          const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* st) {
 	(void)sx; (void)sy; (void)sz; (void)flags; (void)dst; (void)src; (void)A0; (void)Ai; (void)Aj; (void)Ak; (void)reps;
