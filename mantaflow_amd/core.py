@@ -292,6 +292,14 @@ class GridBase(PbClass):
 
     def getDataPointer(self): return "%x" % self.data.data_ptr()
 
+    def save(self, name):
+        """Grid<T>::save, grid.cpp:157-179 (.uni, .raw, .npz)"""
+        return _grid_save(self, str(name))
+
+    def load(self, name):
+        """Grid<T>::load, grid.cpp:135-155"""
+        return _grid_load(self, str(name))
+
     # numpy bridge (plugin/numpyconvert.cpp:145-223): [z][y][x](,[c]) arrays
     def to_numpy(self):
         a = self.data.detach().cpu().numpy()
@@ -308,6 +316,84 @@ class GridBase(PbClass):
         t = torch.from_numpy(flat.astype(np.int32 if self._kind == "int" else np.float32, copy=False))
         self.data.copy_(t.to(self.data.device))
         return self
+
+
+# ---------------------------------------------------------------------------------------------------------
+# .uni / .raw grid files (fileio/iogrids.cpp:36-44, 255-292, 386-513): gzip stream of "MNT3" + UniHeader + the raw
+# element array (x fastest; Vec3 grids as 3 floats per cell).  Data format either side of the hot path.
+# ---------------------------------------------------------------------------------------------------------
+_UNI_HEADER = "<6i252siQ"       # dimX dimY dimZ gridType elementType bytesPerElement info[252] dimT timestamp = 288 B
+
+
+def _unify_grid_type(t):
+    """unifyGridType, iogrids.cpp:213-221"""
+    if t & GridBase.TypeReal: t |= GridBase.TypeLevelset
+    if t & GridBase.TypeLevelset: t |= GridBase.TypeReal
+    if t & GridBase.TypeVec3: t |= GridBase.TypeMAC
+    if t & GridBase.TypeMAC: t |= GridBase.TypeVec3
+    return t
+
+
+def _grid_save(g, name):
+    import gzip, struct, time as _time
+    if "." not in name:
+        raise RuntimeError("file '%s' does not have an extension" % name)
+    ext = name[name.rfind("."):]
+    raw = g.to_numpy().astype(np.int32 if g._kind == "int" else np.float32, copy=False).tobytes()
+    if ext == ".raw":
+        with gzip.open(name, "wb", compresslevel=1) as f:
+            f.write(raw)
+    elif ext == ".uni":
+        et = 0 if (g._gtype & GridBase.TypeInt) else (1 if (g._gtype & GridBase.TypeReal) else 2)
+        info = b"mantaflow_amd 0.1 64bit fp1 hip gfx950"
+        head = struct.pack(_UNI_HEADER, g.sx, g.sy, g.sz, g._gtype, et, 4 * g._ncomp, info, 0, int(_time.time() * 1000))
+        with gzip.open(name, "wb", compresslevel=1) as f:
+            f.write(b"MNT3")
+            f.write(head)
+            f.write(raw)
+    elif ext == ".npz":
+        np.savez_compressed(name, arr_0=g.to_numpy())
+    else:
+        raise RuntimeError("file '%s' filetype not supported" % name)
+    return 1
+
+
+def _grid_load(g, name):
+    import gzip, struct
+    if "." not in name:
+        raise RuntimeError("file '%s' does not have an extension" % name)
+    ext = name[name.rfind("."):]
+    dt = np.int32 if g._kind == "int" else np.float32
+    nbytes = 4 * g._ncomp * g.n
+    shape = (g.sz, g.sy, g.sx) if g._ncomp == 1 else (g.sz, g.sy, g.sx, 3)
+    if ext == ".raw":
+        with gzip.open(name, "rb") as f:
+            raw = f.read()
+        if len(raw) != nbytes:
+            raise RuntimeError("can't read raw file, stream length does not match, %d vs %d" % (nbytes, len(raw)))
+    elif ext == ".uni":
+        with gzip.open(name, "rb") as f:
+            ident = f.read(4)
+            if ident != b"MNT3":
+                raise RuntimeError("readGridUni: Unknown header '%s' " % ident.decode(errors="replace"))
+            hb = f.read(struct.calcsize(_UNI_HEADER))
+            if len(hb) != struct.calcsize(_UNI_HEADER):
+                raise RuntimeError("can't read file, no header present")
+            dx, dy, dz, gtype, etype, bpe, info, dimt, stamp = struct.unpack(_UNI_HEADER, hb)
+            if (dx, dy, dz) != (g.sx, g.sy, g.sz):
+                raise RuntimeError("grid dim doesn't match, [%d,%d,%d] vs [%d,%d,%d]" % (dx, dy, dz, g.sx, g.sy, g.sz))
+            if _unify_grid_type(gtype) != _unify_grid_type(g._gtype):
+                raise RuntimeError("grid type doesn't match %d vs %d" % (gtype, g._gtype))
+            if bpe != 4 * g._ncomp:
+                raise RuntimeError("grid element size doesn't match %d vs %d" % (bpe, 4 * g._ncomp))
+            raw = f.read(nbytes)
+    elif ext == ".npz":
+        g.from_numpy(np.load(name)["arr_0"])
+        return 1
+    else:
+        raise RuntimeError("file '%s' filetype not supported" % name)
+    g.from_numpy(np.frombuffer(raw, dtype=dt).reshape(shape).copy())
+    return 1
 
 
 class Grid(GridBase):

@@ -16,6 +16,7 @@
 #include "conjugategrad.h"
 #include "commonkernels.h"
 #include "levelset.h"
+#include "mantaio.h"
 #include <cstring>
 #include <string>
 #include <vector>
@@ -193,6 +194,18 @@ static void storeVec3(ParticleDataImpl<Vec3>& pd, float* s, int64_t np, int64_t 
 	}
 }
 }  // namespace
+
+template <class G, class T>
+static void uni_io(Ctx& c, int kind_write, const char* name, void* data, int64_t nelem) {
+	G g(&c.solver);
+	if (kind_write) {
+		memcpy(&g[0], data, sizeof(T) * nelem);
+		g.save(name);
+	} else {
+		g.load(name);
+		memcpy(data, &g[0], sizeof(T) * nelem);
+	}
+}
 
 extern "C" {
 
@@ -723,6 +736,21 @@ int ref_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int w) 
 	Ctx c(sx, sy, sz, 1.f);
 	RealRef g(c, grid);
 	g.ref().setBound(value, w);
+	SHIM_CATCH
+}
+
+/* Grid<T>::save / load through the reference's own .uni / .raw writers and readers (fileio/iogrids.cpp).
+ * kind: 0 int, 1 Real, 2 Vec3 (AoS float[n][3]), 3 MAC, 4 Levelset */
+int ref_grid_file(int sx, int sy, int sz, int kind, int write, const char* name, void* data) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	switch (kind) {
+		case 0: uni_io<Grid<int>, int>(c, write, name, data, c.n); break;
+		case 1: uni_io<Grid<Real>, Real>(c, write, name, data, c.n); break;
+		case 2: uni_io<Grid<Vec3>, Vec3>(c, write, name, data, c.n); break;
+		case 3: uni_io<MACGrid, Vec3>(c, write, name, data, c.n); break;
+		default: uni_io<LevelsetGrid, Real>(c, write, name, data, c.n); break;
+	}
 	SHIM_CATCH
 }
 

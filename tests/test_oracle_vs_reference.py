@@ -195,6 +195,39 @@ def test_surface_pieces(oracle_backend, dims):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("ext", [".uni", ".raw"])
+def test_grid_files_interoperate_with_reference(oracle_backend, tmp_path, ext):
+    """.uni / .raw files: what the package writes the reference reads back bit for bit, and vice versa"""
+    from mantaflow_amd import core
+    dims = (11, 7, 5)
+    sx, sy, sz = dims
+    s = cases._mk_solver(dims)
+    rng = np.random.default_rng(3)
+    for kind, cls, shape, dt in ((0, core.IntGrid, (sz, sy, sx), np.int32), (1, core.Grid, (sz, sy, sx), np.float32),
+                                 (2, core.VecGrid, (sz, sy, sx, 3), np.float32), (3, core.MACGrid, (sz, sy, sx, 3), np.float32),
+                                 (4, core.LevelsetGrid, (sz, sy, sx), np.float32)):
+        a = (rng.normal(0, 3, shape) * (100 if kind == 0 else 1)).astype(dt)
+        g = cls(s)
+        g.from_numpy(a)
+        f1 = str(tmp_path / ("ours%d%s" % (kind, ext)))
+        assert g.save(f1) == 1
+        back = np.zeros(shape, dt)
+        util.refcall("ref_grid_file", sx, sy, sz, kind, 0, f1.encode(), back)
+        assert_bitexact(back, a, "reference reads our %s kind %d" % (ext, kind))
+        f2 = str(tmp_path / ("theirs%d%s" % (kind, ext)))
+        util.refcall("ref_grid_file", sx, sy, sz, kind, 1, f2.encode(), a)
+        h = cls(s)
+        assert h.load(f2) == 1
+        assert_bitexact(h.to_numpy(), a, "we read the reference's %s kind %d" % (ext, kind))
+    if ext == ".uni":
+        # wrong size / wrong type are refused like the reference does (iogrids.cpp:493-494)
+        other = core.Grid(cases._mk_solver((10, 7, 5)))
+        with pytest.raises(RuntimeError, match="grid dim doesn't match"):
+            other.load(str(tmp_path / "ours1.uni"))
+        with pytest.raises(RuntimeError, match="grid type doesn't match"):
+            core.Grid(s).load(str(tmp_path / "ours2.uni"))
+
+
 def test_init_domain_matches_reference(oracle_backend):
     from mantaflow_amd import core
     for dims, bw, kw in [((10, 9, 8), 0, {}), ((12, 10, 9), 1, dict(open="xY", outflow="z")), ((16, 12, 1), 0, dict(inflow="y"))]:
