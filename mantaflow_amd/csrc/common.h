@@ -73,6 +73,12 @@ static inline int check_dim(int sx, int sy, int sz) {
 	return 0;
 }
 
+// p2g_ordered.hip: parallel particle->grid transfers with the reference's serial summation order (bit-exact)
+int p2g_ordered_mac(const Dim& d, float* vel, float* weight, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
+                    const float* pvel, const int32_t* ptype, int exclude, hipStream_t st);
+int p2g_ordered_cell(const Dim& d, int ncomp, float* target, float* wsum, int64_t np, int64_t ps, const float* pos,
+                     const int32_t* pflag, const float* psrc, hipStream_t st);
+
 constexpr int BLOCK = 256;
 static inline int blocks_for(int64_t n, int per_block, int cap = MAX_BLOCKS) {
 	int64_t b = (n + per_block - 1) / per_block;

@@ -459,7 +459,10 @@ int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float
 	MF_HIP(hipMemsetAsync(weight, 0, sizeof(float) * 3 * d.n, st));
 	MF_HIP(hipMemsetAsync(vel, 0, sizeof(float) * 3 * d.n, st));
 	if (np > 0) {
-		if (deterministic)
+		static const bool sequential = getenv("MF_P2G_SEQUENTIAL") != nullptr;   // the one-thread walk, kept as a cross-check
+		if (deterministic && !sequential)
+			MF_TRY(p2g_ordered_mac(d, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude, st));
+		else if (deterministic)
 			hipLaunchKernelGGL(k_p2g_mac_sequential, dim3(1), dim3(64), 0, st, d, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude);
 		else if (3 * d.n < ((int64_t)1 << 31) && !getenv("MF_P2G_NOLDS"))
 			hipLaunchKernelGGL(k_p2g_mac_lds, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude);
@@ -498,7 +501,10 @@ int mf_map_parts_to_grid(int sx, int sy, int sz, int ncomp, float* target, float
 	MF_HIP(hipMemsetAsync(target, 0, sizeof(float) * ncomp * d.n, st));
 	MF_HIP(hipMemsetAsync(wtmp, 0, sizeof(float) * d.n, st));
 	if (np > 0) {
-		if (deterministic) {
+		static const bool sequential = getenv("MF_P2G_SEQUENTIAL") != nullptr;
+		if (deterministic && !sequential) {
+			MF_TRY(p2g_ordered_cell(d, ncomp, target, wtmp, np, ps, pos, pflag, psrc, st));
+		} else if (deterministic) {
 			if (ncomp == 1)
 				hipLaunchKernelGGL((k_p2g_cell_sequential<1>), dim3(1), dim3(64), 0, st, d, target, wtmp, np, ps, pos, pflag, psrc);
 			else
