@@ -264,12 +264,14 @@ def lastCgStats():
 # =========================================================================================================
 # FLIP transfers
 # =========================================================================================================
-_deterministic_p2g = False
+_deterministic_p2g = True
 
 
 def setDeterministicP2G(on):
-    """parity switch: particle->grid sums in particle-index order (bit-identical to the reference's single-threaded
-    scatter, flip.cpp:619) instead of fp32 atomics"""
+    """particle->grid transfers: True (default) = sums in particle-index order, bit-identical to the reference's
+    single-threaded scatter (flip.cpp:619) on every run (parallel ordered gather, p2g_ordered.hip; 2.2 ms for 3.8 M
+    particles at 128^3); False = fp32 atomics with block-private LDS accumulation (1.6 ms, last bits depend on the order
+    of arrival)"""
     global _deterministic_p2g
     _deterministic_p2g = bool(on)
 

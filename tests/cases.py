@@ -264,7 +264,7 @@ def run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype=None, exclude
     plugins.mapGridToPartsVec3(soa_to_grid(core.VecGrid(s), vel), pp, pv4)
     out["g2p_vec3"] = _pd_get(pv4, pp.np)
     s.sync()
-    plugins.setDeterministicP2G(False)
+    plugins.setDeterministicP2G(True)
     return out
 
 
@@ -355,7 +355,7 @@ def run_flipglue_pkg(dims, fl0, pos, pflag, pvel, vel, phiObs=None):
     plugins.extrapolateMACSimple(fl, v3, distance=2, intoObs=True)
     out["ems_into"] = grid_to_soa(v3)
     s.sync()
-    plugins.setDeterministicP2G(False)
+    plugins.setDeterministicP2G(True)
     return out
 
 
@@ -599,7 +599,7 @@ def run_dam_pkg(res, steps, deterministic=True):
         plugins.setPartType(parts=pp, ptype=pT, mark=FE, stype=FF, flags=fl, cflag=FE)
         s.step()
     s.sync()
-    plugins.setDeterministicP2G(False)
+    plugins.setDeterministicP2G(True)
     return dict(pos=_ppos(pp), pvel=np.ascontiguousarray(pV.to_numpy().T), ptype=pT.data[:pp.np].cpu().numpy().copy(),
                 flags=grid_to_soa(fl), phi=grid_to_soa(phi), vel=grid_to_soa(V), pres=grid_to_soa(P), iters=iters, gs=gs,
                 dt=float(s.timestep))

@@ -55,7 +55,7 @@ def test_golden_vectors(hip, hip_backend):
 
 
 def test_golden_p2g_atomic_mode(hip, hip_backend):
-    """default (atomic) particle->grid mode: order of fp32 sums is undefined -> 1e-5 relative"""
+    """opt-in atomic particle->grid mode (setDeterministicP2G(False)): order of fp32 sums is undefined -> 1e-5 relative"""
     gold = cases.load_golden()
     dims = (12, 10, 9)
     flags = util.make_flags(*dims, 14, empty_top=True)
@@ -278,6 +278,30 @@ def test_dam_break_steps_match_oracle(hip_backend):
     assert_bitexact(a["ptype"], b["ptype"], "ptype")
     for k in ("pos", "pvel", "vel", "pres", "phi"):
         _close(a[k], b[k], k)
+
+
+@pytest.mark.parametrize("dims,per_cell", [((64, 48, 40), 8), ((96, 80, 1), 4), ((40, 33, 27), 27)])
+def test_ordered_p2g_bitexact_at_scale(hip_backend, dims, per_cell):
+    """the default (ordered) particle->grid transfer: hundreds of thousands of shuffled particles, up to 27 per cell,
+    ptype exclusion and deleted particles -- bit-identical to the oracle's serial scatter, and to itself on a re-run"""
+    from mantaflow_amd import _lib
+    flags = util.make_flags(*dims, 61, empty_top=True)
+    vel, velOld = util.rand_vel(*dims, 62), util.rand_vel(*dims, 63)
+    pos, pflag, pvel = util.make_particles(flags, per_cell, 64)
+    rng = np.random.default_rng(65)
+    perm = rng.permutation(pos.shape[1])             # particles are NOT cell-ordered
+    pos, pflag, pvel = np.ascontiguousarray(pos[:, perm]), np.ascontiguousarray(pflag[perm]), np.ascontiguousarray(pvel[:, perm])
+    ptype = rng.choice(np.array([1, 4, 1], np.int32), pos.shape[1]).astype(np.int32)
+    keys = ("p2g_vel", "p2g_velOld", "p2g_weight", "p2g_real", "p2g_vec3")
+    a = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype=ptype, exclude=4)
+    a2 = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype=ptype, exclude=4)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel, ptype=ptype, exclude=4)
+    _lib.reset()
+    assert pos.shape[1] > 15000
+    for k in keys:
+        assert_bitexact(a[k], b[k], k)
+        assert_bitexact(a[k], a2[k], k + " (re-run)")
 
 
 def test_reductions_and_elementwise(hip, oracle):

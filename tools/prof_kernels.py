@@ -63,7 +63,7 @@ def main():
         # S-flip: fluid block = lower 0.4 x 0.6 x 1.0 of the box, 8 particles per cell, pvel ~ N(0, 0.5^2)
         from mantaflow_amd import scene
         s.timestep = 0.5
-        plugins.setDeterministicP2G(os.environ.get("MF_P2G_DET", "0") == "1")
+        plugins.setDeterministicP2G(os.environ.get("MF_P2G_DET", "1") == "1")
         flags.initDomain(boundaryWidth=0)
         box = scene.Box(parent=s, p0=core.vec3(0, 0, 0), p1=core.vec3(0.4 * n, 0.6 * n, n))
         flags.updateFromLevelset(box.computeLevelset())
