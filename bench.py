@@ -191,7 +191,7 @@ def main():
         gbs = APPLY_MATRIX_BYTES_PER_CELL * n ** 3 / (us.value * 1e-6) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "apply_matrix_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and n == GRID:
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
@@ -212,12 +212,12 @@ def main():
         el = result["elapsed"]
         cells = n ** 3
         line = {
-            "metric": "Mcells/s per step (advect+CG+FLIP), 256^3 grid",
+            "metric": "Mcells/s per step (advect+CG+FLIP), %d^3 grid" % n,
             "value": round(cells * a.steps / el / 1e6, 2), "unit": "Mcells/s", "n_gpus": a.gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(el / max(a.steps, 1) * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "256^3 smoke step on %d x MI355X: advectSemiLagrange(density, order 2) + "
-                                   "advectSemiLagrange(vel, order 2) + setWallBcs + solvePressure (MIC-CG, cgAccuracy 1e-3)" % a.gpus,
+            "config": {"workload": "%d^3 smoke step on %d x MI355X: advectSemiLagrange(density, order 2) + "
+                                   "advectSemiLagrange(vel, order 2) + setWallBcs + solvePressure (MIC-CG, cgAccuracy 1e-3)" % (n, a.gpus),
                        "grid": [n, n, n], "cg_iterations_per_step": result.get("cg_iterations"),
                        "parallelism": "single GPU" if a.gpus == 1 else "z-slab x%d, 1-plane halo p2p + RCCL all-reduce of CG scalars" % a.gpus},
         }
