@@ -58,6 +58,12 @@ int mf_set_slab_window(int zoff, int gsz);
  * "rows" (default for 3D), "tiles", "levels"; NULL or "" = back to the default / MF_MIC_MODE.  Returns 0, or -1 for an
  * unknown name.  The oracle accepts and ignores it. */
 int mf_set_mic_mode(const char* name);
+/* Multi-GPU only (no reference counterpart): tell the MIC sweeps that the caller has cut the preconditioner into
+ * independent blocks of `rows_j` grid rows along y (a multiple of 8) by zeroing the Aj coupling across the block faces --
+ * the block-Jacobi form the z-slab solver already uses across slabs.  The sweeps then skip the hand-off across those
+ * faces (the values exchanged there are multiplied by 0 anyway), which shortens the dependency chain.  The arithmetic
+ * is unchanged: results equal the serial sweep with the same (cut) coefficients bit for bit.  0 = off (default). */
+int mf_set_mic_blocking(int rows_j);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise grid ops used inside the CG loop and by scenes

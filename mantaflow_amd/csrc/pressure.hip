@@ -1074,7 +1074,7 @@ struct RowsChunk {
 constexpr int ROWS_THREADS = 384;   // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the faces
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(ROWS_THREADS)
-k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
+k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
@@ -1117,8 +1117,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 		// face granules: per bundle and face an array [producer step h + 2][face lane]: the 8 face lanes of one step (one
 		// store instruction) fill exactly one 64-byte line, and a consumer lane's 8-step window maps to 8 consecutive lines
 		// (lane (7,c) publishes x' at step x'+7+c, lane (b,7) at x'+b+7: the same steps 8m+5 .. 8m+12 for every face lane)
-		const bool has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
-		const bool has_sj = (tjl + 1 < nbj) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
+		// jb = bundles per independent j-block (mf_set_mic_blocking: the caller has zeroed the Aj coupling across block
+		// faces, so nothing crosses them); jb == nbj: one block = the reference algorithm
+		const int tj_pred = REV ? tj + 1 : tj - 1, tj_succ = REV ? tj - 1 : tj + 1;
+		const bool has_pj = (tjl > 0) && (tj / jb == tj_pred / jb) && (b == 0), has_pk = (tkl > 0) && (c == 0);
+		const bool has_sj = (tjl + 1 < nbj) && (tj / jb == tj_succ / jb) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
 		const int64_t sid = (int64_t)tkl * nbj + tjl;
 		const int64_t XP = X8 + 2 * ROWS_PAD;
 		if (wave == 5) {
@@ -1356,7 +1359,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int nstreams, int nchunks, const int* __rest
 struct FlowState {
 	int nti = 0, ntj = 0, ntk = 0, ntiles = 0;
 	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;   // streaming form
-	int* border = nullptr;
+	int* border = nullptr;       // ticket order of the forward sweep, then of the backward sweep (nblocks entries each)
+	int jb = 0;                  // bundles per j-block the order was built for
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
@@ -1419,29 +1423,39 @@ static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st, bool need
 	*out = &f;
 	return 0;
 }
+static thread_local int g_mic_jblock_rows = 0;   // mf_set_mic_blocking
 static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
 	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8, nchunks = (d.sx + 7) / 8;
 	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC bundle order table");
+	int jb = g_mic_jblock_rows > 0 ? g_mic_jblock_rows / 8 : nbj;
+	if (jb < 1 || jb > nbj) jb = nbj;
 	if (!f.ctl) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 	}
-	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks) {
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb) {
 		MF_HIP(hipStreamSynchronize(st));
 		const int nb = nbj * nbk;
-		int* h = (int*)malloc(sizeof(int) * nb);
-		int q = 0;
-		for (int L = 0; L <= nbj + nbk - 2; L++)
-			for (int bk = 0; bk < nbk; bk++) {
-				const int bj = L - bk;
-				if (bj >= 0 && bj < nbj) h[q++] = bj | (bk << 16);
-			}
+		int* h = (int*)malloc(sizeof(int) * 2 * nb);
+		// tickets in topological order of each sweep: key = position of the bundle inside its j-block along the sweep
+		// direction + tkl (anti-diagonals of the block-local dependency graph)
+		for (int rev = 0; rev < 2; rev++) {
+			int q = 0;
+			for (int L = 0; L <= nbj + nbk - 2; L++)
+				for (int bk = 0; bk < nbk; bk++)
+					for (int bjl = 0; bjl < nbj; bjl++) {
+						const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
+						const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
+						const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
+						if (posj + bk == L) h[rev * nb + q++] = bjl | (bk << 16);
+					}
+		}
 		if (f.border) MF_HIP(hipFree(f.border));
-		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * nb));
-		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * nb, hipMemcpyHostToDevice));
+		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * 2 * nb));
+		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * 2 * nb, hipMemcpyHostToDevice));
 		free(h);
 		// one granule per (bundle, x', face lane) and face
 		const size_t need = (size_t)nb * 8 * (8 * (size_t)nchunks + 2 * ROWS_PAD) * sizeof(unsigned long long);
@@ -1460,6 +1474,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		f.nbk = nbk;
 		f.nblocks = nb;
 		f.nchunks = nchunks;
+		f.jb = jb;
 	}
 	*out = &f;
 	return 0;
@@ -1477,6 +1492,11 @@ extern "C" int mf_set_mic_mode(const char* name) {
 	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
 	else if (!strcmp(name, "rows")) g_mic_mode = 2;
 	else return fail("mf_set_mic_mode: unknown mode (rows | tiles | levels)");
+	return 0;
+}
+extern "C" int mf_set_mic_blocking(int rows_j) {
+	if (rows_j < 0 || (rows_j % 8) != 0) return fail("mf_set_mic_blocking: rows must be a non-negative multiple of 8");
+	g_mic_jblock_rows = rows_j;
 	return 0;
 }
 static int mic_mode() {
@@ -1528,9 +1548,9 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				}
 			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->nblocks, f->nchunks, f->border, f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
 			MF_LAUNCH_CHECK();
 			if (trace) {
 				static int printed = 0;

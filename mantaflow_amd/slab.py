@@ -29,6 +29,9 @@ from . import core
 from .core import _ptr
 
 
+MIC_BLOCK_ROWS = 64   # y-extent of a preconditioner block when the domain is split over several ranks (0 = do not cut)
+
+
 def _off(t, nelem):
     return ctypes.c_void_p(t.data_ptr() + 4 * int(nelem))
 
@@ -209,6 +212,17 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         av[dom.gl - 1] = 0
     if dom.gu:
         av[dom.gl + dom.nown - 1] = 0
+    # with more than one rank the preconditioner is block-Jacobi anyway: also cut it into blocks of MIC_BLOCK_ROWS rows
+    # along y, so that the sweeps of a (thin) slab are not one long dependency chain through all of y
+    Ajm = Aj
+    jblock = 0
+    if dom.comm.world > 1 and MIC_BLOCK_ROWS > 0 and sy >= 2 * MIC_BLOCK_ROWS:
+        jblock = MIC_BLOCK_ROWS
+        Ajm = G(s)
+        Ajm.copyFrom(Aj)
+        ajv = Ajm.data.view(sz, sy, sx)
+        for jc in range(jblock, sy, jblock):
+            ajv[:, jc - 1, :] = 0
     # rhs must vanish outside the owned planes for the local sweeps to be well defined
     rv = rhs.data.view(sz, XY)
     if dom.gl:
@@ -229,14 +243,15 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         lib.call("mf_grid_dot_dev", nown, _off(a.data, off), _off(b.data, off), ctypes.c_void_p(red.data_ptr() + 8 * slot), st)
 
     def mic(dst, src):
-        lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Ai.ptr, Aj.ptr, Akm.ptr, st)
+        lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Ai.ptr, Ajm.ptr, Akm.ptr, st)
 
+    lib.call("mf_set_mic_blocking", jblock)
     # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather
     # whose rows are combined in rank order; the host looks at one number per iteration (the stopping test).
     # doInit, conjugategrad.cpp:210-235
     pressure.clear()
     residual.copyFrom(rhs)
-    lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Akm.ptr, st)
+    lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Ai.ptr, Ajm.ptr, Akm.ptr, st)
     mic(tmp, residual)
     search.copyFrom(tmp)
     dot_into(tmp, residual, 1)
@@ -266,6 +281,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         sigma = sigmaNew
         if not (resNorm < 1e35):
             raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
+    lib.call("mf_set_mic_blocking", 0)
     if stats is not None:
         stats["iterations"], stats["residual"] = iters, float(resNorm)
     dom.exchange(pressure, 1)

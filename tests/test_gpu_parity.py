@@ -114,6 +114,28 @@ def test_mic_every_sweep_mode(hip, oracle, dims, mode):
     _close(x, xo, "cg solution " + mode)
 
 
+@pytest.mark.parametrize("dims,rows", [((32, 64, 24), 16), ((24, 100, 40), 32), ((40, 72, 17), 24)])
+def test_mic_blocked_sweeps_equal_serial_sweep_of_cut_system(hip, oracle, dims, rows):
+    """mf_set_mic_blocking (multi-GPU block-Jacobi in y): with the Aj coupling zeroed at the block faces the row-streaming
+    sweeps skip those hand-offs and still give the bits of the serial sweep over the same cut coefficients"""
+    sx, sy, sz = dims
+    flags, A, src = cases.system_inputs(dims, 7)
+    A = [a.copy() for a in A]
+    for jc in range(rows, sy, rows):
+        A[2][:, jc - 1, :] = 0          # Aj couples rows j and j+1
+    ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
+    assert hip.lib.cdll.mf_set_mic_blocking(rows) == 0
+    try:
+        ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
+        ap2, dst2 = cases.run_mic_impl(hip, dims, flags, A, src)
+    finally:
+        assert hip.lib.cdll.mf_set_mic_blocking(0) == 0
+    assert_bitexact(ap, ap_o, "Aprecond (cut)")
+    assert_bitexact(dst, dst_o, "blocked mic apply")
+    assert_bitexact(dst, dst2, "blocked mic apply re-run")
+    assert hip.lib.cdll.mf_set_mic_blocking(12) != 0
+
+
 def test_mic_mode_rejects_unknown_name(hip):
     assert hip.lib.cdll.mf_set_mic_mode(b"diagonal") != 0
     assert b"unknown mode" in hip.lib.cdll.mf_last_error()
