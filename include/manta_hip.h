@@ -296,6 +296,12 @@ int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boun
  * ---------------------------------------------------------------------------------------------- */
 int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out_dev, void* stream);
 int mf_grid_max_abs_dev(int64_t n, const float* a, float* out_dev, void* stream);
+int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out_dev, void* stream);
+/* scalar steps of GridCg::iterate (conjugategrad.cpp:250-291) on the all-gathered per-rank pairs
+ * gathered[world][2] = {max|residual|, dot}: alpha = sigma / (Real)sum(dot) (0 if the sum is 0);
+ * beta = (Real)sum(dot) / sigma, sigma := (Real)sum(dot), res = max over ranks.  Rows are combined in rank order. */
+int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, float* alpha_dev, void* stream);
+int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev, void* stream);
 /* me += (sign * factor_dev[0]) * other, sign = +-1 */
 int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor_dev, float sign, void* stream);
 /* dst = src + factor_dev[0] * dst */

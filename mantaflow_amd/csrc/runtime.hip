@@ -229,6 +229,39 @@ __global__ void __launch_bounds__(BLOCK) k_maxabs_finish(int nb, const float* __
 	}
 }
 
+// z-slab PCG scalar steps on gathered per-rank reductions g[world][2] = {max|residual|, dot}: rows are summed / maxed in
+// rank order, so every rank computes the same bits (conjugategrad.cpp:250-291 for the formulas)
+__global__ void k_slab_alpha(const double* __restrict__ g, int world, const float* __restrict__ sigma, float* __restrict__ alpha) {
+	double acc = 0.0;
+	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
+	const float dp = (float)acc;
+	alpha[0] = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
+}
+__global__ void k_slab_beta(const double* __restrict__ g, int world, float* __restrict__ sigma, float* __restrict__ beta, float* __restrict__ res) {
+	double acc = 0.0, mx = 0.0;
+	for (int r = 0; r < world; r++) {
+		acc += g[2 * r + 1];
+		mx = g[2 * r] > mx ? g[2 * r] : mx;
+	}
+	const float sigmaNew = (float)acc;
+	res[0] = (float)mx;
+	beta[0] = sigmaNew / sigma[0];
+	sigma[0] = sigmaNew;
+}
+__global__ void __launch_bounds__(BLOCK) k_maxabs_finish64(int nb, const float* __restrict__ partials, double* __restrict__ out) {
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+		lo = fminf(lo, partials[2 * i]);
+		hi = fmaxf(hi, partials[2 * i + 1]);
+	}
+	block_minmax(lo, hi);
+	if (threadIdx.x == 0) {
+		lo = fabsf(lo);
+		hi = fabsf(hi);
+		out[0] = (double)(lo > hi ? lo : hi);
+	}
+}
+
 static int read_back(Workspace* ws, const void* dev, size_t bytes, void* host_out, hipStream_t s) {
 	MF_HIP(hipMemcpyAsync(ws->host, dev, bytes, hipMemcpyDeviceToHost, s));
 	MF_HIP(hipStreamSynchronize(s));
@@ -293,6 +326,25 @@ int mf_grid_max_abs_dev(int64_t n, const float* a, float* out_dev, void* s) {
 	const int nb = blocks_for(n, BLOCK * 8, 1024);
 	hipLaunchKernelGGL(k_minmax_partials, dim3(nb), dim3(BLOCK), 0, (hipStream_t)s, n, a, ws->fpartials);
 	hipLaunchKernelGGL(k_maxabs_finish, dim3(1), dim3(BLOCK), 0, (hipStream_t)s, nb, ws->fpartials, out_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out_dev, void* s) {
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	const int nb = blocks_for(n, BLOCK * 8, 1024);
+	hipLaunchKernelGGL(k_minmax_partials, dim3(nb), dim3(BLOCK), 0, (hipStream_t)s, n, a, ws->fpartials);
+	hipLaunchKernelGGL(k_maxabs_finish64, dim3(1), dim3(BLOCK), 0, (hipStream_t)s, nb, ws->fpartials, out_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, float* alpha_dev, void* s) {
+	hipLaunchKernelGGL(k_slab_alpha, dim3(1), dim3(1), 0, (hipStream_t)s, gathered, world, sigma_dev, alpha_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev, void* s) {
+	hipLaunchKernelGGL(k_slab_beta, dim3(1), dim3(1), 0, (hipStream_t)s, gathered, world, sigma_dev, beta_dev, res_dev);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

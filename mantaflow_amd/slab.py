@@ -233,52 +233,50 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     maxIter = int(np.float32(cgMaxIterFac) * np.float32(gmax))
 
     dev = s.device
-    red = torch.zeros(2, dtype=torch.float64, device=dev)     # [max|residual| (as fp64), dot] of this rank
-    rmax = torch.zeros(1, dtype=torch.float32, device=dev)
-    alpha = torch.zeros(1, dtype=torch.float32, device=dev)
-    beta = torch.zeros(1, dtype=torch.float32, device=dev)
-    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    world = dom.comm.world
+    red = torch.zeros(2, dtype=torch.float64, device=dev)     # {max|residual|, dot} of this rank
+    sc = torch.zeros(4, dtype=torch.float32, device=dev)      # sigma, alpha, beta, resNorm
+    p_sigma, p_alpha, p_beta, p_res = (ctypes.c_void_p(sc.data_ptr() + 4 * i) for i in range(4))
+    p_red0, p_red1 = ctypes.c_void_p(red.data_ptr()), ctypes.c_void_p(red.data_ptr() + 8)
 
-    def dot_into(a, b, slot):
-        lib.call("mf_grid_dot_dev", nown, _off(a.data, off), _off(b.data, off), ctypes.c_void_p(red.data_ptr() + 8 * slot), st)
+    def dot_own(a, b):
+        lib.call("mf_grid_dot_dev", nown, _off(a.data, off), _off(b.data, off), p_red1, st)
 
     def mic(dst, src):
         lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Ai.ptr, Ajm.ptr, Akm.ptr, st)
 
     lib.call("mf_set_mic_blocking", jblock)
-    # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather
-    # whose rows are combined in rank order; the host looks at one number per iteration (the stopping test).
+    # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather whose
+    # rows are combined in rank order by a one-thread kernel; the host reads one number per iteration (the stopping test).
     # doInit, conjugategrad.cpp:210-235
     pressure.clear()
     residual.copyFrom(rhs)
     lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Ai.ptr, Ajm.ptr, Akm.ptr, st)
     mic(tmp, residual)
     search.copyFrom(tmp)
-    dot_into(tmp, residual, 1)
-    sigma = dom.comm.allgather_dev(red)[:, 1].sum().to(torch.float32)
+    dot_own(tmp, residual)
+    sc[0] = 1.0                                                  # sigma := (Real)sum via the beta step (beta unused here)
+    g0 = dom.comm.allgather_dev(red)          # (kept referenced until the kernel that reads it has been queued behind it)
+    lib.call("mf_cg_slab_beta", _ptr(g0), world, p_sigma, p_beta, p_res, st)
     iters, resNorm = 0, 1e20
     for _ in range(maxIter):
         iters += 1
         dom.exchange(search, 1)
         lib.call("mf_apply_matrix", sx, sy, sz, flags.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)
-        dot_into(tmp, search, 1)
-        dp = dom.comm.allgather_dev(red)[:, 1].sum().to(torch.float32)
-        alpha[0] = torch.where(dp.abs() > 0, sigma / dp, zero)          # conjugategrad.cpp:252-254
-        lib.call("mf_grid_scaled_add_dev", nown, _off(pressure.data, off), _off(search.data, off), _ptr(alpha), 1.0, st)
-        lib.call("mf_grid_scaled_add_dev", nown, _off(residual.data, off), _off(tmp.data, off), _ptr(alpha), -1.0, st)
+        dot_own(tmp, search)
+        g1 = dom.comm.allgather_dev(red)
+        lib.call("mf_cg_slab_alpha", _ptr(g1), world, p_sigma, p_alpha, st)   # conjugategrad.cpp:252-254
+        lib.call("mf_grid_scaled_add_dev", nown, _off(pressure.data, off), _off(search.data, off), p_alpha, 1.0, st)
+        lib.call("mf_grid_scaled_add_dev", nown, _off(residual.data, off), _off(tmp.data, off), p_alpha, -1.0, st)
         mic(tmp, residual)
-        lib.call("mf_grid_max_abs_dev", nown, _off(residual.data, off), _ptr(rmax), st)
-        red[0] = rmax[0].to(torch.float64)
-        dot_into(tmp, residual, 1)
-        g = dom.comm.allgather_dev(red)
-        resT = g[:, 0].max().to(torch.float32)
-        sigmaNew = g[:, 1].sum().to(torch.float32)
-        resNorm = float(resT)                                             # the one host read of the iteration
+        lib.call("mf_grid_max_abs_dev_f64", nown, _off(residual.data, off), p_red0, st)
+        dot_own(tmp, residual)
+        g2 = dom.comm.allgather_dev(red)
+        lib.call("mf_cg_slab_beta", _ptr(g2), world, p_sigma, p_beta, p_res, st)
+        resNorm = float(sc[3])                                    # the one host read of the iteration
         if np.float32(resNorm) < np.float32(cgAccuracy):
             break
-        beta[0] = sigmaNew / sigma
-        lib.call("mf_update_search_vec_dev", nown, _off(search.data, off), _off(tmp.data, off), _ptr(beta), st)
-        sigma = sigmaNew
+        lib.call("mf_update_search_vec_dev", nown, _off(search.data, off), _off(tmp.data, off), p_beta, st)
         if not (resNorm < 1e35):
             raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     lib.call("mf_set_mic_blocking", 0)

@@ -2033,6 +2033,32 @@ int mf_grid_max_abs_dev(int64_t n, const float* a, float* out, void* s) {
 	*out = maxabs(n, a);
 	return 0;
 }
+int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out, void* s) {
+	(void)s;
+	*out = (double)maxabs(n, a);
+	return 0;
+}
+int mf_cg_slab_alpha(const double* g, int world, const float* sigma, float* alpha, void* s) {
+	(void)s;
+	double acc = 0.0;
+	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
+	const float dp = (float)acc;
+	alpha[0] = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
+	return 0;
+}
+int mf_cg_slab_beta(const double* g, int world, float* sigma, float* beta, float* res, void* s) {
+	(void)s;
+	double acc = 0.0, mx = 0.0;
+	for (int r = 0; r < world; r++) {
+		acc += g[2 * r + 1];
+		mx = g[2 * r] > mx ? g[2 * r] : mx;
+	}
+	const float sigmaNew = (float)acc;
+	res[0] = (float)mx;
+	beta[0] = sigmaNew / sigma[0];
+	sigma[0] = sigmaNew;
+	return 0;
+}
 int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor, float sign, void* s) {
 	return mf_grid_scaled_add(n, me, other, sign * factor[0], s);
 }
