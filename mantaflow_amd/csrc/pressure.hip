@@ -1955,12 +1955,20 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_sig, accuracy, useL2Norm);
 	MF_LAUNCH_CHECK();
 
-	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done` ----
-	const int batch = (pc == MF_PC_MICP) ? 1 : 4;
+	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done`, one batch behind the batch it has just queued
+	// (every kernel of an iteration returns at once when `done` is already set, so running ahead costs a few empty
+	// launches after convergence and keeps the GPU from idling between iterations) ----
+	const int batch = (pc == MF_PC_MICP && mic_mode() == 0) ? 1 : 4;
 	CgScalars h;
 	memset(&h, 0, sizeof h);
 	h.resNorm = 1e20f;
-	int issued = 0;
+	static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+	if (!ev[0]) {
+		MF_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+		MF_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+	}
+	CgScalars* hslot = (CgScalars*)ws->host;   // two pinned slots
+	int issued = 0, slot = 0, pending = -1;
 	while (issued < maxIter) {
 		const int todo = (maxIter - issued < batch) ? (maxIter - issued) : batch;
 		for (int it = 0; it < todo; it++) {
@@ -1981,11 +1989,20 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 		}
 		MF_LAUNCH_CHECK();
 		issued += todo;
-		MF_HIP(hipMemcpyAsync(ws->host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
-		MF_HIP(hipStreamSynchronize(st));
-		memcpy(&h, ws->host, sizeof h);
-		if (h.done) break;
+		MF_HIP(hipMemcpyAsync(&hslot[slot], sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipEventRecord(ev[slot], st));
+		if (pending >= 0) {
+			MF_HIP(hipEventSynchronize(ev[pending]));
+			memcpy(&h, &hslot[pending], sizeof h);
+			if (h.done) break;
+		}
+		pending = slot;
+		slot ^= 1;
 	}
+	// the final state, after everything that was queued
+	MF_HIP(hipMemcpyAsync(&hslot[0], sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	memcpy(&h, &hslot[0], sizeof h);
 	if (maxIter <= 0) {
 		MF_HIP(hipMemcpyAsync(ws->host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 		MF_HIP(hipStreamSynchronize(st));
