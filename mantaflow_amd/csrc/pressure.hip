@@ -838,6 +838,12 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, float v, un
 	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// same-XCD hand-off: a plain store reaches that XCD's L2, where an agent-scope (sc1) load of another CU of the same XCD
+// finds it (0.26 us one way vs 0.72 us for sc1 -> sc1 across XCDs, tools/micro/pingpong.hip); NOT visible to other XCDs
+__device__ __forceinline__ void granule_store_local(unsigned long long* p, float v, unsigned tag) {
+	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 constexpr int FLOW_SPIN_LIMIT = 1 << 21;
 
 template <int MODE, bool VEC>
@@ -1074,7 +1080,7 @@ struct RowsChunk {
 constexpr int ROWS_THREADS = 384;   // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the faces
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(ROWS_THREADS)
-k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl,
+k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
@@ -1098,7 +1104,17 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 
 	for (;;) {
 		if (threadIdx.x == 0) {
-			s_ticket = atomicAdd(&ctl->ticket, 1);
+			// xt[0..7] tickets, xt[8..16] bounds of the per-XCD queues inside `order`, xt[17] = number of queues (1: one
+			// global queue; 8: bundles are queued per XCD by k-slab, so that most faces are handed over inside one XCD's L2)
+			const int nq = xt[17];
+			const int q = nq > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;   // HW_REG_XCC_ID
+			const int lo = xt[8 + q], hi = xt[9 + q];
+			int tk = nstreams;
+			if (lo < hi) {
+				const int tl = atomicAdd(&xt[q], 1);
+				if (lo + tl < hi) tk = lo + tl;
+			}
+			s_ticket = tk;
 			s_ready[0] = s_ready[1] = s_ready[2] = 0;
 			s_done = 0;
 			s_flushed = 0;
@@ -1265,8 +1281,12 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
 			}
 #define ROWS_TRACE(i) if (tr) trb[m * 4 + (i)] = wall_clock64();
-			auto block = [&](int m, auto edge_tag) {
+			// plain (XCD-local) face stores only when every consumer of this bundle's faces runs on this XCD
+			const int nq_ = xt[17];
+			const bool local_faces = nq_ > 1 && ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk));
+			auto block = [&](int m, auto edge_tag, auto local_tag) {
 				constexpr bool EDGE = decltype(edge_tag)::value;
+				constexpr bool LOCAL = decltype(local_tag)::value;
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
 				ROWS_TRACE(0)
 				if (m < nchunks) {
@@ -1326,7 +1346,10 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					if (valid) sA[row].x = val;
 					if (face_lane) {
 						const bool fvalid = !EDGE || ((unsigned)(xq + s + fskew) < (unsigned)X8);
-						if (fvalid) granule_store(pf + s * 8, fv, gen);
+						if (fvalid) {
+							if (LOCAL) granule_store_local(pf + s * 8, fv, gen);
+							else granule_store(pf + s * 8, fv, gen);
+						}
 					}
 				}
 				// LDS-only release: the block's granule stores need not have been acknowledged before the next block starts
@@ -1337,8 +1360,14 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 #pragma unroll 1
 			for (int m = 0; m <= nchunks + 1; m++) {
 				// interior: every lane's x' is inside [0, X8) for all 8 steps of the block
-				if (m >= 2 && m <= nchunks - 1) block(m, std::false_type{});
-				else block(m, std::true_type{});
+				const bool interior = (m >= 2 && m <= nchunks - 1);
+				if (local_faces) {
+					if (interior) block(m, std::false_type{}, std::true_type{});
+					else block(m, std::true_type{}, std::true_type{});
+				} else {
+					if (interior) block(m, std::false_type{}, std::false_type{});
+					else block(m, std::true_type{}, std::false_type{});
+				}
 			}
 			if (trace && lane == 0 && t < 4096) trace[4 * 4096 + 2 * t + 1] = wall_clock64();
 #undef ROWS_TRACE
@@ -1349,7 +1378,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	if (threadIdx.x == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
 		if (f == (int)gridDim.x - 1) {
-			ctl->ticket = 0;
+			for (int q = 0; q < 8; q++) xt[q] = 0;
 			ctl->finished = 0;
 		}
 	}
@@ -1361,6 +1390,8 @@ struct FlowState {
 	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;   // streaming form
 	int* border = nullptr;       // ticket order of the forward sweep, then of the backward sweep (nblocks entries each)
 	int jb = 0;                  // bundles per j-block the order was built for
+	int nq = 0;                  // ticket queues (1 or 8)
+	int* rows_xt = nullptr;      // [2][18]: tickets, queue bounds, queue count -- forward sweep, backward sweep
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
@@ -1423,6 +1454,28 @@ static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st, bool need
 	*out = &f;
 	return 0;
 }
+// per-XCD ticket queues rely on workgroup b running on XCD b % 8 (round-robin dispatch, verified once per process)
+__global__ void k_probe_xcc(int* out) {
+	if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
+}
+static bool xcd_round_robin_ok() {
+	static int state = -1;
+	if (state < 0) {
+		state = 0;
+		int* dbuf = nullptr;
+		int hbuf[64];
+		if (hipMalloc((void**)&dbuf, sizeof hbuf) == hipSuccess) {
+			hipLaunchKernelGGL(k_probe_xcc, dim3(64), dim3(64), 0, 0, dbuf);
+			if (hipMemcpy(hbuf, dbuf, sizeof hbuf, hipMemcpyDeviceToHost) == hipSuccess) {
+				state = 1;
+				for (int b = 0; b < 64; b++)
+					if (hbuf[b] != (b & 7)) state = 0;
+			}
+			(void)hipFree(dbuf);
+		}
+	}
+	return state == 1;
+}
 static thread_local int g_mic_jblock_rows = 0;   // mf_set_mic_blocking
 static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	int dev = 0;
@@ -1432,27 +1485,41 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC bundle order table");
 	int jb = g_mic_jblock_rows > 0 ? g_mic_jblock_rows / 8 : nbj;
 	if (jb < 1 || jb > nbj) jb = nbj;
+	static const int use_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : 0;
+	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
 	if (!f.ctl) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 	}
-	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb) {
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != nq) {
 		MF_HIP(hipStreamSynchronize(st));
 		const int nb = nbj * nbk;
 		int* h = (int*)malloc(sizeof(int) * 2 * nb);
+		int xt[2][18];
+		memset(xt, 0, sizeof xt);
 		// tickets in topological order of each sweep: key = position of the bundle inside its j-block along the sweep
-		// direction + tkl (anti-diagonals of the block-local dependency graph)
+		// direction + tkl (anti-diagonals of the block-local dependency graph); one queue per XCD = k-slab of bundles
 		for (int rev = 0; rev < 2; rev++) {
 			int q = 0;
-			for (int L = 0; L <= nbj + nbk - 2; L++)
-				for (int bk = 0; bk < nbk; bk++)
-					for (int bjl = 0; bjl < nbj; bjl++) {
-						const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
-						const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
-						const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
-						if (posj + bk == L) h[rev * nb + q++] = bjl | (bk << 16);
-					}
+			for (int x = 0; x < 8; x++) {
+				xt[rev][8 + x] = q;
+				if (x < nq)
+					for (int L = 0; L <= nbj + nbk - 2; L++)
+						for (int bk = 0; bk < nbk; bk++) {
+							if ((bk * nq) / nbk != x) continue;
+							for (int bjl = 0; bjl < nbj; bjl++) {
+								const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
+								const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
+								const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
+								if (posj + bk == L) h[rev * nb + q++] = bjl | (bk << 16);
+							}
+						}
+			}
+			xt[rev][16] = q;
+			xt[rev][17] = nq;
 		}
+		if (!f.rows_xt) MF_HIP(hipMalloc((void**)&f.rows_xt, sizeof(xt)));
+		MF_HIP(hipMemcpy(f.rows_xt, xt, sizeof(xt), hipMemcpyHostToDevice));
 		if (f.border) MF_HIP(hipFree(f.border));
 		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * 2 * nb));
 		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * 2 * nb, hipMemcpyHostToDevice));
@@ -1475,6 +1542,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		f.nblocks = nb;
 		f.nchunks = nchunks;
 		f.jb = jb;
+		f.nq = nq;
 	}
 	*out = &f;
 	return 0;
@@ -1548,9 +1616,9 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				}
 			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
 			MF_LAUNCH_CHECK();
 			if (trace) {
 				static int printed = 0;
