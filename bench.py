@@ -200,7 +200,26 @@ def main():
                               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "avg_launch_us": round(us.value, 2),
                               "algorithmic_bytes_per_launch": APPLY_MATRIX_BYTES_PER_CELL * n ** 3}
-        del A0, Ai, Aj, Ak, src, dst
+        # ---- the kernel that takes most of the step: the two MIC(0) substitution sweeps (conjugategrad.cpp:135-159).
+        # forward reads flags, rhs, Ai, Aj, Ak, Aprecond, dst and writes dst (32 B/cell), backward does not read rhs (28 B/cell)
+        ap = core.Grid(s)
+        lib.call("mf_mic_init", n, n, n, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        for _ in range(3):
+            lib.call("mf_mic_apply", n, n, n, flags.ptr, dst.ptr, src.ptr, ap.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        for _ in range(50):
+            lib.call("mf_mic_apply", n, n, n, flags.ptr, dst.ptr, src.ptr, ap.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        e1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        mic_us = e0.elapsed_time(e1) * 1e3 / 50
+        mic_bytes = 60 * n ** 3
+        result["roofline_mic"] = {"kernel": "k_mic_rows<1> + k_mic_rows<2> (ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159)",
+                                  "bound": "dependency chain (serial sweep in the reference), hbm if it were free",
+                                  "achieved": round(mic_bytes / (mic_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(mic_bytes / (mic_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_apply_us": round(mic_us, 1),
+                                  "algorithmic_bytes_per_apply": mic_bytes}
+        del A0, Ai, Aj, Ak, src, dst, ap
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline((n, n, max(16, n // 4)), v_np, d_np, None, dt)
 
@@ -223,6 +242,8 @@ def main():
         }
         if "roofline" in result:
             line["roofline"] = result["roofline"]
+        if "roofline_mic" in result:
+            line["roofline_mic"] = result["roofline_mic"]
         if "cpu_baseline" in result:
             line["cpu_baseline"] = result["cpu_baseline"]
         if "notes" in result:
