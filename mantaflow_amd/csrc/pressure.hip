@@ -1989,6 +1989,22 @@ int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const
 	return launch_mic<2>(d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
 }
 
+// a dataflow sweep that gives up waiting for a face (FLOW_SPIN_LIMIT) latches an error flag on the device; mf_cg_solve
+// looks at it itself, callers that drive mf_mic_apply directly (the z-slab solver) ask here once per solve
+int mf_mic_check(void* stream) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	if (!g_flow[dev].ctl) return 0;
+	MF_HIP(hipStreamSynchronize((hipStream_t)stream));
+	FlowCtl fc;
+	MF_HIP(hipMemcpy(&fc, g_flow[dev].ctl, sizeof fc, hipMemcpyDeviceToHost));
+	if (fc.err) {
+		MF_HIP(hipMemset(g_flow[dev].ctl, 0, sizeof(FlowCtl)));
+		return fail("MIC dataflow sweep: a workgroup timed out waiting for its predecessor faces");
+	}
+	return 0;
+}
+
 int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual, float* search,
                 float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak, float* Aprecond, int pc,
                 float accuracy, int maxIter, int useL2Norm, float* out_host, void* stream) {

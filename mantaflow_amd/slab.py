@@ -280,6 +280,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         if not (resNorm < 1e35):
             raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     lib.call("mf_set_mic_blocking", 0)
+    lib.call("mf_mic_check", st)
     if stats is not None:
         stats["iterations"], stats["residual"] = iters, float(resNorm)
     dom.exchange(pressure, 1)

@@ -39,6 +39,10 @@ typedef struct {
 	int64_t X, Y, Z, n; /* strides (Z == 0 in 2-D, grid.cpp:56) */
 } Dim;
 static _Thread_local int g_slab_zoff = 0, g_slab_gsz = 0;
+int mf_mic_check(void* stream) {
+	(void)stream;
+	return 0;
+}
 int mf_set_mic_blocking(int rows_j) {
 	(void)rows_j;
 	return 0;
