@@ -294,6 +294,18 @@ int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_
 int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boundaryWidth, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * "next" rows: resampling between grids of different size (wavelet-turbulence up-res helpers)
+ * ---------------------------------------------------------------------------------------------- */
+/* interpolateGrid / interpolateGridVec3 -> knInterpolateGridTempl, grid.h:576-581, plugin/waveletturbulence.cpp:37-56
+ * (orderSpace 1).  target(i,j,k) = source.getInterpolated(Vec3(i,j,k) * sourceFactor + offset); ncomp 1|3 (SoA planes);
+ * sourceFactor / offset are the values calcGridSizeFactorMod (:27-34) produces. */
+int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
+                        float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream);
+/* interpolateMACGrid -> KnInterpolateMACGrid, plugin/waveletturbulence.cpp:59-78: component c sampled at pos - 0.5 e_c */
+int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
+                            float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * device-scalar variants for the multi-GPU PCG (no reference counterpart: same arithmetic as mf_grid_dot /
  * mf_grid_max_abs / mf_grid_scaled_add / mf_update_search_vec, but the scalar results and factors live in device
  * memory, so a rank never waits for the host between a reduction, its all-gather and the update that uses it)

@@ -8,7 +8,8 @@ from .plugins import (Timings, extrapolateMACFromWeight, extrapolateMACSimple, m
                       correctVelocity, flipVelocityUpdate, lastCgStats, mapGridToParts, mapGridToPartsVec3, mapMACToParts,
                       mapPartsToGrid, mapPartsToGridVec3, mapPartsToMAC, setDeterministicP2G, setWallBcs, solvePressure,
                       solvePressureSystem, pushOutofObs, gridParticleIndex, unionParticleLevelset, extrapolateLsSimple,
-                      setPartType, markIsolatedFluidCell, addForcePvel, updateVelocityFromDeltaPos, eulerStep)
+                      setPartType, markIsolatedFluidCell, addForcePvel, updateVelocityFromDeltaPos, eulerStep,
+                      interpolateGrid, interpolateGridVec3, interpolateMACGrid)
 
 from .scene import (Box, Cylinder, Gui, NoiseField, Shape, Sphere, densityInflow, sampleFlagsWithParticles,
                     sampleLevelsetWithParticles, sampleShapeWithParticles)

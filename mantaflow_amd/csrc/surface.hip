@@ -279,7 +279,56 @@ k_ls_subtract(int64_t n, float* __restrict__ a, const float* __restrict__ b, con
 	if (b[i] < 0.) a[i] = b[i] * -1.f;
 }
 
+// knInterpolateGridTempl (grid.h:576-581) / KnInterpolateMACGrid (waveletturbulence.cpp:59-71): one thread per target cell
+template <bool MAC>
+__global__ void __launch_bounds__(BLOCK)
+k_interpolate_grid(Dim t, float* __restrict__ target, Dim s, const float* __restrict__ source, int ncomp, float sfx, float sfy, float sfz,
+                   float ox, float oy, float oz) {
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (idx >= t.n) return;
+	const int i = (int)(idx % t.sx), j = (int)((idx / t.sx) % t.sy), k = (int)(idx / ((int64_t)t.sx * t.sy));
+	const float px = (float)i * sfx + ox, py = (float)j * sfy + oy;
+	float pz = (float)k * sfz + oz;
+	if (MAC) {
+		// MACGrid::getInterpolatedHi -> interpolMAC (grid.h:269-275); one component of each evaluation is kept
+		float vx, vy, vz;
+		interpol_mac(s, source, px - 0.5f, py, pz, vx, vy, vz);
+		target[idx] = vx;
+		interpol_mac(s, source, px, py - 0.5f, pz, vx, vy, vz);
+		target[t.n + idx] = vy;
+		if (s.is3d) {
+			interpol_mac(s, source, px, py, pz - 0.5f, vx, vy, vz);
+			target[2 * t.n + idx] = vz;
+		} else {
+			target[2 * t.n + idx] = 0.f;
+		}
+	} else {
+		if (!s.is3d) pz = 0.f;
+		for (int c = 0; c < ncomp; c++) target[c * t.n + idx] = interpol1(s, source + c * s.n, px, py, pz);
+	}
+}
+
 extern "C" {
+
+int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
+                        float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream) {
+	MF_TRY(check_dim(tsx, tsy, tsz));
+	MF_TRY(check_dim(ssx, ssy, ssz));
+	if (ncomp != 1 && ncomp != 3) return fail("ncomp must be 1 or 3");
+	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	hipLaunchKernelGGL((k_interpolate_grid<false>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, ncomp, sfx, sfy, sfz, ox, oy, oz);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
+                            float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream) {
+	MF_TRY(check_dim(tsx, tsy, tsz));
+	MF_TRY(check_dim(ssx, ssy, ssz));
+	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	hipLaunchKernelGGL((k_interpolate_grid<true>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, 3, sfx, sfy, sfz, ox, oy, oz);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
 
 int mf_project_out_of_bnd(int sx, int sy, int sz, int64_t np, int64_t pstride, float* pos, const int32_t* pflag, float bnd, int axis,
                           const int32_t* ptype, int exclude, void* stream) {

@@ -464,6 +464,57 @@ def eulerStep(parts, vel, ptype, exclude):
 
 
 # =========================================================================================================
+# resampling between grids of different size (plugin/waveletturbulence.cpp:27-78)
+# =========================================================================================================
+def _size_factor(source, target, scale, offset, size):
+    """calcGridSizeFactorMod, waveletturbulence.cpp:27-34 (fp32 Vec3 arithmetic)"""
+    f32 = np.float32
+    scale, offset = _to_vec3(scale), _to_vec3(offset)
+    s1 = (source.sx, source.sy, source.sz)
+    s2 = [target.sx, target.sy, target.sz]
+    if size is not None:
+        size = tuple(int(v) for v in (size if not isinstance(size, vec3) else (size.x, size.y, size.z)))
+        for c in range(3):
+            if size[c] > 0:
+                s2[c] = size[c]
+    sf = [f32(f32(f32(s1[c]) / f32(s2[c])) / f32((scale.x, scale.y, scale.z)[c])) for c in range(3)]
+    off = [f32(f32(f32(-f32((offset.x, offset.y, offset.z)[c])) * sf[c]) + f32(sf[c] * f32(0.5))) for c in range(3)]
+    return [float(v) for v in sf], [float(v) for v in off]
+
+
+def _interpolate(target, source, scale, offset, size, orderSpace, ncomp):
+    if int(orderSpace) != 1:
+        raise RuntimeError("interpolateGrid: orderSpace=2 (cubic) is outside the hot path")
+    sf, off = _size_factor(source, target, scale, offset, size)
+    s = target.parent
+    s.lib.call("mf_interpolate_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz, source.ptr,
+               ncomp, sf[0], sf[1], sf[2], off[0], off[1], off[2], s.stream)
+
+
+@plugin
+def interpolateGrid(target, source, scale=vec3(1.), offset=vec3(0.), size=None, orderSpace=1):
+    _chk(target, Grid, "Grid<Real>"); _chk(source, Grid, "Grid<Real>")
+    _interpolate(target, source, scale, offset, size, orderSpace, 1)
+
+
+@plugin
+def interpolateGridVec3(target, source, scale=vec3(1.), offset=vec3(0.), size=None, orderSpace=1):
+    _chk(target, VecGrid, "Grid<Vec3>"); _chk(source, VecGrid, "Grid<Vec3>")
+    _interpolate(target, source, scale, offset, size, orderSpace, 3)
+
+
+@plugin
+def interpolateMACGrid(target, source, scale=vec3(1.), offset=vec3(0.), size=None, orderSpace=1):
+    _chk(target, MACGrid, "MACGrid"); _chk(source, MACGrid, "MACGrid")
+    if int(orderSpace) != 1:
+        raise RuntimeError("interpolateMACGrid: orderSpace=2 (cubic) is outside the hot path")
+    sf, off = _size_factor(source, target, scale, offset, size)
+    s = target.parent
+    s.lib.call("mf_interpolate_mac_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz,
+               source.ptr, sf[0], sf[1], sf[2], off[0], off[1], off[2], s.stream)
+
+
+# =========================================================================================================
 # glue (SURVEY 8f-1)
 # =========================================================================================================
 @plugin

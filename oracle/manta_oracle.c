@@ -2026,6 +2026,46 @@ int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_
 	return 0;
 }
 
+/* knInterpolateGridTempl, grid.h:576-581 */
+int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
+                        float sfx, float sfy, float sfz, float ox, float oy, float oz, void* st) {
+	(void)st;
+	Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	for (int k = 0; k < tsz; k++)
+		for (int j = 0; j < tsy; j++)
+			for (int i = 0; i < tsx; i++) {
+				float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)k * sfz + oz;
+				if (!s.is3d) pz = 0.f;
+				for (int c = 0; c < ncomp; c++) target[c * t.n + IDX(t, i, j, k)] = interpol1(&s, source + c * s.n, px, py, pz);
+			}
+	return 0;
+}
+/* KnInterpolateMACGrid, plugin/waveletturbulence.cpp:59-71 */
+int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
+                            float sfx, float sfy, float sfz, float ox, float oy, float oz, void* st) {
+	(void)st;
+	Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	for (int k = 0; k < tsz; k++)
+		for (int j = 0; j < tsy; j++)
+			for (int i = 0; i < tsx; i++) {
+				const float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)k * sfz + oz;
+				const int64_t idx = IDX(t, i, j, k);
+				/* MACGrid::getInterpolatedHi -> interpolMAC (grid.h:269-275), one component of each evaluation is kept */
+				float v[3];
+				interpol_mac(&s, source, px - 0.5f, py, pz, v);
+				target[idx] = v[0];
+				interpol_mac(&s, source, px, py - 0.5f, pz, v);
+				target[t.n + idx] = v[1];
+				if (s.is3d) {
+					interpol_mac(&s, source, px, py, pz - 0.5f, v);
+					target[2 * t.n + idx] = v[2];
+				} else {
+					target[2 * t.n + idx] = 0.f;
+				}
+			}
+	return 0;
+}
+
 /* device-scalar variants (here: host pointers) */
 int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out, void* s) {
 	(void)s;

@@ -90,6 +90,9 @@ void updateVelocityFromDeltaPos(const BasicParticleSystem& parts, ParticleDataIm
                                 const int exclude);                                                       // ptsplugins.cpp:38
 void eulerStep(BasicParticleSystem& parts, const ParticleDataImpl<Vec3>& vel, const ParticleDataImpl<int>* ptype,
                const int exclude);                                                                        // ptsplugins.cpp:50
+void interpolateGrid(Grid<Real>& target, const Grid<Real>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);      // waveletturbulence.cpp:37
+void interpolateGridVec3(Grid<Vec3>& target, const Grid<Vec3>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);  // :51
+void interpolateMACGrid(MACGrid& target, const MACGrid& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);         // :73
 }  // namespace Manta
 
 using namespace Manta;
@@ -750,6 +753,26 @@ int ref_grid_file(int sx, int sy, int sz, int kind, int write, const char* name,
 		case 2: uni_io<Grid<Vec3>, Vec3>(c, write, name, data, c.n); break;
 		case 3: uni_io<MACGrid, Vec3>(c, write, name, data, c.n); break;
 		default: uni_io<LevelsetGrid, Real>(c, write, name, data, c.n); break;
+	}
+	SHIM_CATCH
+}
+
+/* interpolateGrid / interpolateGridVec3 / interpolateMACGrid, plugin/waveletturbulence.cpp:37-78.  kind 0 Real, 1 Vec3, 2 MAC */
+int ref_interpolate_grid(int kind, int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
+                         float scx, float scy, float scz, float ox, float oy, float oz, int zx, int zy, int zz) {
+	SHIM_TRY
+	Ctx ct(tsx, tsy, tsz, 1.f), cs(ssx, ssy, ssz, 1.f);
+	const Vec3 scale(scx, scy, scz), off(ox, oy, oz);
+	const Vec3i size(zx, zy, zz);
+	if (kind == 0) {
+		RealRef t(ct, target), s(cs, source);
+		interpolateGrid(t.ref(), s.ref(), scale, off, size, 1);
+	} else if (kind == 1) {
+		Vec3IO t(ct, target, true), s(cs, source, false);
+		interpolateGridVec3(t.g, s.g, scale, off, size, 1);
+	} else {
+		MacIO t(ct, target, true), s(cs, source, false);
+		interpolateMACGrid(t.g, s.g, scale, off, size, 1);
 	}
 	SHIM_CATCH
 }

@@ -605,6 +605,48 @@ def run_dam_pkg(res, steps, deterministic=True):
                 dt=float(s.timestep))
 
 
+# ---- resampling between grids of different size ----
+INTERP_CASES = [  # (source dims, target dims, scale, offset, size)
+    ((10, 8, 6), (20, 16, 12), (1., 1., 1.), (0., 0., 0.), None),
+    ((16, 12, 10), (9, 7, 5), (1., 1., 1.), (0., 0., 0.), None),
+    ((12, 9, 7), (17, 13, 10), (1.5, 0.75, 1.25), (0.5, -1.0, 0.25), (20, -1, 12)),
+    ((14, 10, 1), (21, 15, 1), (1., 1., 1.), (0., 0., 0.), None),
+]
+
+
+def run_interp_pkg(sd, td, scale, offset, size, fields):
+    from mantaflow_amd import core, plugins
+    ss, ts = _mk_solver(sd), _mk_solver(td)
+    kw = dict(scale=core.vec3(*scale), offset=core.vec3(*offset))
+    if size is not None:
+        kw["size"] = size
+    out = {}
+    g = core.Grid(ts)
+    plugins.interpolateGrid(g, soa_to_grid(core.Grid(ss), fields["real"]), **kw)
+    out["real"] = grid_to_soa(g)
+    g = core.VecGrid(ts)
+    plugins.interpolateGridVec3(g, soa_to_grid(core.VecGrid(ss), fields["vec"]), **kw)
+    out["vec"] = grid_to_soa(g)
+    g = core.MACGrid(ts)
+    plugins.interpolateMACGrid(g, soa_to_grid(core.MACGrid(ss), fields["vec"]), **kw)
+    out["mac"] = grid_to_soa(g)
+    ts.sync()
+    return out
+
+
+def run_interp_ref(sd, td, scale, offset, size, fields):
+    cf = ctypes.c_float
+    zs = size if size is not None else (-1, -1, -1)
+    out = {}
+    for kind, key, src in ((0, "real", fields["real"]), (1, "vec", fields["vec"]), (2, "mac", fields["vec"])):
+        shape = (td[2], td[1], td[0]) if kind == 0 else (3, td[2], td[1], td[0])
+        t = np.zeros(shape, np.float32)
+        refcall("ref_interpolate_grid", kind, td[0], td[1], td[2], t, sd[0], sd[1], sd[2], src, cf(scale[0]), cf(scale[1]), cf(scale[2]),
+                cf(offset[0]), cf(offset[1]), cf(offset[2]), zs[0], zs[1], zs[2])
+        out[key] = t
+    return out
+
+
 def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims, dt)

@@ -326,6 +326,19 @@ def test_ordered_p2g_bitexact_at_scale(hip_backend, dims, per_cell):
         assert_bitexact(a[k], a2[k], k + " (re-run)")
 
 
+@pytest.mark.parametrize("case", range(len(cases.INTERP_CASES)))
+def test_interpolate_between_grid_sizes(hip_backend, case):
+    from mantaflow_amd import _lib
+    sd, td, scale, offset, size = cases.INTERP_CASES[case]
+    fields = {"real": util.rand_real((sd[2], sd[1], sd[0]), 71), "vec": util.rand_vel(*sd, 72)}
+    a = cases.run_interp_pkg(sd, td, scale, offset, size, fields)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_interp_pkg(sd, td, scale, offset, size, fields)
+    _lib.reset()
+    for k in b:
+        assert_bitexact(a[k], b[k], "%s case %d" % (k, case))
+
+
 def test_reductions_and_elementwise(hip, oracle):
     n = 1 << 20
     a, b = util.rand_real((n + 3,), 30, 3.0), util.rand_real((n + 3,), 31, 2.0)

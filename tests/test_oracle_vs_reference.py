@@ -228,6 +228,18 @@ def test_grid_files_interoperate_with_reference(oracle_backend, tmp_path, ext):
             core.Grid(s).load(str(tmp_path / "ours2.uni"))
 
 
+@pytest.mark.parametrize("case", range(len(cases.INTERP_CASES)))
+def test_interpolate_between_grid_sizes(oracle_backend, case):
+    """interpolateGrid / interpolateGridVec3 / interpolateMACGrid (waveletturbulence.cpp:37-78): up- and down-sampling,
+    anisotropic scale, offset, explicit size, 2-D"""
+    sd, td, scale, offset, size = cases.INTERP_CASES[case]
+    fields = {"real": util.rand_real((sd[2], sd[1], sd[0]), 71), "vec": util.rand_vel(*sd, 72)}
+    a = cases.run_interp_pkg(sd, td, scale, offset, size, fields)
+    b = cases.run_interp_ref(sd, td, scale, offset, size, fields)
+    for k in b:
+        assert_bitexact(a[k], b[k], "%s case %d" % (k, case))
+
+
 def test_init_domain_matches_reference(oracle_backend):
     from mantaflow_amd import core
     for dims, bw, kw in [((10, 9, 8), 0, {}), ((12, 10, 9), 1, dict(open="xY", outflow="z")), ((16, 12, 1), 0, dict(inflow="y"))]:
