@@ -1,0 +1,1196 @@
+// mic.hip -- the MIC(0) preconditioner of the pressure solve on gfx950: InitPreconditionModifiedIncompCholesky2 and the two
+// substitution sweeps of ApplyPreconditionModifiedIncompCholesky2 (source/conjugategrad.cpp:66-97, 135-159), which the
+// reference runs as single-threaded lexicographic sweeps.  Three parallelisations with identical results:
+// "levels" (k_mic_tiles), "tiles" (k_mic_flow), "rows" (k_mic_rows, default for the apply sweeps).
+#include "common.h"
+#include "pressure.h"
+#include <float.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <type_traits>
+
+using namespace mf;
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// =========================================================================================================
+// MIC(0) preconditioner, conjugategrad.cpp:66-97 (init) and :135-159 (apply).
+//
+// The reference runs these as single-threaded lexicographic sweeps with a (i-1, j-1, k-1) dependency
+// (forward) / (i+1, j+1, k+1) (backward).  Here the grid is cut into 8x8x8 tiles; tiles on one hyperplane
+// ti+tj+tk = L are independent and run as one launch (one 64-lane wave per tile); inside a tile the wave
+// walks the 22 cell hyperplanes, lane = one x-row (lj,lk), neighbour values move by wave shuffles and the
+// per-cell coefficients are staged in LDS.  Per-cell arithmetic is exactly the reference's expression, so the
+// result is bit-identical to the serial sweep.
+//   MODE 0: init   dst := Aprecond,  var1 := A0
+//   MODE 1: forward substitution     dst := tmp, var1 := residual
+//   MODE 2: backward substitution (tile and in-tile coordinates mirrored)
+// =========================================================================================================
+// load 8 consecutive floats of one x-row (logical order a = 0..7 <-> physical li); branch-free so that the
+// compiler issues every load of a tile before the first wait.  `nv` = number of in-domain cells of the row (0..8).
+template <bool VEC, bool REV>
+__device__ __forceinline__ void load_row8(const float* __restrict__ base, int64_t rowidx, int nv, float out[8]) {
+	float t[8];
+	if (VEC) {
+		// x0 % 8 == 0 and sx % 4 == 0: both halves are 16-byte aligned; a half is either fully inside or outside
+		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		const int64_t i0 = nv > 0 ? rowidx : 0, i1 = nv > 4 ? rowidx + 4 : 0;
+		float4 lo = *(const float4*)(base + i0), hi = *(const float4*)(base + i1);
+		if (nv <= 0) lo = z;
+		if (nv <= 4) hi = z;
+		t[0] = lo.x; t[1] = lo.y; t[2] = lo.z; t[3] = lo.w;
+		t[4] = hi.x; t[5] = hi.y; t[6] = hi.z; t[7] = hi.w;
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const float v = base[e < nv ? rowidx + e : 0];
+			t[e] = e < nv ? v : 0.f;
+		}
+	}
+#pragma unroll
+	for (int a = 0; a < 8; a++) out[a] = t[REV ? 7 - a : a];
+}
+template <bool VEC, bool REV>
+__device__ __forceinline__ void load_row8i(const int32_t* __restrict__ base, int64_t rowidx, int nv, int out[8]) {
+	float t[8];
+	load_row8<VEC, REV>((const float*)base, rowidx, nv, t);
+#pragma unroll
+	for (int a = 0; a < 8; a++) out[a] = __float_as_int(t[a]);
+}
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(64)
+k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restrict__ flags, float* __restrict__ dst,
+            const float* __restrict__ var1, const float* __restrict__ Ap, const float* __restrict__ Ai,
+            const float* __restrict__ Aj, const float* __restrict__ Ak, const CgScalars* __restrict__ sc) {
+	constexpr bool REV = (MODE == 2);
+	constexpr int NC = (MODE == 0) ? 2 : 1;  // values handed to each neighbour
+	const int tjl = blockIdx.x, tkl = blockIdx.y;
+	const int til = level - tjl - tkl;
+	if (til < 0 || til >= nti) return;
+	const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
+	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
+	const int x0 = ti * 8, j = tj * 8 + lj, k = tk * 8 + lk;
+	const bool row_in = (j < d.sy) && (k < d.sz);
+	const int64_t rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
+	const int back = REV ? 1 : -1;  // physical offset of the logical predecessor
+	const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;  // in-domain cells of a row of this tile
+	const int nv = row_in ? nvx : 0;
+
+	__shared__ float sV[512], sAi[512], sAj[512], sAk[512], sP[512], sD[512];
+	__shared__ int sF[512];
+	__shared__ float sHj[NC][64], sHk[NC][64];
+
+	// ---- issue every global load of the tile (own row, i-halo cell, j-/k-halo rows), then consume ----
+	int rF[8];
+	float rV[8], rAi[8], rAj[8], rAk[8], rP[8], rD[8];
+	load_row8i<VEC, REV>(flags, rowbase, nv, rF);
+	load_row8<VEC, REV>(var1, rowbase, nv, rV);
+	load_row8<VEC, REV>(Ai, rowbase, nv, rAi);
+	load_row8<VEC, REV>(Aj, rowbase, nv, rAj);
+	load_row8<VEC, REV>(Ak, rowbase, nv, rAk);
+	if (MODE != 0) {
+		load_row8<VEC, REV>(Ap, rowbase, nv, rP);
+		load_row8<VEC, REV>(dst, rowbase, nv, rD);
+	}
+	// i-halo: the cell before my row (one per lane)
+	const int gi = x0 + (REV ? 8 : -1);
+	const bool hin = row_in && gi >= 0 && gi < d.sx;
+	const int64_t hidx = hin ? rowbase + (REV ? 8 : -1) : 0;
+	const float hAi = Ai[hidx], hAj = Aj[hidx], hAk = Ak[hidx], hD = dst[hidx];
+	const float hP = (MODE == 1) ? Ap[hidx] : 0.f;
+	// j-halo row (used by lanes with b == 0) and k-halo row (lanes with c == 0)
+	const int jn = j + back, kn = k + back;
+	const int nvj = ((b == 0) && (jn >= 0) && (jn < d.sy) && (k < d.sz)) ? nvx : 0;
+	const int nvk = ((c == 0) && (kn >= 0) && (kn < d.sz) && (j < d.sy)) ? nvx : 0;
+	const int64_t jrow = rowbase + (int64_t)back * d.Y, krow = rowbase + (int64_t)back * d.Z;
+	float jD[8], jA[8], jB[8], jC[8], jP[8], kD[8], kA[8], kB[8], kC[8], kP[8];
+	if (b == 0) {
+		load_row8<VEC, REV>(dst, jrow, nvj, jD);
+		if (MODE != 2) load_row8<VEC, REV>(Aj, jrow, nvj, jA);
+		if (MODE == 1) load_row8<VEC, REV>(Ap, jrow, nvj, jP);
+		if (MODE == 0) {
+			load_row8<VEC, REV>(Ai, jrow, nvj, jB);
+			load_row8<VEC, REV>(Ak, jrow, nvj, jC);
+		}
+	}
+	if (c == 0) {
+		load_row8<VEC, REV>(dst, krow, nvk, kD);
+		if (MODE != 2) load_row8<VEC, REV>(Ak, krow, nvk, kA);
+		if (MODE == 1) load_row8<VEC, REV>(Ap, krow, nvk, kP);
+		if (MODE == 0) {
+			load_row8<VEC, REV>(Ai, krow, nvk, kB);
+			load_row8<VEC, REV>(Aj, krow, nvk, kC);
+		}
+	}
+
+	// value(s) a finished neighbour cell hands to its logical successor in direction `dir`:
+	//   MODE 1: (dst*A_dir)*Ap   MODE 2: dst   MODE 0: square(A_dir*Ap), A_dir*(A_o1+A_o2)*square(Ap)
+	auto hand = [&](float dv, float adir, float osum, float ap, float& h0, float& h1) {
+		h1 = 0.f;
+		if (MODE == 1) {
+			h0 = (dv * adir) * ap;
+		} else if (MODE == 2) {
+			h0 = dv;
+		} else {
+			const float t = adir * dv;  // dv = Aprecond of the neighbour (being built)
+			h0 = t * t;
+			h1 = adir * osum * (dv * dv);
+		}
+	};
+#pragma unroll
+	for (int a = 0; a < 8; a++) {
+		const int s = lane * 8 + a;
+		const bool in = a < 8 && ((REV ? 7 - a : a) < nv);
+		const int fl = in ? ((rF[a] & MF_FLUID) ? 1 : 2) : 0;  // 1 fluid, 2 in-domain non-fluid, 0 outside
+		sF[s] = fl;
+		sV[s] = (fl == 1) ? rV[a] : 0.f;
+		sAi[s] = rAi[a];
+		sAj[s] = rAj[a];
+		sAk[s] = rAk[a];
+		if (MODE == 0) {
+			sP[s] = 0.f;
+			sD[s] = 0.f;  // Aprecond.clear(): non-fluid cells stay 0
+		} else {
+			sP[s] = rP[a];
+			sD[s] = rD[a];
+		}
+	}
+	float hi0, hi1;
+	hand(hin ? hD : 0.f, hin ? hAi : 0.f, hAj + hAk, hP, hi0, hi1);
+	if (!hin) hi0 = hi1 = 0.f;
+	if (b == 0) {
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			float h0, h1;
+			hand(jD[a], MODE != 2 ? jA[a] : 0.f, MODE == 0 ? (jB[a] + jC[a]) : 0.f, MODE == 1 ? jP[a] : 0.f, h0, h1);
+			sHj[0][c * 8 + a] = h0;
+			if (NC == 2) sHj[NC - 1][c * 8 + a] = h1;
+		}
+	}
+	if (c == 0) {
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			float h0, h1;
+			hand(kD[a], MODE != 2 ? kA[a] : 0.f, MODE == 0 ? (kB[a] + kC[a]) : 0.f, MODE == 1 ? kP[a] : 0.f, h0, h1);
+			sHk[0][b * 8 + a] = h0;
+			if (NC == 2) sHk[NC - 1][b * 8 + a] = h1;
+		}
+	}
+	__syncthreads();
+	if (sc && sc->done) return;   // checked after the loads were issued: one global round trip less per level
+
+	// ---- 22 cell hyperplanes ----
+	float oi0 = 0.f, oi1 = 0.f, oj0 = 0.f, oj1 = 0.f, ok0 = 0.f, ok1 = 0.f;
+#pragma unroll 2
+	for (int h = 0; h < 22; h++) {
+		const int a = h - b - c;
+		const bool valid = (a >= 0) && (a < 8);
+		const int ac = a < 0 ? 0 : (a > 7 ? 7 : a);
+		float ij0 = __shfl_up(oj0, 1, 64), ik0 = __shfl_up(ok0, 8, 64);
+		float ij1 = 0.f, ik1 = 0.f;
+		if (NC == 2) {
+			ij1 = __shfl_up(oj1, 1, 64);
+			ik1 = __shfl_up(ok1, 8, 64);
+		}
+		if (b == 0) {
+			ij0 = sHj[0][c * 8 + ac];
+			if (NC == 2) ij1 = sHj[NC - 1][c * 8 + ac];
+		}
+		if (c == 0) {
+			ik0 = sHk[0][b * 8 + ac];
+			if (NC == 2) ik1 = sHk[NC - 1][b * 8 + ac];
+		}
+		const float ii0 = (a == 0) ? hi0 : oi0;
+		const float ii1 = (a == 0) ? hi1 : oi1;
+		if (valid) {
+			const int s = lane * 8 + ac;
+			const int fl = sF[s];
+			const float ai = sAi[s], aj = sAj[s], ak = sAk[s];
+			if (MODE == 0) {
+				float ap = 0.f;
+				if (fl == 1) {
+					const float a0 = sV[s];
+					float e = a0 - ii0 - ij0 - ik0;
+					const float s3 = ii1 + ij1 + ik1;
+					// e -= tau * ( ... + 0. ): fp64 product and subtraction, conjugategrad.cpp:84-88
+					const float tau = 0.97f;
+					e = (float)((double)e - (double)tau * ((double)s3 + 0.));
+					if (e < 0.25f * a0) e = a0;
+					ap = (float)(1. / (double)sqrtf(e));
+				}
+				sD[s] = ap;
+				const float ti_ = ai * ap, tj_ = aj * ap, tk_ = ak * ap;
+				const float ap2 = ap * ap;
+				oi0 = ti_ * ti_;
+				oj0 = tj_ * tj_;
+				ok0 = tk_ * tk_;
+				oi1 = ai * (aj + ak) * ap2;
+				oj1 = aj * (ai + ak) * ap2;
+				ok1 = ak * (ai + aj) * ap2;
+			} else if (MODE == 1) {
+				const float p = sP[s];
+				float val = sD[s];
+				if (fl == 1) {
+					val = p * (sV[s] - ii0 - ij0 - ik0);
+					sD[s] = val;
+				}
+				oi0 = (val * ai) * p;
+				oj0 = (val * aj) * p;
+				ok0 = (val * ak) * p;
+			} else {
+				const float p = sP[s];
+				float val = sD[s];
+				if (fl == 1) {
+					val = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+					sD[s] = val;
+				}
+				oi0 = oj0 = ok0 = val;
+			}
+		}
+	}
+	__syncthreads();
+	// ---- write back my row (non-fluid cells carry their loaded value, so whole in-domain halves are stored) ----
+	float w[8];
+#pragma unroll
+	for (int a = 0; a < 8; a++) w[REV ? 7 - a : a] = sD[lane * 8 + a];
+	if (VEC) {
+		if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
+		if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; e++)
+			if (e < nv) dst[rowbase + e] = w[e];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MIC apply as ONE launch per sweep ("dataflow"): one wave per tile, tiles are handed out in hyperplane order by an
+// atomic ticket (a ticketed tile's predecessors hold smaller tickets, i.e. they are already running or finished, so the
+// wait below always ends whatever the dispatch order), and the three faces a tile hands to its +i/+j/+k successors
+// travel as 8-byte {value, tag} granules written with ONE agent-scope (sc1, write-through) store each and polled with
+// agent-scope (sc1, L1-bypassing) loads: no flag, no fence (MI355X_MICROARCH.md, "handoff-1to1").  tag = launch
+// generation, so the exchange buffer never needs clearing.  Per-cell arithmetic is identical to k_mic_tiles.
+// ---------------------------------------------------------------------------------------------------------
+struct FlowCtl {
+	int ticket, finished, err, pad;
+};
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(unsigned long long* p, float v, unsigned tag) {
+	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// same-XCD hand-off: a plain store reaches that XCD's L2, where an agent-scope (sc1) load of another CU of the same XCD
+// finds it (0.26 us one way vs 0.72 us for sc1 -> sc1 across XCDs, tools/micro/pingpong.hip); NOT visible to other XCDs
+__device__ __forceinline__ void granule_store_local(unsigned long long* p, float v, unsigned tag) {
+	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+constexpr int FLOW_SPIN_LIMIT = 1 << 21;
+
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(64)
+k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__ order, FlowCtl* ctl,
+           unsigned long long* xch, unsigned gen, const int32_t* __restrict__ flags, float* __restrict__ dst,
+           const float* __restrict__ var1, const float* __restrict__ Ap, const float* __restrict__ Ai,
+           const float* __restrict__ Aj, const float* __restrict__ Ak, const CgScalars* __restrict__ sc) {
+	static_assert(MODE == 1 || MODE == 2, "dataflow kernel implements the apply sweeps");
+	constexpr bool REV = (MODE == 2);
+	if (sc && sc->done) return;
+	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
+	// double-buffered tile operands: while tile n runs its 22 steps out of one buffer, the operands of the tile this
+	// wave will run next are already in flight (its ticket was drawn one tile earlier), so ticket, tile lookup and the
+	// HBM round trip of the operands are off the dependency chain between tiles
+	__shared__ float4 sA[2][512];   // {V, Ai, Aj, Ak}
+	__shared__ float4 sB[2][512];   // {Aprecond, dst, fluid, -}
+	__shared__ float sHj[64], sHk[64];
+	const unsigned long long fresh0 = (unsigned long long)gen << 32;
+
+	struct TileRegs {
+		int F[8];
+		float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+	};
+	auto tile_geom = [&](int packed, int& x0, int64_t& rowbase, int& nv) {
+		const int til = packed & 1023, tjl = (packed >> 10) & 1023, tkl = (packed >> 20) & 1023;
+		const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
+		const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
+		x0 = ti * 8;
+		const int j = tj * 8 + lj, k = tk * 8 + lk;
+		const bool row_in = (j < d.sy) && (k < d.sz);
+		rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
+		const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+		nv = row_in ? nvx : 0;
+	};
+	auto issue = [&](TileRegs& r, int packed) {
+		int x0, nv;
+		int64_t rowbase;
+		tile_geom(packed, x0, rowbase, nv);
+		load_row8i<VEC, REV>(flags, rowbase, nv, r.F);
+		load_row8<VEC, REV>(var1, rowbase, nv, r.V);
+		load_row8<VEC, REV>(Ai, rowbase, nv, r.Ai);
+		load_row8<VEC, REV>(Aj, rowbase, nv, r.Aj);
+		load_row8<VEC, REV>(Ak, rowbase, nv, r.Ak);
+		load_row8<VEC, REV>(Ap, rowbase, nv, r.P);
+		load_row8<VEC, REV>(dst, rowbase, nv, r.D);
+	};
+	auto commit = [&](const TileRegs& r, int packed, int buf) {
+		int x0, nv;
+		int64_t rowbase;
+		tile_geom(packed, x0, rowbase, nv);
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			const bool in = ((REV ? 7 - a : a) < nv);
+			const bool fl = in && (r.F[a] & MF_FLUID);
+			sA[buf][a * 64 + lane] = make_float4(fl ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
+			sB[buf][a * 64 + lane] = make_float4(r.P[a], r.D[a], fl ? 1.f : 0.f, 0.f);
+		}
+	};
+	auto draw = [&]() {
+		int t = 0;
+		if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
+		return __builtin_amdgcn_readfirstlane(t);
+	};
+
+	int t_cur = draw();
+	int t_nxt = draw();
+	int pk_cur = (t_cur < ntiles) ? order[t_cur] : 0;
+	int pk_nxt = (t_nxt < ntiles) ? order[t_nxt] : 0;
+	TileRegs R;
+	if (t_cur < ntiles) {
+		issue(R, pk_cur);
+		commit(R, pk_cur, 0);
+	}
+	int buf = 0, spins = 0;
+	while (t_cur < ntiles) {
+		int tnn_raw = 0;           // ticket of the tile after next: drawn now, looked at when this tile is done
+		if (lane == 0) tnn_raw = atomicAdd(&ctl->ticket, 1);
+		// ---- geometry of the current tile ----
+		const int til = pk_cur & 1023, tjl = (pk_cur >> 10) & 1023, tkl = (pk_cur >> 20) & 1023;
+		const int64_t tid = ((int64_t)tkl * ntj + tjl) * nti + til;
+		const bool has_pi = til > 0, has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
+		const bool has_si = til + 1 < nti, has_sj = (tjl + 1 < ntj) && (b == 7), has_sk = (tkl + 1 < ntk) && (c == 7);
+		unsigned long long* out_i = xch + ((tid * 3 + 0) << 6) + lane;
+		unsigned long long* out_j = xch + ((tid * 3 + 1) << 6) + c * 8;
+		unsigned long long* out_k = xch + ((tid * 3 + 2) << 6) + b * 8;
+		const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6) + lane;
+		const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6) + c * 8;
+		const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6) + b * 8;
+		// ---- first look at the predecessors' faces, then the next tile's operands (both stay in flight) ----
+		unsigned long long gi = has_pi ? granule_load(in_i) : fresh0;
+		unsigned long long gj[8], gk[8];
+#pragma unroll
+		for (int a = 0; a < 8; a++) gj[a] = has_pj ? granule_load(in_j + a) : fresh0;
+#pragma unroll
+		for (int a = 0; a < 8; a++) gk[a] = has_pk ? granule_load(in_k + a) : fresh0;
+		if (t_nxt < ntiles) issue(R, pk_nxt);
+		// ---- wait until every face value is there ----
+		for (;;) {
+			bool ok = ((unsigned)(gi >> 32) == gen);
+#pragma unroll
+			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(gj[a] >> 32) == gen) && ((unsigned)(gk[a] >> 32) == gen);
+			if (ok || ++spins > FLOW_SPIN_LIMIT) break;
+			__builtin_amdgcn_s_sleep(1);
+			if ((unsigned)(gi >> 32) != gen) gi = granule_load(in_i);
+#pragma unroll
+			for (int a = 0; a < 8; a++) {
+				if ((unsigned)(gj[a] >> 32) != gen) gj[a] = granule_load(in_j + a);
+				if ((unsigned)(gk[a] >> 32) != gen) gk[a] = granule_load(in_k + a);
+			}
+		}
+		if (b == 0) {
+#pragma unroll
+			for (int a = 0; a < 8; a++) sHj[c * 8 + a] = __uint_as_float((unsigned)gj[a]);
+		}
+		if (c == 0) {
+#pragma unroll
+			for (int a = 0; a < 8; a++) sHk[b * 8 + a] = __uint_as_float((unsigned)gk[a]);
+		}
+		const float hi0 = __uint_as_float((unsigned)gi);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// ---- 22 cell hyperplanes (no global loads inside) ----
+		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+		int a = -b - c;
+		int ac = 0;
+		float4 nA = sA[buf][lane], nB = sB[buf][lane];
+		float nHj = sHj[c * 8], nHk = sHk[b * 8];
+#pragma unroll 2
+		for (int h = 0; h < 22; h++) {
+			const float4 cA = nA, cB = nB;
+			const float hj = nHj, hk = nHk;
+			const int cc = ac;
+			{
+				const int a1 = a + 1;
+				ac = a1 < 0 ? 0 : (a1 > 7 ? 7 : a1);
+				nA = sA[buf][ac * 64 + lane];
+				nB = sB[buf][ac * 64 + lane];
+				nHj = sHj[c * 8 + ac];
+				nHk = sHk[b * 8 + ac];
+			}
+			const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+			const float sk = __shfl_up(ok0, 8, 64);
+			const float ij0 = (b == 0) ? hj : dj;
+			const float ik0 = (c == 0) ? hk : sk;
+			const float ii0 = (a == 0) ? hi0 : oi0;
+			const bool valid = (unsigned)a < 8u;
+			const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+			const bool fl = valid && (cB.z != 0.f);
+			float val = cB.y;
+			if (MODE == 1) {
+				const float nv = p * (cA.x - ii0 - ij0 - ik0);
+				val = fl ? nv : val;
+				oi0 = (val * ai) * p;
+				oj0 = (val * aj) * p;
+				ok0 = (val * ak) * p;
+			} else {
+				const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+				val = fl ? nv : val;
+				oi0 = oj0 = ok0 = val;
+			}
+			if (valid) {
+				sB[buf][cc * 64 + lane].y = val;
+				if (has_si && a == 7) granule_store(out_i, oi0, gen);
+				if (has_sj) granule_store(out_j + a, oj0, gen);
+				if (has_sk) granule_store(out_k + a, ok0, gen);
+			}
+			a++;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// ---- write back the finished tile ----
+		{
+			int x0, nv;
+			int64_t rowbase;
+			tile_geom(pk_cur, x0, rowbase, nv);
+			float w[8];
+#pragma unroll
+			for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sB[buf][e * 64 + lane].y;
+			if (VEC) {
+				if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
+				if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
+			} else {
+#pragma unroll
+				for (int e = 0; e < 8; e++)
+					if (e < nv) dst[rowbase + e] = w[e];
+			}
+		}
+		// ---- land the next tile's operands in the other buffer, rotate ----
+		if (t_nxt < ntiles) commit(R, pk_nxt, buf ^ 1);
+		const int t_nn = __builtin_amdgcn_readfirstlane(tnn_raw);
+		buf ^= 1;
+		t_cur = t_nxt;
+		pk_cur = pk_nxt;
+		t_nxt = t_nn;
+		pk_nxt = (t_nn < ntiles) ? order[t_nn] : 0;
+	}
+	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+	// the last workgroup to leave re-arms the ticket for the next sweep (visible at the kernel boundary)
+	if (lane == 0) {
+		const int f = atomicAdd(&ctl->finished, 1);
+		if (f == (int)gridDim.x - 1) {
+			ctl->ticket = 0;
+			ctl->finished = 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MIC apply, row-streaming form ("rows"): a workgroup of TWO waves owns an 8x8 bundle of x-rows (tj,tk) and streams
+// along the whole x extent.
+//   compute wave: lane (b,c) works on cell x' = h - b - c at step h.  The i-dependency never leaves the lane's
+//     registers (no i-faces, no 14-step fill/drain per 8 cells), the j/k dependencies inside the bundle move by DPP /
+//     ds_bpermute as in the tile kernel, and only the two outer faces of the bundle cross workgroups -- as tagged
+//     8-byte sc1 granules, one per (x', face lane), polled 8 steps at a time in a lane-relative window (a consumer
+//     bundle runs 15 steps behind its producer).  Its only vector-memory traffic is those granules: vmcnt is in-order,
+//     so a polling load must never queue behind an HBM fetch.
+//   memory wave: fetches the operands of the bundle's rows in 8-cell chunks, three chunks ahead, commits them to a
+//     32-step LDS ring and writes finished chunks back to dst.  The ring is indexed by the STEP at which a lane
+//     consumes the cell ((h+2) & 31), i.e. the skew b+c is applied when the memory wave stores, and every lane of the
+//     compute wave reads the same ring row at a given step: immediate LDS offsets, no per-lane address arithmetic.
+//   The two waves meet only through two LDS counters (chunks committed / blocks finished).
+// Bundles are ticketed in anti-diagonal order (tj+tk): a workgroup only ever waits for bundles drawn before its own.
+// 256^3: 1024 bundles, 62 bundle hops per sweep.  Per-cell arithmetic = k_mic_tiles = the reference's.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int ROWS_PAD = 16;
+struct RowsChunk {
+	int F[8];
+	float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+};
+constexpr int ROWS_THREADS = 384;   // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the faces
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(ROWS_THREADS)
+k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
+           unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
+           float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
+           const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
+           const CgScalars* __restrict__ sc, long long* trace, int trace_ticket, int trace_ticket2) {
+	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
+	constexpr bool REV = (MODE == 2);
+	if (sc && sc->done) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
+	const int skew = b + c;
+	// the compute wave is the critical path: everything else yields to it
+	if (wave == 0) __builtin_amdgcn_s_setprio(3);
+	else __builtin_amdgcn_s_setprio(0);
+	__shared__ float4 sA[32 * 64];   // {fluid ? rhs : dst  (-> result), Ai, Aj, Ak}     index = ((h + 2) & 31) * 64 + lane
+	__shared__ float2 sB[32 * 64];   // {Aprecond, fluid}
+	__shared__ __attribute__((aligned(16))) float sFj[2][8][8];
+	__shared__ __attribute__((aligned(16))) float sFk[2][8][8];   // face values of a block [block parity][face lane][step]
+	__shared__ int s_ready[3], s_done, s_flushed, s_faces, s_ticket;
+	const unsigned long long fresh0 = (unsigned long long)gen << 32;
+	const int X8 = nchunks * 8;
+	int spins = 0;
+
+	for (;;) {
+		if (threadIdx.x == 0) {
+			// xt[0..7] tickets, xt[8..16] bounds of the per-XCD queues inside `order`, xt[17] = number of queues (1: one
+			// global queue; 8: bundles are queued per XCD by k-slab, so that most faces are handed over inside one XCD's L2)
+			const int nq = xt[17];
+			const int q = nq > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;   // HW_REG_XCC_ID
+			const int lo = xt[8 + q], hi = xt[9 + q];
+			int tk = nstreams;
+			if (lo < hi) {
+				const int tl = atomicAdd(&xt[q], 1);
+				if (lo + tl < hi) tk = lo + tl;
+			}
+			s_ticket = tk;
+			s_ready[0] = s_ready[1] = s_ready[2] = 0;
+			s_done = 0;
+			s_flushed = 0;
+			s_faces = 0;
+		}
+		__syncthreads();
+		const int t = s_ticket;
+		if (t >= nstreams) break;
+		const int pk = order[t];
+		const int tjl = pk & 0xffff, tkl = pk >> 16;
+		const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
+		const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
+		const bool row_in = (j < d.sy) && (k < d.sz);
+		const int64_t rowbase = d.Y * j + d.Z * k;
+
+		// face granules: per bundle and face an array [producer step h + 2][face lane]: the 8 face lanes of one step (one
+		// store instruction) fill exactly one 64-byte line, and a consumer lane's 8-step window maps to 8 consecutive lines
+		// (lane (7,c) publishes x' at step x'+7+c, lane (b,7) at x'+b+7: the same steps 8m+5 .. 8m+12 for every face lane)
+		// jb = bundles per independent j-block (mf_set_mic_blocking: the caller has zeroed the Aj coupling across block
+		// faces, so nothing crosses them); jb == nbj: one block = the reference algorithm
+		const int tj_pred = REV ? tj + 1 : tj - 1, tj_succ = REV ? tj - 1 : tj + 1;
+		const bool has_pj = (tjl > 0) && (tj / jb == tj_pred / jb) && (b == 0), has_pk = (tkl > 0) && (c == 0);
+		const bool has_sj = (tjl + 1 < nbj) && (tj / jb == tj_succ / jb) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
+		const int64_t sid = (int64_t)tkl * nbj + tjl;
+		const int64_t XP = X8 + 2 * ROWS_PAD;
+		if (wave == 5) {
+			// ================= face poller: the only wave that loads granules (and it never stores to global memory) =====
+			const unsigned long long* in_j = xj + (sid - 1) * XP * 8 + c;          // + (h + 2) * 8
+			const unsigned long long* in_k = xk + (sid - nbj) * XP * 8 + b;
+#pragma unroll 1
+			for (int m = 0; m <= nchunks + 1; m++) {
+				const int xq = 8 * m - 2 - skew;
+				unsigned long long gj[8], gk[8];
+#pragma unroll
+				for (int a = 0; a < 8; a++) gj[a] = gk[a] = fresh0;
+				for (;;) {
+					if (has_pj) {
+#pragma unroll
+						for (int a = 0; a < 8; a++) gj[a] = granule_load(in_j + (int64_t)(8 * m + 7 + a) * 8);
+					}
+					if (has_pk) {
+#pragma unroll
+						for (int a = 0; a < 8; a++) gk[a] = granule_load(in_k + (int64_t)(8 * m + 7 + a) * 8);
+					}
+					// tags only grow: the window is complete when its smallest tag is this sweep's generation
+					unsigned tmin = gen;
+#pragma unroll
+					for (int a = 0; a < 8; a++) {
+						const bool in = (unsigned)(xq + a) < (unsigned)X8;
+						const unsigned tj_ = (unsigned)(gj[a] >> 32), tk_ = (unsigned)(gk[a] >> 32);
+						tmin = min(tmin, in ? min(tj_, tk_) : gen);
+					}
+					if (__all(tmin == gen) || ++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				// the buffer of this parity was read by block m-2
+				if (m >= 2) {
+					while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m - 1) {
+						if (++spins > FLOW_SPIN_LIMIT) break;
+						__builtin_amdgcn_s_sleep(8);
+					}
+				}
+				if (b == 0) {
+#pragma unroll
+					for (int a = 0; a < 8; a++) sFj[m & 1][c][a] = __uint_as_float((unsigned)gj[a]);
+				}
+				if (c == 0) {
+#pragma unroll
+					for (int a = 0; a < 8; a++) sFk[m & 1][b][a] = __uint_as_float((unsigned)gk[a]);
+				}
+				__hip_atomic_store(&s_faces, m + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		} else if (wave != 0) {
+			// ================= memory waves: waves 1-3 load + commit, wave 4 writes finished chunks back =================
+			// (separate waves because vmcnt is one in-order counter per wave: a wave that has loads of several chunks or
+			// loads and stores in flight ends up waiting for all of them)
+			auto chunk_geom = [&](int m, int64_t& rowidx, int& nv) {
+				const int x0 = (REV ? nchunks - 1 - m : m) * 8;
+				const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+				nv = row_in ? nvx : 0;
+				rowidx = rowbase + x0;
+			};
+			auto wait_for = [&](int* flag, int need) {
+				while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(8);
+				}
+			};
+			if (wave <= 3) {
+				auto issue = [&](RowsChunk& r, int m) {
+					int64_t rowidx;
+					int nv;
+					chunk_geom(m, rowidx, nv);
+					load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
+					if (MODE == 1) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
+					load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
+					load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
+					load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
+					load_row8<VEC, REV>(Ap, rowidx, nv, r.P);
+					load_row8<VEC, REV>(dst, rowidx, nv, r.D);
+				};
+				auto commit = [&](const RowsChunk& r, int m) {
+					int64_t rowidx;
+					int nv;
+					chunk_geom(m, rowidx, nv);
+					const int p0 = 8 * m + skew + 2;
+#pragma unroll
+					for (int a = 0; a < 8; a++) {
+						const bool in = ((REV ? 7 - a : a) < nv);
+						const bool fl = in && (r.F[a] & MF_FLUID);
+						const int idx = ((p0 + a) & 31) * 64 + lane;
+						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], r.Ai[a], r.Aj[a], r.Ak[a]);
+						sB[idx] = make_float2(r.P[a], fl ? 1.f : 0.f);
+					}
+				};
+				// one chunk in flight per loader wave: its loads are issued as soon as the previous chunk of this wave is
+				// committed (three blocks before the compute wave needs them), then the wave waits for the ring rows
+				RowsChunk R;
+				const int w = wave - 1;
+#pragma unroll 1
+				for (int n = w; n < nchunks; n += 3) {
+					issue(R, n);
+					// the ring rows of chunk n were last used by chunk n-4: it must have been written back
+					if (n >= 4) wait_for(&s_flushed, n - 3);
+					commit(R, n);
+					__hip_atomic_store(&s_ready[w], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			} else {
+#pragma unroll 1
+				for (int q = 0; q < nchunks; q++) {
+					wait_for(&s_done, q + 3);   // chunk q is complete once block q+2 is finished
+					int64_t rowidx;
+					int nv;
+					chunk_geom(q, rowidx, nv);
+					const int p0 = 8 * q + skew + 2;
+					float w[8];
+#pragma unroll
+					for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sA[((p0 + e) & 31) * 64 + lane].x;
+					__hip_atomic_store(&s_flushed, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (VEC) {
+						if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
+						if (nv > 4) *(float4*)(dst + rowidx + 4) = make_float4(w[4], w[5], w[6], w[7]);
+					} else {
+#pragma unroll
+						for (int e = 0; e < 8; e++)
+							if (e < nv) dst[rowidx + e] = w[e];
+					}
+				}
+			}
+		} else {
+			// ================= compute wave: LDS in, LDS + face granules out =================
+			// Lane 0 stands in for lane 63's k face (same step, but its own x' runs 14 ahead of lane 63's)
+			const bool corner_proxy = (lane == 0) && (tkl + 1 < nbk);
+			const bool face_lane = has_sj || (has_sk && lane != 63) || corner_proxy;
+			const int fskew = corner_proxy ? -14 : 0;
+			unsigned long long* out_f = has_sj ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
+			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+			float4 nA = sA[lane];                  // ring row of h = -2 (never valid)
+			float2 nB = sB[lane];
+			const bool tr = trace && (t == trace_ticket || t == trace_ticket2) && lane == 0;
+			long long* trb = trace + (t == trace_ticket2 ? 8 * 4096 : 0);
+			if (trace && lane == 0 && t < 4096) {
+				trace[4 * 4096 + 2 * t] = wall_clock64();
+				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+			}
+#define ROWS_TRACE(i) if (tr) trb[m * 4 + (i)] = wall_clock64();
+			// plain (XCD-local) face stores only when every consumer of this bundle's faces runs on this XCD
+			const int nq_ = xt[17];
+			const bool local_faces = nq_ > 1 && ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk));
+			auto block = [&](int m, auto edge_tag, auto local_tag) {
+				constexpr bool EDGE = decltype(edge_tag)::value;
+				constexpr bool LOCAL = decltype(local_tag)::value;
+				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
+				ROWS_TRACE(0)
+				if (m < nchunks) {
+					int* flag = &s_ready[m % 3];
+					while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m + 1) {
+						if (++spins > FLOW_SPIN_LIMIT) break;
+						__builtin_amdgcn_s_sleep(1);
+					}
+				}
+				ROWS_TRACE(1)
+				while (__hip_atomic_load(&s_faces, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m + 1) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				float gj[8], gk[8];
+				{
+					const float4 j0 = *(const float4*)&sFj[m & 1][c][0], j1 = *(const float4*)&sFj[m & 1][c][4];
+					const float4 k0 = *(const float4*)&sFk[m & 1][b][0], k1 = *(const float4*)&sFk[m & 1][b][4];
+					gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
+					gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
+				}
+				ROWS_TRACE(2)
+				const int base = (8 * m) & 31;
+				unsigned long long* pf = out_f + (int64_t)(8 * m) * 8;   // row h + 2 = 8m + s
+#pragma unroll
+				for (int s = 0; s < 8; s++) {
+					const float4 cA = nA;
+					const float2 cB = nB;
+					const int row = ((base + s) & 31) * 64 + lane;
+					const int nrow = ((base + s + 1) & 31) * 64 + lane;
+					nA = sA[nrow];
+					nB = sB[nrow];
+					const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+					const float sk = __shfl_up(ok0, 8, 64);
+					const float ij0 = (b == 0) ? gj[s] : dj;
+					const float ik0 = (c == 0) ? gk[s] : sk;
+					const float ii0 = oi0;
+					const bool valid = !EDGE || ((unsigned)(xq + s) < (unsigned)X8);
+					const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
+					const bool fl = cB.y != 0.f;
+					float val = cA.x;
+					if (MODE == 1) {
+						const float nv = p * (val - ii0 - ij0 - ik0);
+						val = fl ? nv : val;
+						oi0 = valid ? (val * ai) * p : 0.f;
+						oj0 = valid ? (val * aj) * p : 0.f;
+						ok0 = valid ? (val * ak) * p : 0.f;
+					} else {
+						const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+						val = fl ? nv : val;
+						oi0 = oj0 = ok0 = valid ? val : 0.f;
+					}
+					// one face store per step: lanes b == 7 publish the j face, lanes c == 7 the k face, and lane 0 (never a
+					// face lane) publishes the k value of the corner lane 63, which is busy with its j value
+					const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), 63));
+					const float fv = (lane == 0) ? corner : ((b == 7) ? oj0 : ok0);
+					if (valid) sA[row].x = val;
+					if (face_lane) {
+						const bool fvalid = !EDGE || ((unsigned)(xq + s + fskew) < (unsigned)X8);
+						if (fvalid) {
+							if (LOCAL) granule_store_local(pf + s * 8, fv, gen);
+							else granule_store(pf + s * 8, fv, gen);
+						}
+					}
+				}
+				// LDS-only release: the block's granule stores need not have been acknowledged before the next block starts
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+				__hip_atomic_store(&s_done, m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				ROWS_TRACE(3)
+			};
+#pragma unroll 1
+			for (int m = 0; m <= nchunks + 1; m++) {
+				// interior: every lane's x' is inside [0, X8) for all 8 steps of the block
+				const bool interior = (m >= 2 && m <= nchunks - 1);
+				if (local_faces) {
+					if (interior) block(m, std::false_type{}, std::true_type{});
+					else block(m, std::true_type{}, std::true_type{});
+				} else {
+					if (interior) block(m, std::false_type{}, std::false_type{});
+					else block(m, std::true_type{}, std::false_type{});
+				}
+			}
+			if (trace && lane == 0 && t < 4096) trace[4 * 4096 + 2 * t + 1] = wall_clock64();
+#undef ROWS_TRACE
+		}
+		__syncthreads();
+	}
+	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+	if (threadIdx.x == 0) {
+		const int f = atomicAdd(&ctl->finished, 1);
+		if (f == (int)gridDim.x - 1) {
+			for (int q = 0; q < 8; q++) xt[q] = 0;
+			ctl->finished = 0;
+		}
+	}
+}
+
+// host-side state of the dataflow sweeps (per device): tile order for the current grid, exchange buffer, generation
+struct FlowState {
+	int nti = 0, ntj = 0, ntk = 0, ntiles = 0;
+	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;   // streaming form
+	int* border = nullptr;       // ticket order of the forward sweep, then of the backward sweep (nblocks entries each)
+	int jb = 0;                  // bundles per j-block the order was built for
+	int nq = 0;                  // ticket queues (1 or 8)
+	int* rows_xt = nullptr;      // [2][18]: tickets, queue bounds, queue count -- forward sweep, backward sweep
+	unsigned long long *sxj = nullptr, *sxk = nullptr;
+	size_t sx_cap = 0;
+	unsigned sgen = 0;
+	int* order = nullptr;
+	int level_count[3072];
+	unsigned long long* xch = nullptr;
+	size_t xch_cap = 0;
+	FlowCtl* ctl = nullptr;
+	unsigned gen = 0;
+};
+static FlowState g_flow[16];
+
+static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st, bool need_xch = false) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
+	if (nti > 1023 || ntj > 1023 || ntk > 1023) return fail("grid too large for the MIC tile order table");
+	if (!f.ctl) {
+		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+	}
+	if (f.nti != nti || f.ntj != ntj || f.ntk != ntk) {
+		MF_HIP(hipStreamSynchronize(st));
+		const int nt = nti * ntj * ntk;
+		int* h = (int*)malloc(sizeof(int) * nt);
+		int q = 0;
+		for (int L = 0; L <= nti + ntj + ntk - 3; L++) {
+			const int q0 = q;
+			for (int tk = 0; tk < ntk; tk++)
+				for (int tj = 0; tj < ntj; tj++) {
+					const int ti = L - tj - tk;
+					if (ti >= 0 && ti < nti) h[q++] = ti | (tj << 10) | (tk << 20);
+				}
+			f.level_count[L] = q - q0;
+		}
+		if (f.order) MF_HIP(hipFree(f.order));
+		MF_HIP(hipMalloc((void**)&f.order, sizeof(int) * nt));
+		MF_HIP(hipMemcpy(f.order, h, sizeof(int) * nt, hipMemcpyHostToDevice));
+		free(h);
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+		f.gen = 0;
+		f.nti = nti;
+		f.ntj = ntj;
+		f.ntk = ntk;
+		f.ntiles = nt;
+		if (f.xch) MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
+	}
+	if (need_xch) {
+		const size_t need = (size_t)f.ntiles * 3 * 64 * sizeof(unsigned long long);
+		if (need > f.xch_cap) {
+			MF_HIP(hipStreamSynchronize(st));
+			if (f.xch) MF_HIP(hipFree(f.xch));
+			MF_HIP(hipMalloc((void**)&f.xch, need));
+			f.xch_cap = need;
+			MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
+			f.gen = 0;
+		}
+	}
+	*out = &f;
+	return 0;
+}
+// per-XCD ticket queues rely on workgroup b running on XCD b % 8 (round-robin dispatch, verified once per process)
+__global__ void k_probe_xcc(int* out) {
+	if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
+}
+static bool xcd_round_robin_ok() {
+	static int state = -1;
+	if (state < 0) {
+		state = 0;
+		int* dbuf = nullptr;
+		int hbuf[64];
+		if (hipMalloc((void**)&dbuf, sizeof hbuf) == hipSuccess) {
+			hipLaunchKernelGGL(k_probe_xcc, dim3(64), dim3(64), 0, 0, dbuf);
+			if (hipMemcpy(hbuf, dbuf, sizeof hbuf, hipMemcpyDeviceToHost) == hipSuccess) {
+				state = 1;
+				for (int b = 0; b < 64; b++)
+					if (hbuf[b] != (b & 7)) state = 0;
+			}
+			(void)hipFree(dbuf);
+		}
+	}
+	return state == 1;
+}
+static thread_local int g_mic_jblock_rows = 0;   // mf_set_mic_blocking
+static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8, nchunks = (d.sx + 7) / 8;
+	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC bundle order table");
+	int jb = g_mic_jblock_rows > 0 ? g_mic_jblock_rows / 8 : nbj;
+	if (jb < 1 || jb > nbj) jb = nbj;
+	static const int use_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : 0;
+	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
+	if (!f.ctl) {
+		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+	}
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != nq) {
+		MF_HIP(hipStreamSynchronize(st));
+		const int nb = nbj * nbk;
+		int* h = (int*)malloc(sizeof(int) * 2 * nb);
+		int xt[2][18];
+		memset(xt, 0, sizeof xt);
+		// tickets in topological order of each sweep: key = position of the bundle inside its j-block along the sweep
+		// direction + tkl (anti-diagonals of the block-local dependency graph); one queue per XCD = k-slab of bundles
+		for (int rev = 0; rev < 2; rev++) {
+			int q = 0;
+			for (int x = 0; x < 8; x++) {
+				xt[rev][8 + x] = q;
+				if (x < nq)
+					for (int L = 0; L <= nbj + nbk - 2; L++)
+						for (int bk = 0; bk < nbk; bk++) {
+							if ((bk * nq) / nbk != x) continue;
+							for (int bjl = 0; bjl < nbj; bjl++) {
+								const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
+								const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
+								const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
+								if (posj + bk == L) h[rev * nb + q++] = bjl | (bk << 16);
+							}
+						}
+			}
+			xt[rev][16] = q;
+			xt[rev][17] = nq;
+		}
+		if (!f.rows_xt) MF_HIP(hipMalloc((void**)&f.rows_xt, sizeof(xt)));
+		MF_HIP(hipMemcpy(f.rows_xt, xt, sizeof(xt), hipMemcpyHostToDevice));
+		if (f.border) MF_HIP(hipFree(f.border));
+		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * 2 * nb));
+		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * 2 * nb, hipMemcpyHostToDevice));
+		free(h);
+		// one granule per (bundle, x', face lane) and face
+		const size_t need = (size_t)nb * 8 * (8 * (size_t)nchunks + 2 * ROWS_PAD) * sizeof(unsigned long long);
+		if (need > f.sx_cap) {
+			if (f.sxj) MF_HIP(hipFree(f.sxj));
+			if (f.sxk) MF_HIP(hipFree(f.sxk));
+			MF_HIP(hipMalloc((void**)&f.sxj, need));
+			MF_HIP(hipMalloc((void**)&f.sxk, need));
+			f.sx_cap = need;
+		}
+		MF_HIP(hipMemset(f.sxj, 0, f.sx_cap));
+		MF_HIP(hipMemset(f.sxk, 0, f.sx_cap));
+		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
+		f.sgen = 0;
+		f.nbj = nbj;
+		f.nbk = nbk;
+		f.nblocks = nb;
+		f.nchunks = nchunks;
+		f.jb = jb;
+		f.nq = nq;
+	}
+	*out = &f;
+	return 0;
+}
+// MF_MIC_MODE selects how the two apply sweeps are parallelised (all three give bit-identical results):
+// 2 "rows"  : one launch per sweep, a 6-wave workgroup per 8x8 bundle of x-rows streaming along x (default for 3D grids:
+//              256^3 apply 0.83 ms; 2D grids fall through to "tiles")
+// 1 "tiles" : one launch per sweep, ticketed 8^3 tiles + tagged sc1 granules, operands of the next tile prefetched
+//              (256^3 apply 1.32 ms)
+// 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback, 2.2 ms)
+static int g_mic_mode = -1;
+extern "C" int mf_set_mic_mode(const char* name) {
+	if (!name || !*name) g_mic_mode = -1;
+	else if (!strcmp(name, "levels")) g_mic_mode = 0;
+	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
+	else if (!strcmp(name, "rows")) g_mic_mode = 2;
+	else return fail("mf_set_mic_mode: unknown mode (rows | tiles | levels)");
+	return 0;
+}
+extern "C" int mf_set_mic_blocking(int rows_j) {
+	if (rows_j < 0 || (rows_j % 8) != 0) return fail("mf_set_mic_blocking: rows must be a non-negative multiple of 8");
+	g_mic_jblock_rows = rows_j;
+	return 0;
+}
+static int mic_mode_() {
+	if (g_mic_mode < 0) {
+		const char* e = getenv("MF_MIC_MODE");
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : 2);
+	}
+	return g_mic_mode;
+}
+
+template <int MODE>
+static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+                      const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
+	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
+	const int levels = nti + ntj + ntk - 2;
+	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
+	if constexpr (MODE != 0) {
+		if (mic_mode_() == 2 && d.is3d) {
+			FlowState* f;
+			MF_TRY(rows_prepare(d, &f, st));
+			f->sgen++;
+			if (f->sgen == 0) {
+				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
+				MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
+				f->sgen = 1;
+			}
+			static int rwgs = -1;
+			if (rwgs < 0) {
+				const char* e = getenv("MF_ROWS_WGS");
+				int dev = 0, ncu = 256;
+				(void)hipGetDevice(&dev);
+				(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+				// one bundle per CU measured best (256^3: 834 us per apply with 256 workgroups, 1040 us with 512): the
+				// sweep is bound by the chain of face hand-offs, and a second bundle per CU slows both
+				rwgs = e ? atoi(e) : ncu;
+				if (rwgs < 1) rwgs = 1;
+			}
+			const int grid = f->nblocks < rwgs ? f->nblocks : rwgs;
+			// MF_ROWS_TRACE=<ticket>: per-block wall-clock stamps (100 MHz) of that bundle's compute wave, printed per launch
+			static long long* trace = nullptr;
+			static int trace_ticket = -2;
+			static const int trace_ticket2 = getenv("MF_ROWS_TRACE2") ? atoi(getenv("MF_ROWS_TRACE2")) : -1;
+			if (trace_ticket == -2) {
+				const char* e = getenv("MF_ROWS_TRACE");
+				trace_ticket = e ? atoi(e) : -1;
+				if (trace_ticket >= 0) {
+					MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 12 * 4096));
+					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 12 * 4096));
+				}
+			}
+			if (vec)
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+			else
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+			MF_LAUNCH_CHECK();
+			if (trace) {
+				static int printed = 0;
+				MF_HIP(hipStreamSynchronize(st));
+				if (printed++ < 4) {
+					const int nb = f->nchunks + 2;
+					long long* h = (long long*)malloc(sizeof(long long) * 4 * nb);
+					MF_HIP(hipMemcpy(h, trace, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
+					fprintf(stderr, "[rows trace] mode %d ticket %d: block: gap ready poll steps (us)\n", MODE, trace_ticket);
+					for (int m = 0; m < nb; m++)
+						fprintf(stderr, "  m=%2d  %6.2f %6.2f %6.2f %6.2f   t=%.2f\n", m, m ? (h[m * 4] - h[m * 4 - 1]) * 0.01 : 0.0, (h[m * 4 + 1] - h[m * 4]) * 0.01,
+						        (h[m * 4 + 2] - h[m * 4 + 1]) * 0.01, (h[m * 4 + 3] - h[m * 4 + 2]) * 0.01, (h[m * 4 + 3] - h[0]) * 0.01);
+					if (trace_ticket2 >= 0) {
+						// producer (ticket) vs consumer (ticket2): consumer block m needs the producer's step 8m+12 (its block m+1)
+						long long* h2 = (long long*)malloc(sizeof(long long) * 4 * nb);
+						MF_HIP(hipMemcpy(h2, trace + 8 * 4096, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
+						fprintf(stderr, "[rows trace] hand-off %d -> %d: m  producer_end(m+1)  consumer_faces_ready(m)  delta   consumer_block_start(m)\n", trace_ticket, trace_ticket2);
+						for (int m = 0; m + 1 < nb; m++)
+							fprintf(stderr, "  m=%2d  %8.2f  %8.2f  %6.2f   %8.2f\n", m, (h[(m + 1) * 4 + 3] - h[0]) * 0.01, (h2[m * 4 + 2] - h[0]) * 0.01,
+							        (h2[m * 4 + 2] - h[(m + 1) * 4 + 3]) * 0.01, (h2[m * 4] - h[0]) * 0.01);
+						free(h2);
+					}
+					free(h);
+					const int ns = f->nblocks < 4096 ? f->nblocks : 4096;
+					long long* g = (long long*)malloc(sizeof(long long) * 2 * ns);
+					MF_HIP(hipMemcpy(g, trace + 4 * 4096, sizeof(long long) * 2 * ns, hipMemcpyDeviceToHost));
+					long long t0 = g[0];
+					for (int i = 0; i < ns; i++) if (g[2 * i] < t0) t0 = g[2 * i];
+					fprintf(stderr, "[rows trace] bundles: ticket start end (us since first start)\n");
+					for (int i = 0, L = 0; i < ns; L++, i += (L < f->nbj ? L : 1) + 0) {
+						fprintf(stderr, "  t=%4d  %8.2f %8.2f\n", i, (g[2 * i] - t0) * 0.01, (g[2 * i + 1] - t0) * 0.01);
+						if (L > 200) break;
+					}
+					free(g);
+					long long* hw = (long long*)malloc(sizeof(long long) * ns);
+					MF_HIP(hipMemcpy(hw, trace + 6 * 4096, sizeof(long long) * ns, hipMemcpyDeviceToHost));
+					fprintf(stderr, "[rows trace] compute wave placement: ticket block simd cu sh se\n");
+					for (int i = 0; i < ns && i < 1024; i += 37) {
+						const unsigned v = (unsigned)hw[i];
+						fprintf(stderr, "  t=%4d blk=%4d simd=%u cu=%u sh=%u se=%u wave=%u\n", i, (int)(hw[i] >> 32), (v >> 4) & 3, (v >> 8) & 15, (v >> 12) & 1, (v >> 13) & 7, v & 15);
+					}
+					free(hw);
+				}
+			}
+			return 0;
+		}
+		if (mic_mode_() >= 1) {
+			FlowState* f;
+			MF_TRY(flow_prepare(d, &f, st, true));
+			f->gen++;
+			if (f->gen == 0) {  // 32-bit wrap: stale tags could alias -> clear once
+				MF_HIP(hipMemsetAsync(f->xch, 0, f->xch_cap, st));
+				f->gen = 1;
+			}
+			static int wgs = -1;
+			if (wgs < 0) {
+				const char* e = getenv("MF_FLOW_WGS");
+				wgs = e ? atoi(e) : 512;   // two single-wave workgroups per CU measured best (256: too few, 1024: contention)
+				if (wgs < 1) wgs = 1;
+			}
+			const int grid = f->ntiles < wgs ? f->ntiles : wgs;
+			if (vec)
+				hipLaunchKernelGGL((k_mic_flow<MODE, true>), dim3(grid), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+			else
+				hipLaunchKernelGGL((k_mic_flow<MODE, false>), dim3(grid), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+			MF_LAUNCH_CHECK();
+			return 0;
+		}
+	}
+	for (int L = 0; L < levels; L++) {
+		if (vec)
+			hipLaunchKernelGGL((k_mic_tiles<MODE, true>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+		else
+			hipLaunchKernelGGL((k_mic_tiles<MODE, false>), dim3(ntj, ntk), dim3(64), 0, st, d, L, nti, ntj, ntk, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+	}
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+
+namespace mf {
+int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+               const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
+	if (mode == 0) return launch_mic<0>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
+	if (mode == 1) return launch_mic<1>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
+	return launch_mic<2>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
+}
+int mic_flow_error() {
+	if (mic_mode_() < 1) return 0;
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	if (!g_flow[dev].ctl) return 0;
+	FlowCtl fc;
+	MF_HIP(hipMemcpy(&fc, g_flow[dev].ctl, sizeof fc, hipMemcpyDeviceToHost));
+	if (fc.err) {
+		MF_HIP(hipMemset(g_flow[dev].ctl, 0, sizeof(FlowCtl)));
+		return fail("MIC dataflow sweep: a workgroup timed out waiting for its predecessor faces");
+	}
+	return 0;
+}
+int mic_mode() { return mic_mode_(); }
+}  // namespace mf
+
+extern "C" {
+
+int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0, const float* Ai,
+                const float* Aj, const float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, (hipStream_t)stream));
+	return mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
+}
+int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
+                 const float* Ai, const float* Aj, const float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	MF_TRY(mic_launch(1, d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream));
+	return mic_launch(2, d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
+}
+
+// a dataflow sweep that gives up waiting for a face (FLOW_SPIN_LIMIT) latches an error flag on the device; mf_cg_solve
+// looks at it itself, callers that drive mf_mic_apply directly (the z-slab solver) ask here once per solve
+int mf_mic_check(void* stream) {
+	MF_HIP(hipStreamSynchronize((hipStream_t)stream));
+	return mic_flow_error();
+}
+
+}  // extern "C"

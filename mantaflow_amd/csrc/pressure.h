@@ -1,0 +1,19 @@
+// pressure.h -- what pressure.hip (PCG loop) and mic.hip (MIC(0) preconditioner sweeps) share.
+#pragma once
+#include "common.h"
+
+// device-resident PCG scalars (GridCg members, conjugategrad.h:95-112): written by one-block kernels, read by every
+// kernel of an iteration; `done` makes the kernels of iterations queued after convergence return at once
+struct CgScalars {
+	float sigma, alpha, nalpha, beta, resNorm, dp, sigmaNew, accuracy;
+	int iterations, done, diverged, useL2;
+};
+
+namespace mf {
+// mode 0: InitPreconditionModifiedIncompCholesky2 (dst := Aprecond, var1 := A0); 1 / 2: forward / backward substitution
+// of ApplyPreconditionModifiedIncompCholesky2.  sc (nullable): skip when sc->done.
+int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+               const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st);
+int mic_mode();          // 0 levels, 1 tiles, 2 rows
+int mic_flow_error();    // reads (and clears) the deadlock-guard flag of the single-launch sweeps; needs a synchronised stream
+}  // namespace mf

@@ -335,6 +335,9 @@ def bench_slab_step(n, dt, steps, warmup, rank, world):
     for _ in range(warmup):
         smoke_step(dom, flags, vel, vel0, dens, pres, stats)
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.freeze()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
