@@ -306,6 +306,22 @@ int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, i
                             float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Wavelet noise (noisefield.{h,cpp}) and the noise-modulated smoke source of scenes/simpleplume.py
+ * ---------------------------------------------------------------------------------------------- */
+/* WaveletNoiseField::generateTile, noisefield.cpp:95-186: the 3 x 128^3 tile for `seed` (the reference's static
+ * randomSeed is 13322223), generated on the host exactly as the reference does (MT19937 + Box-Muller in double, fp32
+ * down/up-sampling filters) and stored to `tile` (device memory for the GPU library). */
+int mf_noise_generate_tile(float* tile, int seed, void* stream);
+/* mSeedOffset = RandomStream(fixedSeed).getVec3Norm(), noisefield.cpp:64-70 (fixedSeed -1 -> randomSeed + 123); host output */
+int mf_noise_seed_offset(int fixedSeed, float* out3_host);
+/* densityInflow -> KnApplyNoiseInfl, plugin/initplugins.cpp:27-43, with WaveletNoiseField::evaluate / WNoise,
+ * noisefield.h:118-137, 313-336.  sdf = shape.computeLevelset().  params (host, 20 floats): [0..2] mGsInv, [3..5]
+ * mSeedOffset, [6] getTime(), [7..9] posScale, [10..12] posOffset, [13] valOffset, [14] valScale, [15] clamp (0|1),
+ * [16] clampNeg, [17] clampPos. */
+int mf_density_inflow(int sx, int sy, int sz, const int32_t* flags, float* density, const float* sdf, const float* tile,
+                      const float* params_host, float scale, float sigma, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * device-scalar variants for the multi-GPU PCG (no reference counterpart: same arithmetic as mf_grid_dot /
  * mf_grid_max_abs / mf_grid_scaled_add / mf_update_search_vec, but the scalar results and factors live in device
  * memory, so a rank never waits for the host between a reduction, its all-gather and the update that uses it)

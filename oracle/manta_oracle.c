@@ -2066,6 +2066,196 @@ int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, i
 	return 0;
 }
 
+/* ================================================================================================
+ * wavelet noise, noisefield.{h,cpp}; MTRand, util/randomstream.h
+ * ============================================================================================== */
+typedef struct {
+	uint32_t state[624];
+	uint32_t* next;
+	int left;
+} MTRand;
+static uint32_t mt_twist(uint32_t m, uint32_t s0, uint32_t s1) {
+	return m ^ (((s0 & 0x80000000u) | (s1 & 0x7fffffffu)) >> 1) ^ ((uint32_t)(-(int32_t)(s1 & 1u)) & 0x9908b0dfu);
+}
+static void mt_reload(MTRand* m) { /* randomstream.h:261-276 */
+	uint32_t* p = m->state;
+	int i;
+	for (i = 624 - 397; i--; ++p) *p = mt_twist(p[397], p[0], p[1]);
+	for (i = 397; --i; ++p) *p = mt_twist(p[397 - 624], p[0], p[1]);
+	*p = mt_twist(p[397 - 624], p[0], m->state[0]);
+	m->left = 624;
+	m->next = m->state;
+}
+static void mt_seed(MTRand* m, uint32_t seed) { /* initialize + reload, randomstream.h:174-179, 243-259 */
+	m->state[0] = seed;
+	for (int i = 1; i < 624; i++) m->state[i] = 1812433253u * (m->state[i - 1] ^ (m->state[i - 1] >> 30)) + (uint32_t)i;
+	mt_reload(m);
+}
+static uint32_t mt_int(MTRand* m) { /* randInt, randomstream.h:138-152 */
+	if (m->left == 0) mt_reload(m);
+	--m->left;
+	uint32_t s1 = *m->next++;
+	s1 ^= (s1 >> 11);
+	s1 ^= (s1 << 7) & 0x9d2c5680u;
+	s1 ^= (s1 << 15) & 0xefc60000u;
+	return s1 ^ (s1 >> 18);
+}
+static double mt_rand(MTRand* m) { return (double)mt_int(m) * (1.0 / 4294967295.0); }
+static double mt_rand_norm(MTRand* m, double mean, double variance) { /* randNorm, randomstream.h:129-136 */
+	double r = sqrt(-2.0 * log(1.0 - ((double)mt_int(m) + 0.5) * (1.0 / 4294967296.0))) * variance;
+	double phi = 2.0 * 3.14159265358979323846264338328 * ((double)mt_int(m) * (1.0 / 4294967296.0));
+	return mean + r * cos(phi);
+}
+
+static const float noise_aCoeffs[32] = {
+	0.000334, -0.001528, 0.000410, 0.003545, -0.000938, -0.008233, 0.002172, 0.019120,
+	-0.005040, -0.044412, 0.011655, 0.103311, -0.025936, -0.243780, 0.033979, 0.655340,
+	0.655340, 0.033979, -0.243780, -0.025936, 0.103311, 0.011655, -0.044412, -0.005040,
+	0.019120, 0.002172, -0.008233, -0.000938, 0.003546, 0.000410, -0.001528, 0.000334};
+static const float noise_pCoeffs[4] = {0.25, 0.75, 0.75, 0.25};
+static void noise_downsample(const float* from, float* to, int n, int stride) { /* noisefield.cpp:42-50 */
+	const float* a = &noise_aCoeffs[16];
+	for (int i = 0; i < n / 2; i++) {
+		to[i * stride] = 0;
+		for (int k = 2 * i - 16; k < 2 * i + 16; k++) to[i * stride] += a[k - 2 * i] * from[(k & 127) * stride];
+	}
+}
+static int mod_slow(int x, int n) {
+	int m = x % n;
+	return (m < 0) ? m + n : m;
+}
+static void noise_upsample(const float* from, float* to, int n, int stride) { /* noisefield.cpp:54-63 */
+	const float* pp = &noise_pCoeffs[1];
+	for (int i = 0; i < n; i++) {
+		to[i * stride] = 0;
+		for (int k = i / 2 - 1; k < i / 2 + 3; k++)
+			to[i * stride] = (float)((double)to[i * stride] + 0.5 * (double)pp[k - i / 2] * (double)from[mod_slow(k, n / 2) * stride]);
+	}
+}
+/* WaveletNoiseField::generateTile, noisefield.cpp:95-186 */
+int mf_noise_generate_tile(float* tile, int seed, void* st) {
+	(void)st;
+	const int n = 128;
+	const int64_t n3 = (int64_t)n * n * n, n3d = n3 * 3;
+	float* noise3 = tile;
+	float* temp13 = (float*)calloc(n3d, sizeof(float));
+	float* temp23 = (float*)calloc(n3d, sizeof(float));
+	if (!temp13 || !temp23) return fail("out of memory");
+	MTRand mt;
+	mt_seed(&mt, (uint32_t)seed);
+	for (int64_t i = 0; i < n3d; i++) noise3[i] = (float)mt_rand_norm(&mt, (double)0.f, (double)1.f);
+	for (int t = 0; t < 3; t++) {
+		for (int iy = 0; iy < n; iy++)
+			for (int iz = 0; iz < n; iz++) {
+				const int64_t i = iy * n + (int64_t)iz * n * n + t * n3;
+				noise_downsample(&noise3[i], &temp13[i], n, 1);
+				noise_upsample(&temp13[i], &temp23[i], n, 1);
+			}
+		for (int ix = 0; ix < n; ix++)
+			for (int iz = 0; iz < n; iz++) {
+				const int64_t i = ix + (int64_t)iz * n * n + t * n3;
+				noise_downsample(&temp23[i], &temp13[i], n, n);
+				noise_upsample(&temp13[i], &temp23[i], n, n);
+			}
+		for (int ix = 0; ix < n; ix++)
+			for (int iy = 0; iy < n; iy++) {
+				const int64_t i = ix + iy * n + t * n3;
+				noise_downsample(&temp23[i], &temp13[i], n, n * n);
+				noise_upsample(&temp13[i], &temp23[i], n, n * n);
+			}
+	}
+	for (int64_t i = 0; i < n3d; i++) noise3[i] -= temp23[i];
+	int offset = n / 2;
+	if (offset % 2 == 0) offset++;
+	int64_t icnt = 0;
+	for (int t = 0; t < 3; t++)
+		for (int ix = 0; ix < n; ix++)
+			for (int iy = 0; iy < n; iy++)
+				for (int iz = 0; iz < n; iz++) {
+					temp13[icnt] = noise3[((ix + offset) & 127) + ((iy + offset) & 127) * n + (int64_t)((iz + offset) & 127) * n * n + t * n3];
+					icnt++;
+				}
+	for (int64_t i = 0; i < n3d; i++) noise3[i] += temp13[i];
+	free(temp13);
+	free(temp23);
+	return 0;
+}
+/* mSeedOffset, noisefield.cpp:64-70 */
+int mf_noise_seed_offset(int fixedSeed, float* out) {
+	if (fixedSeed == -1) fixedSeed = 13322223 + 123;
+	MTRand mt;
+	mt_seed(&mt, (uint32_t)fixedSeed);
+	float v[3];
+	for (int c = 0; c < 3; c++) v[c] = (float)mt_rand(&mt);
+	normalize3(v);
+	out[0] = v[0];
+	out[1] = v[1];
+	out[2] = v[2];
+	return 0;
+}
+/* WNoise, noisefield.h:163-196 */
+static float wnoise(float p0, float p1, float p2, const float* data) {
+	float w[3][3], t, result = 0;
+	const float p[3] = {p0, p1, p2};
+	int mid[3];
+	for (int c = 0; c < 3; c++) {
+		mid[c] = (int)ceilf(p[c] - 0.5f);
+		t = (float)mid[c] - (p[c] - 0.5f);
+		w[c][0] = t * t * 0.5f;
+		w[c][2] = (1.f - t) * (1.f - t) * 0.5f;
+		w[c][1] = 1.f - w[c][0] - w[c][2];
+	}
+	for (int z = -1; z <= 1; z++)
+		for (int y = -1; y <= 1; y++)
+			for (int x = -1; x <= 1; x++) {
+				float weight = 1.0f;
+				const int xC = (mid[0] + x) & 127;
+				weight *= w[0][x + 1];
+				const int yC = (mid[1] + y) & 127;
+				weight *= w[1][y + 1];
+				const int zC = (mid[2] + z) & 127;
+				weight *= w[2][z + 1];
+				result += weight * data[(zC * 128 + yC) * 128 + xC];
+			}
+	return result;
+}
+/* WaveletNoiseField::evaluate, noisefield.h:313-336 */
+static float noise_evaluate(const float* P, const float* tile, float x, float y, float z) {
+	float pos[3] = {x, y, z};
+	for (int c = 0; c < 3; c++) pos[c] *= P[c];
+	for (int c = 0; c < 3; c++) pos[c] += P[3 + c];
+	for (int c = 0; c < 3; c++) pos[c] += P[6];
+	for (int c = 0; c < 3; c++) pos[c] *= P[7 + c];
+	for (int c = 0; c < 3; c++) pos[c] += P[10 + c];
+	float v = wnoise(pos[0], pos[1], pos[2], tile);
+	v += P[13];
+	v *= P[14];
+	if (P[15] != 0.f) {
+		if (v < P[16]) v = P[16];
+		if (v > P[17]) v = P[17];
+	}
+	return v;
+}
+/* KnApplyNoiseInfl, plugin/initplugins.cpp:27-36 */
+int mf_density_inflow(int sx, int sy, int sz, const int32_t* flags, float* density, const float* sdf, const float* tile,
+                      const float* P, float scale, float sigma, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				const int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID) || sdf[idx] > sigma) continue;
+				double f = 1.0 - 0.5 / (double)sigma * (double)(sdf[idx] + sigma);
+				if (f < 0.0) f = 0.0;
+				else if (f > 1.0) f = 1.0;
+				const float factor = (float)f;
+				const float target = noise_evaluate(P, tile, (float)i, (float)j, (float)k) * scale * factor;
+				if (density[idx] < target) density[idx] = target;
+			}
+	return 0;
+}
+
 /* device-scalar variants (here: host pointers) */
 int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out, void* s) {
 	(void)s;

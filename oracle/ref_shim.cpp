@@ -17,6 +17,8 @@
 #include "commonkernels.h"
 #include "levelset.h"
 #include "mantaio.h"
+#include "shapes.h"
+#include "noisefield.h"
 #include <cstring>
 #include <string>
 #include <vector>
@@ -90,6 +92,8 @@ void updateVelocityFromDeltaPos(const BasicParticleSystem& parts, ParticleDataIm
                                 const int exclude);                                                       // ptsplugins.cpp:38
 void eulerStep(BasicParticleSystem& parts, const ParticleDataImpl<Vec3>& vel, const ParticleDataImpl<int>* ptype,
                const int exclude);                                                                        // ptsplugins.cpp:50
+void densityInflow(const FlagGrid& flags, Grid<Real>& density, const WaveletNoiseField& noise, Shape* shape, Real scale,
+                   Real sigma);                                                                           // initplugins.cpp:39
 void interpolateGrid(Grid<Real>& target, const Grid<Real>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);      // waveletturbulence.cpp:37
 void interpolateGridVec3(Grid<Vec3>& target, const Grid<Vec3>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);  // :51
 void interpolateMACGrid(MACGrid& target, const MACGrid& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);         // :73
@@ -773,6 +777,93 @@ int ref_interpolate_grid(int kind, int tsx, int tsy, int tsz, float* target, int
 	} else {
 		MacIO t(ct, target, true), s(cs, source, false);
 		interpolateMACGrid(t.g, s.g, scale, off, size, 1);
+	}
+	SHIM_CATCH
+}
+
+/* shapes: kind 0 Box(p0 = a, p1 = b), 1 Sphere(center a, radius b.x, scale c), 2 Cylinder(center a, radius b.x, z c) */
+static Shape* make_shape(Ctx& c, int kind, const float* q) {
+	const Vec3 a(q[0], q[1], q[2]), b(q[3], q[4], q[5]), cc(q[6], q[7], q[8]);
+	if (kind == 0) return new Box(&c.solver, Vec3::Invalid, a, b, Vec3::Invalid);
+	if (kind == 1) return new Sphere(&c.solver, a, b.x, cc);
+	return new Cylinder(&c.solver, a, b.x, cc);
+}
+/* Shape::computeLevelset, shapes.cpp */
+int ref_shape_levelset(int sx, int sy, int sz, int kind, const float* q, float* phi) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	std::unique_ptr<Shape> sh(make_shape(c, kind, q));
+	LevelRef ph(c, phi);
+	sh->generateLevelset(*ph.g);
+	SHIM_CATCH
+}
+/* the reference's wavelet noise tile (3 x 128^3, generated once per process) and seed offset */
+int ref_noise_tile(float* out) {
+	SHIM_TRY
+	Ctx c(8, 8, 8, 1.f);
+	WaveletNoiseField nf(&c.solver, -1, 0);
+	memcpy(out, nf.data(), sizeof(float) * 3 * 128 * 128 * 128);
+	SHIM_CATCH
+}
+/* densityInflow, initplugins.cpp:27-43: P = posScale[3], posOffset[3], valOffset, valScale, clamp, clampNeg, clampPos, timeAnim */
+int ref_density_inflow(int sx, int sy, int sz, float timeTotal, const int32_t* flags, float* density, int kind, const float* q,
+                       int fixedSeed, const float* P, float scale, float sigma) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	c.solver.mTimeTotal = timeTotal;
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	RealRef d(c, density);
+	std::unique_ptr<Shape> sh(make_shape(c, kind, q));
+	WaveletNoiseField nf(&c.solver, fixedSeed, 0);
+	nf.mPosScale = Vec3(P[0], P[1], P[2]);
+	nf.mPosOffset = Vec3(P[3], P[4], P[5]);
+	nf.mValOffset = P[6];
+	nf.mValScale = P[7];
+	nf.mClamp = P[8] != 0.f;
+	nf.mClampNeg = P[9];
+	nf.mClampPos = P[10];
+	nf.mTimeAnim = P[11];
+	densityInflow(fl, d.ref(), nf, sh.get(), scale, sigma);
+	SHIM_CATCH
+}
+
+/* scenes/simpleplume.py driven through the reference's own classes and plugins (the loop below is this shim's code: same
+ * calls, same arguments, same order as the scene's main loop), `steps` steps at resolution `res`.  Outputs: density
+ * [sz][sy][sx], velocity SoA [3][sz][sy][sx]. */
+int ref_simpleplume(int res, int steps, int inflow_steps, float* density_out, float* vel_out) {
+	SHIM_TRY
+	const Vec3i gsi(res, int(1.5 * res), res);
+	const Vec3 gs(gsi.x, gsi.y, gsi.z);
+	FluidSolver solver(gsi, 3);
+	FlagGrid flags(&solver);
+	MACGrid vel(&solver);
+	Grid<Real> density(&solver), pressure(&solver);
+	WaveletNoiseField noise(&solver, -1, 0);
+	noise.mPosScale = Vec3(45);
+	noise.mClamp = true;
+	noise.mClampNeg = 0;
+	noise.mClampPos = 1;
+	noise.mValOffset = 0.75;
+	noise.mTimeAnim = 0.2;
+	Cylinder source(&solver, gs * Vec3(0.5, 0.1, 0.5), res * 0.14, gs * Vec3(0, 0.02, 0));
+	flags.initDomain(0, "xXyYzZ", "      ", "      ", "      ", nullptr);
+	flags.fillGrid();
+	for (int t = 0; t < steps; t++) {
+		if (t < inflow_steps) densityInflow(flags, density, noise, &source, 1, 0.5);
+		advectSemiLagrange(&flags, &vel, &density, 2, 1.0, 1, false, -1, 2, 1);
+		advectSemiLagrange(&flags, &vel, &vel, 2, 1.0, 1, false, -1, 2, 1);
+		setWallBcs(flags, vel, nullptr, nullptr, nullptr, 0);
+		addBuoyancy(flags, density, vel, Vec3(0, -6e-4, 0), 1.0, true);
+		solvePressure(vel, pressure, flags, 1e-3, nullptr, nullptr, nullptr, nullptr, 0.01, 1.5, true, 1, false, false, false,
+		              nullptr, 0., nullptr);
+		solver.step();
+	}
+	const int64_t n = (int64_t)gsi.x * gsi.y * gsi.z;
+	for (int64_t i = 0; i < n; i++) {
+		density_out[i] = density[i];
+		vel_out[i] = vel[i].x;
+		vel_out[n + i] = vel[i].y;
+		vel_out[2 * n + i] = vel[i].z;
 	}
 	SHIM_CATCH
 }

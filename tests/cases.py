@@ -647,6 +647,42 @@ def run_interp_ref(sd, td, scale, offset, size, fields):
     return out
 
 
+def run_simpleplume_pkg(res, steps, inflow_steps=100):
+    """the main loop of scenes/simpleplume.py (BASELINE config 0) through the package"""
+    from mantaflow_amd import core, plugins, scene
+    v3 = core.vec3
+    gs = v3(res, int(1.5 * res), res)
+    s = core.FluidSolver(name="main", gridSize=gs)
+    flags, vel, density, pressure = s.create(core.FlagGrid), s.create(core.MACGrid), s.create(core.RealGrid), s.create(core.RealGrid)
+    noise = s.create(scene.NoiseField, loadFromFile=True)
+    noise.posScale = v3(45)
+    noise.clamp, noise.clampNeg, noise.clampPos = True, 0, 1
+    noise.valOffset, noise.timeAnim = 0.75, 0.2
+    source = s.create(scene.Cylinder, center=gs * v3(0.5, 0.1, 0.5), radius=res * 0.14, z=gs * v3(0, 0.02, 0))
+    flags.initDomain()
+    flags.fillGrid()
+    iters = []
+    for t in range(steps):
+        if t < inflow_steps:
+            scene.densityInflow(flags=flags, density=density, noise=noise, shape=source, scale=1, sigma=0.5)
+        plugins.advectSemiLagrange(flags=flags, vel=vel, grid=density, order=2)
+        plugins.advectSemiLagrange(flags=flags, vel=vel, grid=vel, order=2, strength=1.0)
+        plugins.setWallBcs(flags=flags, vel=vel)
+        plugins.addBuoyancy(density=density, vel=vel, gravity=v3(0, -6e-4, 0), flags=flags)
+        plugins.solvePressure(flags=flags, vel=vel, pressure=pressure)
+        iters.append(plugins.lastCgStats()["iterations"])
+        s.step()
+    s.sync()
+    return {"density": grid_to_soa(density), "vel": grid_to_soa(vel), "iters": iters}
+
+
+def run_simpleplume_ref(res, steps, inflow_steps=100):
+    sx, sy, sz = res, int(1.5 * res), res
+    rd, rv = np.zeros((sz, sy, sx), np.float32), np.zeros((3, sz, sy, sx), np.float32)
+    refcall("ref_simpleplume", res, steps, inflow_steps, rd, rv)
+    return {"density": rd, "vel": rv}
+
+
 def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims, dt)
@@ -730,6 +766,8 @@ def golden_outputs(impl, deterministic_p2g=True):
         out["glue_" + k] = v
     for k, v in run_surface_pkg(gd, surface_inputs(gd, 51)).items():
         out["surf_" + k] = v
+    r = run_simpleplume_pkg(16, 5)
+    out["plume_density"], out["plume_vel"] = r["density"], r["vel"]
     return out
 
 

@@ -62,6 +62,9 @@ def main():
         out["glue_" + k] = v
     for k, v in cases.run_surface_ref(gd, cases.surface_inputs(gd, 51)).items():
         out["surf_" + k] = v
+    # BASELINE config 0: scenes/simpleplume.py, 5 steps at res 16, through the reference's own classes (ref_simpleplume)
+    r = cases.run_simpleplume_ref(16, 5)
+    out["plume_density"], out["plume_vel"] = r["density"], r["vel"]
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote %d arrays, %.1f KiB" % (len(out), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")) / 1024))
 

@@ -1,5 +1,7 @@
 """Pins the plain-C oracle restatement (oracle/manta_oracle.c) and the package's host orchestration against the
 reference's own compiled C++ (oracle/_ref/libmanta_ref.so, built by oracle/ref.mk).  Bit-exact everywhere."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -238,6 +240,66 @@ def test_interpolate_between_grid_sizes(oracle_backend, case):
     b = cases.run_interp_ref(sd, td, scale, offset, size, fields)
     for k in b:
         assert_bitexact(a[k], b[k], "%s case %d" % (k, case))
+
+
+SHAPES = [  # kind, 9 floats (see ref_shape_levelset), constructor
+    (0, (2.5, 3.0, 1.5, 9.25, 8.0, 6.5, 0, 0, 0), lambda sc, s: sc.Box(parent=s, p0=(2.5, 3.0, 1.5), p1=(9.25, 8.0, 6.5))),
+    (1, (6.0, 5.5, 4.0, 3.25, 0, 0, 1.0, 1.5, 0.75), lambda sc, s: sc.Sphere(parent=s, center=(6.0, 5.5, 4.0), radius=3.25, scale=(1.0, 1.5, 0.75))),
+    (2, (6.5, 2.0, 5.0, 2.75, 0, 0, 0, 1.5, 0), lambda sc, s: sc.Cylinder(parent=s, center=(6.5, 2.0, 5.0), radius=2.75, z=(0, 1.5, 0))),
+    (2, (5.0, 5.0, 5.0, 2.0, 0, 0, 1.0, 2.0, 0.5), lambda sc, s: sc.Cylinder(parent=s, center=(5.0, 5.0, 5.0), radius=2.0, z=(1.0, 2.0, 0.5))),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SHAPES)))
+@pytest.mark.parametrize("dims", [(13, 11, 9), (16, 12, 1)])
+def test_shape_levelsets(oracle_backend, case, dims):
+    """Box / Sphere / Cylinder signed distance fields (shapes.cpp) -- the inputs of densityInflow"""
+    from mantaflow_amd import core, scene
+    kind, q, mk = SHAPES[case]
+    s = cases._mk_solver(dims)
+    to3 = lambda t: core.vec3(*t)
+    class SC:   # constructors taking tuples
+        Box = staticmethod(lambda parent, p0, p1: scene.Box(parent=parent, p0=to3(p0), p1=to3(p1)))
+        Sphere = staticmethod(lambda parent, center, radius, scale: scene.Sphere(parent=parent, center=to3(center), radius=radius, scale=to3(scale)))
+        Cylinder = staticmethod(lambda parent, center, radius, z: scene.Cylinder(parent=parent, center=to3(center), radius=radius, z=to3(z)))
+    ours = mk(SC, s).computeLevelset().to_numpy()
+    ref = np.zeros((dims[2], dims[1], dims[0]), np.float32)
+    util.refcall("ref_shape_levelset", dims[0], dims[1], dims[2], kind, np.array(q, np.float32), ref)
+    assert_bitexact(ours, ref, "levelset of shape %d" % case)
+
+
+def test_noise_tile_and_density_inflow(oracle_backend, oracle):
+    """the wavelet noise tile (3 x 128^3, noisefield.cpp:95-186) and densityInflow (initplugins.cpp:27-43) with the source
+    of scenes/simpleplume.py: bit-identical to the reference"""
+    from mantaflow_amd import core, scene
+    tile = np.zeros(3 * 128 ** 3, np.float32)
+    oracle.lib.call("mf_noise_generate_tile", util.P(tile), 13322223, None)
+    ref_tile = np.zeros_like(tile)
+    util.refcall("ref_noise_tile", ref_tile)
+    assert_bitexact(tile, ref_tile, "wavelet noise tile")
+    dims = (24, 32, 20)
+    sx, sy, sz = dims
+    for t_total, sigma, seed in ((0.0, 0.5, -1), (3.5, 0.5, -1), (1.25, 0.0, 77), (2.0, 1.5, 5)):
+        s = cases._mk_solver(dims)
+        s.timeTotal = t_total
+        flags = util.make_flags(sx, sy, sz, 81)
+        fl = cases.soa_to_grid(core.FlagGrid(s), flags)
+        d0 = (util.rand_real((sz, sy, sx), 82) * 0.3).astype(np.float32)
+        dens = cases.soa_to_grid(core.Grid(s), d0)
+        noise = scene.NoiseField(parent=s, fixedSeed=seed, loadFromFile=True)
+        noise.posScale = core.vec3(45)
+        noise.clamp, noise.clampNeg, noise.clampPos = True, 0, 1
+        noise.valOffset, noise.timeAnim = 0.75, 0.2
+        src = scene.Cylinder(parent=s, center=core.vec3(12, 4, 10), radius=4.5, z=core.vec3(0, 1.5, 0))
+        scene.densityInflow(flags=fl, density=dens, noise=noise, shape=src, scale=1, sigma=sigma)
+        ours = cases.grid_to_soa(dens)
+        ref = d0.copy()
+        q = np.array([12, 4, 10, 4.5, 0, 0, 0, 1.5, 0], np.float32)
+        P = np.array([45, 45, 45, 0, 0, 0, 0.75, 1.0, 1, 0, 1, 0.2], np.float32)
+        cf = ctypes.c_float
+        util.refcall("ref_density_inflow", sx, sy, sz, cf(t_total), flags, ref, 2, q, seed, P, cf(1.0), cf(sigma))
+        assert (ref != d0).sum() > 50
+        assert_bitexact(ours, ref, "densityInflow t=%g sigma=%g" % (t_total, sigma))
 
 
 def test_init_domain_matches_reference(oracle_backend):

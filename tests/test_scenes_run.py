@@ -72,3 +72,20 @@ def test_benchmark_dam(oracle_backend):
     assert ((fl & 1) != 0).sum() > 2000
     phi = g["gPhi"].to_numpy()
     assert (phi < 0).sum() > 2000 and np.isfinite(phi).all()
+
+
+def test_simpleplume_end_to_end_equals_reference(oracle_backend):
+    """BASELINE config 0: scenes/simpleplume.py (noise-textured smoke source, MacCormack advection, buoyancy, MIC-CG) run
+    UNCHANGED through `from manta import *` (only the resolution and the frame count are edited in the text) gives the
+    same density and velocity, bit for bit, as the same loop driven through the reference's own classes."""
+    import numpy as np
+    res, steps = 24, 6
+    g = run_scene("simpleplume.py", steps, [("res = 64", "res = %d" % res)])
+    d, v = g["density"].to_numpy(), g["vel"].to_numpy()
+    sx, sy, sz = res, int(1.5 * res), res
+    rd = np.zeros((sz, sy, sx), np.float32)
+    rv = np.zeros((3, sz, sy, sx), np.float32)
+    util.refcall("ref_simpleplume", res, steps, 100, rd, rv)
+    assert rd.max() > 0.5 and np.abs(rv).max() > 1e-3
+    util.assert_bitexact(d, rd, "simpleplume density after %d steps" % steps)
+    util.assert_bitexact(np.ascontiguousarray(v.transpose(3, 0, 1, 2)), rv, "simpleplume velocity after %d steps" % steps)
