@@ -322,6 +322,25 @@ int mf_density_inflow(int sx, int sy, int sz, const int32_t* flags, float* densi
                       const float* params_host, float scale, float sigma, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * wavelet turbulence pieces of scenes/waveletTurbulence.py (plugin/waveletturbulence.cpp, plugin/extforces.cpp)
+ * ---------------------------------------------------------------------------------------------- */
+/* computeEnergy -> KnApplyComputeEnergy, waveletturbulence.cpp:180-194 */
+int mf_compute_energy(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* energy, void* stream);
+/* vorticityConfinement, extforces.cpp:409-428: GetCentered (commonkernels.h:126-131), CurlOp (:38-47), GridNorm (:116-118),
+ * KnConfForce, KnApplyForceField (extforces.cpp:24-43, additive, not MAC).  velCenter/curl/force: zeroed Vec3 scratch grids,
+ * norm: Real scratch grid; strengthCell nullable. */
+int mf_vorticity_confinement(int sx, int sy, int sz, float* vel, const int32_t* flags, float strength,
+                             const float* strengthCell, float* velCenter, float* curl, float* norm, float* force, void* stream);
+/* computeWaveletCoeffs -> WaveletNoiseField::computeCoefficients, noisefield.cpp:191-297; temp1/temp2: Real scratch grids */
+int mf_compute_wavelet_coeffs(int sx, int sy, int sz, float* input, float* temp1, float* temp2, void* stream);
+/* applyNoiseVec3 -> knApplyNoiseVec3, waveletturbulence.cpp:120-178 (no uv grid): target += evaluateCurl((i,j,k)+0.5) *
+ * scaleSpatial...) * scale * w, w = weight(i,j,k) or, when the weight grid has another size, weight.getInterpolated.
+ * params as for mf_density_inflow; weight nullable. */
+int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* target, const float* tile,
+                        const float* params_host, float scale, float scaleSpatial, const float* weight, int wsx, int wsy,
+                        int wsz, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * device-scalar variants for the multi-GPU PCG (no reference counterpart: same arithmetic as mf_grid_dot /
  * mf_grid_max_abs / mf_grid_scaled_add / mf_update_search_vec, but the scalar results and factors live in device
  * memory, so a rank never waits for the host between a reduction, its all-gather and the update that uses it)

@@ -9,7 +9,8 @@ from .plugins import (Timings, extrapolateMACFromWeight, extrapolateMACSimple, m
                       mapPartsToGrid, mapPartsToGridVec3, mapPartsToMAC, setDeterministicP2G, setWallBcs, solvePressure,
                       solvePressureSystem, pushOutofObs, gridParticleIndex, unionParticleLevelset, extrapolateLsSimple,
                       setPartType, markIsolatedFluidCell, addForcePvel, updateVelocityFromDeltaPos, eulerStep,
-                      interpolateGrid, interpolateGridVec3, interpolateMACGrid)
+                      interpolateGrid, interpolateGridVec3, interpolateMACGrid, computeEnergy, computeWaveletCoeffs,
+                      vorticityConfinement, applyNoiseVec3, setOpenBound)
 
 from .scene import (Box, Cylinder, Gui, NoiseField, Shape, Sphere, densityInflow, sampleFlagsWithParticles,
                     sampleLevelsetWithParticles, sampleShapeWithParticles)

@@ -515,6 +515,76 @@ def interpolateMACGrid(target, source, scale=vec3(1.), offset=vec3(0.), size=Non
 
 
 # =========================================================================================================
+# wavelet turbulence pieces of scenes/waveletTurbulence.py
+# =========================================================================================================
+@plugin
+def computeEnergy(flags, vel, energy):
+    """waveletturbulence.cpp:180-194"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(vel, MACGrid, "MACGrid"); _chk(energy, Grid, "Grid<Real>")
+    s = flags.parent
+    s.lib.call("mf_compute_energy", flags.sx, flags.sy, flags.sz, flags.ptr, vel.ptr, energy.ptr, s.stream)
+
+
+@plugin
+def computeWaveletCoeffs(input):
+    """waveletturbulence.cpp:197-201 -> WaveletNoiseField::computeCoefficients"""
+    _chk(input, Grid, "Grid<Real>")
+    s = input.parent
+    t1, t2 = Grid(s), Grid(s)
+    s.lib.call("mf_compute_wavelet_coeffs", input.sx, input.sy, input.sz, input.ptr, t1.ptr, t2.ptr, s.stream)
+
+
+@plugin
+def vorticityConfinement(vel, flags, strength=0, strengthCell=None):
+    """extforces.cpp:409-428"""
+    _chk(vel, MACGrid, "MACGrid"); _chk(flags, FlagGrid, "FlagGrid")
+    strengthCell = _opt(strengthCell, Grid, "Grid<Real>")
+    s = flags.parent
+    vc, curl, force, nrm = VecGrid(s), VecGrid(s), VecGrid(s), Grid(s)
+    s.lib.call("mf_vorticity_confinement", flags.sx, flags.sy, flags.sz, vel.ptr, flags.ptr, float(strength),
+               None if strengthCell is None else strengthCell.ptr, vc.ptr, curl.ptr, nrm.ptr, force.ptr, s.stream)
+
+
+@plugin
+def applyNoiseVec3(flags, target, noise, scale=1.0, scaleSpatial=1.0, weight=None, uv=None):
+    """waveletturbulence.cpp:120-178 (weight grid of any size; the uv variant is outside the hot path)"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(target, VecGrid, "Grid<Vec3>")
+    if uv is not None:
+        raise RuntimeError("applyNoiseVec3: the uv-grid variant is outside the hot path")
+    weight = _opt(weight, Grid, "Grid<Real>")
+    s = flags.parent
+    w = (None, 0, 0, 0) if weight is None else (weight.ptr, weight.sx, weight.sy, weight.sz)
+    s.lib.call("mf_apply_noise_vec3", flags.sx, flags.sy, flags.sz, flags.ptr, target.ptr, _ptr(noise._tile), noise._params(),
+               float(scale), float(scaleSpatial), w[0], w[1], w[2], w[3], s.stream)
+
+
+@plugin
+def setOpenBound(flags, bWidth, openBound="", type=16 | 4):
+    """extforces.cpp:106-131 (scene set-up: flag edit on the host)"""
+    _chk(flags, FlagGrid, "FlagGrid")
+    if openBound == "":
+        return
+    lo = {c: (c in openBound) for c in "xyz"}
+    up = {c: (c.upper() in openBound) for c in "xyz"}
+    f = flags.to_numpy()
+    sz, sy, sx = f.shape
+    k, j, i = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+    bw = int(bWidth)
+    loX, loY = lo["x"] & (i <= bw), lo["y"] & (j <= bw)
+    upX, upY = up["x"] & (i >= sx - bw - 1), up["y"] & (j >= sy - bw - 1)
+    inI, inJ = (i > bw) & (i < sx - bw - 1), (j > bw) & (j < sy - bw - 1)
+    obs = (f & core.TypeObstacle) != 0
+    if not flags.is3D():
+        m = (loX | upX | loY | upY) & (loX | upX | inI) & (loY | upY | inJ) & obs
+    else:
+        loZ, upZ = lo["z"] & (k <= bw), up["z"] & (k >= sz - bw - 1)
+        inK = (k > bw) & (k < sz - bw - 1)
+        m = (loX | upX | loY | upY | loZ | upZ) & (loX | upX | inI) & (loY | upY | inJ) & (loZ | upZ | inK) & obs
+    f[m] = int(type)
+    flags.from_numpy(f)
+
+
+# =========================================================================================================
 # glue (SURVEY 8f-1)
 # =========================================================================================================
 @plugin

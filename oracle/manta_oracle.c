@@ -2256,6 +2256,253 @@ int mf_density_inflow(int sx, int sy, int sz, const int32_t* flags, float* densi
 	return 0;
 }
 
+/* ================================================================================================
+ * wavelet turbulence pieces: plugin/waveletturbulence.cpp, plugin/extforces.cpp:409-428, noisefield.cpp:191-297
+ * ============================================================================================== */
+/* KnApplyComputeEnergy, waveletturbulence.cpp:180-189 */
+int mf_compute_energy(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* energy, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	for (int64_t idx = 0; idx < d.n; idx++) {
+		float e = 0.f;
+		if (flags[idx] & MF_FLUID) {
+			float v[3];
+			get_centered(&d, vel, idx, v);
+			e = (float)(0.5 * (double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+		}
+		energy[idx] = e;
+	}
+	return 0;
+}
+/* norm(), vectorbase.h:385-389 */
+static float norm3(float x, float y, float z) {
+	const float l = x * x + y * y + z * z;
+	const float eps2 = 1e-6f * 1e-6f;
+	if (l <= eps2) return 0.f;
+	return (fabs((double)l - 1.) < eps2) ? 1.f : sqrtf(l);
+}
+int mf_vorticity_confinement(int sx, int sy, int sz, float* vel, const int32_t* flags, float strength, const float* strengthCell,
+                             float* vc, float* curl, float* nrm, float* force, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n, Y = d.Y, Z = d.Z;
+	memset(vc, 0, sizeof(float) * 3 * n);
+	memset(curl, 0, sizeof(float) * 3 * n);
+	memset(force, 0, sizeof(float) * 3 * n);
+#define IN_LOOP                                    \
+	for (int k = K0(d, 1); k < K1(d, 1); k++)      \
+		for (int j = 1; j < sy - 1; j++)           \
+			for (int i = 1; i < sx - 1; i++)
+	/* GetCentered, commonkernels.h:126-131 */
+	IN_LOOP {
+		const int64_t idx = IDX(d, i, j, k);
+		vc[idx] = (float)(0.5 * (double)(vel[idx] + vel[idx + 1]));
+		vc[n + idx] = (float)(0.5 * (double)(vel[n + idx] + vel[n + idx + Y]));
+		float vz = (float)(0.5 * (double)(vel[2 * n + idx] + 0.f));
+		if (d.is3d) vz = (float)((double)vz + 0.5 * (double)vel[2 * n + idx + Z]);
+		else vz = 0.f;
+		vc[2 * n + idx] = vz;
+	}
+	/* CurlOp, commonkernels.h:38-47 */
+	IN_LOOP {
+		const int64_t idx = IDX(d, i, j, k);
+		const float *gx = vc, *gy = vc + n, *gz = vc + 2 * n;
+		float v0 = 0.f, v1 = 0.f;
+		const float v2 = (float)(0.5 * (double)((gy[idx + 1] - gy[idx - 1]) - (gx[idx + Y] - gx[idx - Y])));
+		if (d.is3d) {
+			v0 = (float)(0.5 * (double)((gz[idx + Y] - gz[idx - Y]) - (gy[idx + Z] - gy[idx - Z])));
+			v1 = (float)(0.5 * (double)((gx[idx + Z] - gx[idx - Z]) - (gz[idx + 1] - gz[idx - 1])));
+		}
+		curl[idx] = v0;
+		curl[n + idx] = v1;
+		curl[2 * n + idx] = v2;
+	}
+	/* GridNorm, commonkernels.h:116-118 */
+	for (int64_t idx = 0; idx < n; idx++) nrm[idx] = norm3(curl[idx], curl[n + idx], curl[2 * n + idx]);
+	/* KnConfForce, extforces.cpp:410-417 */
+	IN_LOOP {
+		const int64_t idx = IDX(d, i, j, k);
+		float g[3];
+		g[0] = (float)(0.5 * (double)(nrm[idx + 1] - nrm[idx - 1]));
+		g[1] = (float)(0.5 * (double)(nrm[idx + Y] - nrm[idx - Y]));
+		g[2] = (float)(0.5 * 0.);
+		if (d.is3d) g[2] = (float)(0.5 * (double)(nrm[idx + Z] - nrm[idx - Z]));
+		normalize3(g);
+		float str = strength;
+		if (strengthCell) str += strengthCell[idx];
+		const float cx = curl[idx], cy = curl[n + idx], cz = curl[2 * n + idx];
+		force[idx] = str * ((g[1] * cz) - (g[2] * cy));
+		force[n + idx] = str * ((g[2] * cx) - (g[0] * cz));
+		force[2 * n + idx] = str * ((g[0] * cy) - (g[1] * cx));
+	}
+	/* KnApplyForceField(additive, !isMAC), extforces.cpp:24-43 */
+	IN_LOOP {
+		const int64_t idx = IDX(d, i, j, k);
+		const int curFluid = flags[idx] & MF_FLUID, curEmpty = flags[idx] & MF_EMPTY;
+		if (!curFluid && !curEmpty) continue;
+		const float fx = (float)(0.5 * (double)(force[idx - 1] + force[idx]));
+		const float fy = (float)(0.5 * (double)(force[n + idx - Y] + force[n + idx]));
+		float fz = 0.f;
+		if (d.is3d) fz = (float)(0.5 * (double)(force[2 * n + idx - Z] + force[2 * n + idx]));
+		if ((flags[idx - 1] & MF_FLUID) || (curFluid && (flags[idx - 1] & MF_EMPTY))) vel[idx] = vel[idx] + fx;
+		if ((flags[idx - Y] & MF_FLUID) || (curFluid && (flags[idx - Y] & MF_EMPTY))) vel[n + idx] = vel[n + idx] + fy;
+		if (d.is3d && ((flags[idx - Z] & MF_FLUID) || (curFluid && (flags[idx - Z] & MF_EMPTY)))) vel[2 * n + idx] = vel[2 * n + idx] + fz;
+	}
+#undef IN_LOOP
+	return 0;
+}
+/* downsampleNeumann / upsampleNeumann, noisefield.cpp:191-227 */
+static void noise_downsample_neumann(const float* from, float* to, int n, int64_t stride) {
+	const float* a = &noise_aCoeffs[16];
+	for (int i = 0; i < n / 2; i++) {
+		to[i * stride] = 0;
+		for (int k = 2 * i - 16; k < 2 * i + 16; k++) {
+			float fv;
+			if (k < 0) fv = from[0];
+			else if (k > n - 1) fv = from[(n - 1) * stride];
+			else fv = from[k * stride];
+			to[i * stride] += a[k - 2 * i] * fv;
+		}
+	}
+}
+static void noise_upsample_neumann(const float* from, float* to, int n, int64_t stride) {
+	const float* pp = &noise_pCoeffs[1];
+	for (int i = 0; i < n; i++) {
+		to[i * stride] = 0;
+		for (int k = i / 2 - 1; k < i / 2 + 3; k++) {
+			float fv;
+			if (k > n / 2 - 1) fv = from[(n / 2 - 1) * stride];
+			else if (k < 0) fv = from[0];
+			else fv = from[k * stride];
+			to[i * stride] = (float)((double)to[i * stride] + 0.5 * (double)pp[k - i / 2] * (double)fv);
+		}
+	}
+}
+/* WaveletNoiseField::computeCoefficients, noisefield.cpp:229-297 */
+int mf_compute_wavelet_coeffs(int sx, int sy, int sz, float* input, float* temp13, float* temp23, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n3 = d.n, sxy = (int64_t)sx * sy;
+	float* noise3 = input;
+	for (int64_t i = 0; i < n3; i++) temp13[i] = temp23[i] = 0.f;
+	for (int iz = 0; iz < sz; iz++)
+		for (int iy = 0; iy < sy; iy++) {
+			const int64_t i = iz * sxy + (int64_t)iy * sx;
+			noise_downsample_neumann(&noise3[i], &temp13[i], sx, 1);
+			noise_upsample_neumann(&temp13[i], &temp23[i], sx, 1);
+		}
+	for (int iz = 0; iz < sz; iz++)
+		for (int ix = 0; ix < sx; ix++) {
+			const int64_t i = iz * sxy + ix;
+			noise_downsample_neumann(&temp23[i], &temp13[i], sy, sx);
+			noise_upsample_neumann(&temp13[i], &temp23[i], sy, sx);
+		}
+	if (d.is3d)
+		for (int iy = 0; iy < sy; iy++)
+			for (int ix = 0; ix < sx; ix++) {
+				const int64_t i = (int64_t)iy * sx + ix;
+				noise_downsample_neumann(&temp23[i], &temp13[i], sz, sxy);
+				noise_upsample_neumann(&temp13[i], &temp23[i], sz, sxy);
+			}
+	for (int64_t i = 0; i < n3; i++) {
+		const float residual = noise3[i] - temp23[i];
+		temp13[i] = sqrtf(fabsf(residual));
+	}
+	float smoothingFactor = (float)(1. / 6.);
+	if (!d.is3d) smoothingFactor = (float)(1. / 4.);
+	for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int j = 1; j < sy - 1; j++)
+			for (int i = 1; i < sx - 1; i++) {
+				const int64_t c = k * sxy + (int64_t)j * sx + i;
+				float res = temp13[c - 1] + temp13[c + 1];
+				res += temp13[c - sx] + temp13[c + sx];
+				if (d.is3d) res += temp13[c - sxy] + temp13[c + sxy];
+				input[c] = res * smoothingFactor;
+			}
+	return 0;
+}
+/* WNoiseVec, noisefield.h:210-310 */
+static void wnoise_vec(float p0, float p1, float p2, const float* data, float out[3]) {
+	const float p[3] = {p0, p1, p2};
+	int mid[3];
+	float t[3], w[3][3], dw[3][3], nb[3][3][3];
+	for (int c = 0; c < 3; c++) {
+		mid[c] = (int)ceil((double)(p[c] - 0.5f));
+		t[c] = (float)mid[c] - (p[c] - 0.5f);
+	}
+	for (int z = -1; z <= 1; z++)
+		for (int y = -1; y <= 1; y++)
+			for (int x = -1; x <= 1; x++) {
+				const int xC = (mid[0] + x) & 127, yC = (mid[1] + y) & 127, zC = (mid[2] + z) & 127;
+				nb[x + 1][y + 1][z + 1] = data[zC * 128 * 128 + yC * 128 + xC];
+			}
+	for (int c = 0; c < 3; c++) {
+		dw[c][0] = -t[c];
+		dw[c][2] = (1.f - t[c]);
+		dw[c][1] = 2.0f * t[c] - 1.0f;
+		w[c][0] = t[c] * t[c] * 0.5f;
+		w[c][2] = (1.f - t[c]) * (1.f - t[c]) * 0.5f;
+		w[c][1] = 1.f - w[c][0] - w[c][2];
+	}
+	for (int comp = 0; comp < 3; comp++) {
+		float result = 0.0f;
+		for (int z = -1; z <= 1; z++)
+			for (int y = -1; y <= 1; y++)
+				for (int x = -1; x <= 1; x++) {
+					const float a = (comp == 0 ? dw[0] : w[0])[x + 1], b = (comp == 1 ? dw[1] : w[1])[y + 1], c = (comp == 2 ? dw[2] : w[2])[z + 1];
+					const float weight = a * b * c;
+					result += weight * nb[x + 1][y + 1][z + 1];
+				}
+		out[comp] = result;
+	}
+}
+/* WaveletNoiseField::evaluateVec, noisefield.h:338-364 */
+static void noise_evaluate_vec(const float* P, const float* tile, float x, float y, float z, int t, float v[3]) {
+	float pos[3] = {x, y, z};
+	for (int c = 0; c < 3; c++) pos[c] *= P[c];
+	for (int c = 0; c < 3; c++) pos[c] += P[3 + c];
+	for (int c = 0; c < 3; c++) pos[c] += P[6];
+	for (int c = 0; c < 3; c++) pos[c] *= P[7 + c];
+	for (int c = 0; c < 3; c++) pos[c] += P[10 + c];
+	wnoise_vec(pos[0], pos[1], pos[2], tile + (int64_t)t * 128 * 128 * 128, v);
+	for (int c = 0; c < 3; c++) v[c] += P[13];
+	for (int c = 0; c < 3; c++) v[c] *= P[14];
+	if (P[15] != 0.f)
+		for (int c = 0; c < 3; c++) {
+			if (v[c] < P[16]) v[c] = P[16];
+			if (v[c] > P[17]) v[c] = P[17];
+		}
+}
+/* knApplyNoiseVec3, waveletturbulence.cpp:120-154 (uv == NULL) */
+int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* target, const float* tile, const float* P,
+                        float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int interp = weight && (wsx != sx || wsy != sy || wsz != sz);
+	Dim wd = weight ? mkdim(wsx, wsy, wsz) : d;
+	const float sf[3] = {(float)wsx / sx, (float)wsy / sy, (float)wsz / sz};   /* calcGridSizeFactor, grid.h:391-393 */
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				const int64_t idx = IDX(d, i, j, k);
+				if (!(flags[idx] & MF_FLUID)) continue;
+				float w = 1;
+				if (weight) {
+					if (!interp) w = weight[idx];
+					else w = interpol1(&wd, weight, (float)i * sf[0], (float)j * sf[1], (float)k * sf[2]);
+				}
+				float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
+				for (int c = 0; c < 3; c++) pos[c] *= scaleSpatial;
+				float d0[3], d1[3], d2[3];
+				noise_evaluate_vec(P, tile, pos[0], pos[1], pos[2], 0, d0);
+				noise_evaluate_vec(P, tile, pos[0], pos[1], pos[2], 1, d1);
+				noise_evaluate_vec(P, tile, pos[0], pos[1], pos[2], 2, d2);
+				const float cu[3] = {d0[1] - d1[2], d2[2] - d0[0], d1[0] - d2[1]};
+				for (int c = 0; c < 3; c++) target[c * d.n + idx] += cu[c] * scale * w;
+			}
+	return 0;
+}
+
 /* device-scalar variants (here: host pointers) */
 int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out, void* s) {
 	(void)s;

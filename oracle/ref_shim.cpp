@@ -94,6 +94,12 @@ void eulerStep(BasicParticleSystem& parts, const ParticleDataImpl<Vec3>& vel, co
                const int exclude);                                                                        // ptsplugins.cpp:50
 void densityInflow(const FlagGrid& flags, Grid<Real>& density, const WaveletNoiseField& noise, Shape* shape, Real scale,
                    Real sigma);                                                                           // initplugins.cpp:39
+void computeEnergy(const FlagGrid& flags, const MACGrid& vel, Grid<Real>& energy);                           // waveletturbulence.cpp:191
+void computeWaveletCoeffs(Grid<Real>& input);                                                                // :197
+void applyNoiseVec3(const FlagGrid& flags, Grid<Vec3>& target, const WaveletNoiseField& noise, Real scale, Real scaleSpatial,
+                    const Grid<Real>* weight, const Grid<Vec3>* uv);                                         // :156
+void vorticityConfinement(MACGrid& vel, const FlagGrid& flags, Real strength, const Grid<Real>* strengthCell);  // extforces.cpp:419
+void setOpenBound(FlagGrid& flags, int bWidth, std::string openBound, int type);                             // extforces.cpp:106
 void interpolateGrid(Grid<Real>& target, const Grid<Real>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);      // waveletturbulence.cpp:37
 void interpolateGridVec3(Grid<Vec3>& target, const Grid<Vec3>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);  // :51
 void interpolateMACGrid(MACGrid& target, const MACGrid& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);         // :73
@@ -865,6 +871,66 @@ int ref_simpleplume(int res, int steps, int inflow_steps, float* density_out, fl
 		vel_out[n + i] = vel[i].y;
 		vel_out[2 * n + i] = vel[i].z;
 	}
+	SHIM_CATCH
+}
+
+/* computeEnergy / computeWaveletCoeffs / vorticityConfinement / setOpenBound / applyNoiseVec3 */
+int ref_compute_energy(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* energy) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, false);
+	RealRef e(c, energy);
+	computeEnergy(fl, v.g, e.ref());
+	SHIM_CATCH
+}
+int ref_compute_wavelet_coeffs(int sx, int sy, int sz, float* input) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	RealRef e(c, input);
+	computeWaveletCoeffs(e.ref());
+	SHIM_CATCH
+}
+int ref_vorticity_confinement(int sx, int sy, int sz, float* vel, const int32_t* flags, float strength, const float* strengthCell) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, true);
+	RealRef sc(c, strengthCell);
+	vorticityConfinement(v.g, fl, strength, sc.ptr());
+	SHIM_CATCH
+}
+int ref_set_open_bound(int sx, int sy, int sz, int32_t* flags, int bWidth, const char* openBound, int type) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, flags);
+	setOpenBound(fl, bWidth, std::string(openBound), type);
+	SHIM_CATCH
+}
+/* P as in ref_density_inflow; weight grid of size (wsx, wsy, wsz), nullable */
+int ref_apply_noise_vec3(int sx, int sy, int sz, float timeTotal, const int32_t* flags, float* target, int fixedSeed, const float* P,
+                         float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	c.solver.mTimeTotal = timeTotal;
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	Vec3IO t(c, target, true);
+	WaveletNoiseField nf(&c.solver, fixedSeed, 0);
+	nf.mPosScale = Vec3(P[0], P[1], P[2]);
+	nf.mPosOffset = Vec3(P[3], P[4], P[5]);
+	nf.mValOffset = P[6];
+	nf.mValScale = P[7];
+	nf.mClamp = P[8] != 0.f;
+	nf.mClampNeg = P[9];
+	nf.mClampPos = P[10];
+	nf.mTimeAnim = P[11];
+	std::unique_ptr<Ctx> cw;
+	std::unique_ptr<RealRef> w;
+	if (weight) {
+		cw.reset(new Ctx(wsx, wsy, wsz, 1.f));
+		w.reset(new RealRef(*cw, weight));
+	}
+	applyNoiseVec3(fl, t.g, nf, scale, scaleSpatial, w ? w->ptr() : nullptr, nullptr);
 	SHIM_CATCH
 }
 

@@ -683,6 +683,96 @@ def run_simpleplume_ref(res, steps, inflow_steps=100):
     return {"density": rd, "vel": rv}
 
 
+# ---- wavelet turbulence pieces (scenes/waveletTurbulence.py) ----
+def run_turb_pkg(dims, flags, vel, energy_in, weight_small, small_dims, t_total=2.5):
+    from mantaflow_amd import core, plugins, scene
+    s = _mk_solver(dims)
+    s.timeTotal = t_total
+    out = {}
+    fl = soa_to_grid(core.FlagGrid(s), flags)
+    v = soa_to_grid(core.MACGrid(s), vel)
+    e = core.Grid(s)
+    plugins.computeEnergy(flags=fl, vel=v, energy=e)
+    out["energy"] = grid_to_soa(e)
+    w = soa_to_grid(core.Grid(s), energy_in)
+    plugins.computeWaveletCoeffs(w)
+    out["coeffs"] = grid_to_soa(w)
+    v = soa_to_grid(core.MACGrid(s), vel)
+    plugins.vorticityConfinement(vel=v, flags=fl, strength=0.3)
+    out["vortconf"] = grid_to_soa(v)
+    v = soa_to_grid(core.MACGrid(s), vel)
+    plugins.vorticityConfinement(vel=v, flags=fl, strength=0.1, strengthCell=soa_to_grid(core.Grid(s), energy_in))
+    out["vortconf_cell"] = grid_to_soa(v)
+    for nm, bw, ob in (("open_Y", 0, "Y"), ("open_xYz", 1, "xYz")):
+        f2 = soa_to_grid(core.FlagGrid(s), np.where(flags & util.OBS, flags, 1).astype(np.int32))
+        f2.initDomain(boundaryWidth=bw)
+        f2.fillGrid()
+        plugins.setOpenBound(f2, bw, ob, 16 | 4)
+        out[nm] = grid_to_soa(f2)
+    noise = scene.NoiseField(parent=s, loadFromFile=True)
+    noise.posScale = core.vec3(int(1.0 * dims[0])) * 0.5
+    noise.timeAnim = 0.1
+    t = soa_to_grid(core.VecGrid(s), vel)
+    plugins.applyNoiseVec3(flags=fl, target=t, noise=noise, scale=0.4, weight=w)
+    out["noise_same"] = grid_to_soa(t)
+    ss = _mk_solver(small_dims)
+    t = soa_to_grid(core.MACGrid(s), vel)
+    plugins.applyNoiseVec3(flags=fl, target=t, noise=noise, scale=0.24, scaleSpatial=1.5, weight=soa_to_grid(core.Grid(ss), weight_small))
+    out["noise_interp"] = grid_to_soa(t)
+    t = soa_to_grid(core.VecGrid(s), vel)
+    plugins.applyNoiseVec3(flags=fl, target=t, noise=noise)
+    out["noise_plain"] = grid_to_soa(t)
+    s.sync()
+    return out
+
+
+def run_turb_ref(dims, flags, vel, energy_in, weight_small, small_dims, t_total=2.5):
+    sx, sy, sz = dims
+    cf = ctypes.c_float
+    out = {}
+    e = np.zeros((sz, sy, sx), np.float32)
+    refcall("ref_compute_energy", sx, sy, sz, flags, vel, e)
+    out["energy"] = e
+    w = energy_in.copy()
+    refcall("ref_compute_wavelet_coeffs", sx, sy, sz, w)
+    out["coeffs"] = w
+    v = vel.copy()
+    refcall("ref_vorticity_confinement", sx, sy, sz, v, flags, cf(0.3), None)
+    out["vortconf"] = v
+    v = vel.copy()
+    refcall("ref_vorticity_confinement", sx, sy, sz, v, flags, cf(0.1), energy_in)
+    out["vortconf_cell"] = v
+    pad = lambda x: (x + "      ").encode()
+    for nm, bw, ob in (("open_Y", 0, "Y"), ("open_xYz", 1, "xYz")):
+        f2 = np.zeros((sz, sy, sx), np.int32)
+        refcall("ref_init_domain", sx, sy, sz, f2, bw, b"xXyYzZ", pad(""), pad(""), pad(""), 1)
+        refcall("ref_set_open_bound", sx, sy, sz, f2, bw, ob.encode(), 16 | 4)
+        out[nm] = f2
+    ps = np.float32(int(1.0 * dims[0])) * np.float32(0.5)
+    P = np.array([ps, ps, ps, 0, 0, 0, 0.0, 1.0, 0, 0, 1, 0.1], np.float32)
+    t = vel.copy()
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.4), cf(1.0), w, sx, sy, sz)
+    out["noise_same"] = t
+    t = vel.copy()
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.24), cf(1.5), weight_small, small_dims[0], small_dims[1], small_dims[2])
+    out["noise_interp"] = t
+    t = vel.copy()
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(1.0), cf(1.0), None, 0, 0, 0)
+    out["noise_plain"] = t
+    return out
+
+
+def turb_inputs(dims, small_dims, seed):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=True)
+    vel = util.smooth_vel(sx, sy, sz, seed + 1, 1.5)
+    if sz == 1:
+        vel[2] = 0
+    energy_in = np.abs(util.rand_real((sz, sy, sx), seed + 2)).astype(np.float32)
+    weight_small = np.abs(util.rand_real((small_dims[2], small_dims[1], small_dims[0]), seed + 3)).astype(np.float32)
+    return flags, vel, energy_in, weight_small
+
+
 def run_glue_pkg(dims, dt, flags, vel, density, obvel=None):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims, dt)
@@ -768,6 +858,9 @@ def golden_outputs(impl, deterministic_p2g=True):
         out["surf_" + k] = v
     r = run_simpleplume_pkg(16, 5)
     out["plume_density"], out["plume_vel"] = r["density"], r["vel"]
+    td, ts = (20, 14, 12), (10, 7, 6)
+    for k, v in run_turb_pkg(td, *turb_inputs(td, ts, 91), ts).items():
+        out["turb_" + k] = v
     return out
 
 

@@ -65,6 +65,10 @@ def main():
     # BASELINE config 0: scenes/simpleplume.py, 5 steps at res 16, through the reference's own classes (ref_simpleplume)
     r = cases.run_simpleplume_ref(16, 5)
     out["plume_density"], out["plume_vel"] = r["density"], r["vel"]
+    # wavelet-turbulence pieces (scenes/waveletTurbulence.py)
+    td, ts = (20, 14, 12), (10, 7, 6)
+    for k, v in cases.run_turb_ref(td, *cases.turb_inputs(td, ts, 91), ts).items():
+        out["turb_" + k] = v
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote %d arrays, %.1f KiB" % (len(out), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")) / 1024))
 

@@ -286,6 +286,21 @@ def test_surface_pieces(hip_backend, dims):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims,small", [((20, 14, 12), (10, 7, 6)), ((24, 30, 1), (12, 15, 1)), ((17, 11, 9), (9, 6, 5)), ((64, 48, 40), (32, 24, 20))])
+def test_wavelet_turbulence_pieces(hip_backend, dims, small):
+    """computeEnergy / computeWaveletCoeffs / vorticityConfinement / applyNoiseVec3 (scenes/waveletTurbulence.py): HIP bit-identical
+    to the oracle, itself pinned to the compiled reference by test_oracle_vs_reference.py::test_wavelet_turbulence_pieces"""
+    from mantaflow_amd import _lib
+    inp = cases.turb_inputs(dims, small, 91)
+    a = cases.run_turb_pkg(dims, *inp, small)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_turb_pkg(dims, *inp, small)
+    _lib.reset()
+    assert np.abs(b["noise_plain"] - inp[1]).max() > 1e-3
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 def test_dam_break_steps_match_oracle(hip_backend):
     """three steps of a ghost-fluid FLIP dam break (benchmark_dam.py's loop) on the GPU = the same steps on the oracle:
     flags and particle types bit-exact, CG iteration counts identical, fields within 1e-5 (deterministic P2G)"""

@@ -302,6 +302,17 @@ def test_noise_tile_and_density_inflow(oracle_backend, oracle):
         assert_bitexact(ours, ref, "densityInflow t=%g sigma=%g" % (t_total, sigma))
 
 
+@pytest.mark.parametrize("dims,small", [((20, 14, 12), (10, 7, 6)), ((24, 30, 1), (12, 15, 1)), ((17, 11, 9), (9, 6, 5))])
+def test_wavelet_turbulence_pieces(oracle_backend, dims, small):
+    """computeEnergy, computeWaveletCoeffs, vorticityConfinement, setOpenBound, applyNoiseVec3 (scenes/waveletTurbulence.py)"""
+    inp = cases.turb_inputs(dims, small, 91)
+    a = cases.run_turb_pkg(dims, *inp, small)
+    b = cases.run_turb_ref(dims, *inp, small)
+    assert np.abs(b["noise_plain"] - inp[1]).max() > 1e-3 and (b["open_Y"] != 2).sum() > 0
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 def test_init_domain_matches_reference(oracle_backend):
     from mantaflow_amd import core
     for dims, bw, kw in [((10, 9, 8), 0, {}), ((12, 10, 9), 1, dict(open="xY", outflow="z")), ((16, 12, 1), 0, dict(inflow="y"))]:
