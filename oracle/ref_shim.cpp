@@ -874,6 +874,110 @@ int ref_simpleplume(int res, int steps, int inflow_steps, float* density_out, fl
 	SHIM_CATCH
 }
 
+/* scenes/waveletTurbulence.py driven through the reference's own classes and plugins (the loop is this shim's code: same calls, same
+ * arguments, same order as the scene's main loop).  Shape::applyToGrid needs the Python argument store (NOPYTHON build: errMsg), so
+ * the MAC branch is applied here with the shape's own isInside at the three face positions (shapes.cpp:61-68).
+ * Outputs: coarse density/velocity and the up-sampled (xl) density/velocity, SoA. */
+static void shim_apply_to_mac(MACGrid& g, Shape& sh, Vec3 value) {
+	FOR_IJK(g) {
+		if (sh.isInside(Vec3(i, j + 0.5, k + 0.5))) g(i, j, k).x = value.x;
+		if (sh.isInside(Vec3(i + 0.5, j, k + 0.5))) g(i, j, k).y = value.y;
+		if (sh.isInside(Vec3(i + 0.5, j + 0.5, k))) g(i, j, k).z = value.z;
+	}
+}
+static void shim_wlt_noise(WaveletNoiseField& n, WaveletNoiseField* like, Real timeAnim) {
+	n.mPosScale = like ? like->mPosScale : Vec3(20);
+	n.mClamp = true;
+	n.mClampNeg = 0;
+	n.mClampPos = 2;
+	n.mValScale = 1;
+	n.mValOffset = 0.075;
+	n.mTimeAnim = timeAnim;
+}
+int ref_waveletturbulence(int res, int dim, int steps, int upres, float* density_out, float* vel_out, float* xl_density_out,
+                          float* xl_vel_out) {
+	SHIM_TRY
+	const double wltStrength = 0.4; // a Python float in the scene
+	Vec3i gsi(res, int(1.5 * res), res);
+	if (dim == 2) gsi.z = 1;
+	const Vec3 gs(gsi.x, gsi.y, gsi.z);
+	FluidSolver sm(gsi, dim);
+	sm.mDt = 1.5;
+	const Vec3 velInflow(0.025, 0, 0);
+	WaveletNoiseField noise(&sm, 265, 0);
+	shim_wlt_noise(noise, nullptr, 0.3);
+	Cylinder source(&sm, gs * Vec3(0.3, 0.2, 0.5), res * 0.081, gs * Vec3(0.081, 0, 0));
+	Cylinder sourceVel(&sm, gs * Vec3(0.3, 0.2, 0.5), res * 0.15, gs * Vec3(0.15, 0, 0));
+	Vec3i xlgsi(upres * gsi.x, upres * gsi.y, upres * gsi.z);
+	if (dim == 2) xlgsi.z = 1;
+	const Vec3 xl_gs(xlgsi.x, xlgsi.y, xlgsi.z);
+	FluidSolver xl(xlgsi, dim);
+	xl.mDt = sm.mDt;
+	FlagGrid xl_flags(&xl);
+	MACGrid xl_vel(&xl);
+	Grid<Real> xl_density(&xl), xl_weight(&xl);
+	xl_flags.initDomain(0, "xXyYzZ", "      ", "      ", "      ", nullptr);
+	xl_flags.fillGrid();
+	Cylinder xl_source(&xl, xl_gs * Vec3(0.3, 0.2, 0.5), xl_gs.x * 0.081, xl_gs * Vec3(0.081, 0, 0));
+	WaveletNoiseField xl_noise(&xl, 265, 0);
+	shim_wlt_noise(xl_noise, &noise, 0.3 * upres);
+	WaveletNoiseField wlt1(&xl, -1, 0), wlt2(&xl, -1, 0), wlt3(&xl, -1, 0);
+	wlt1.mPosScale = Vec3(int(1.0 * gs.x)) * 0.5;
+	wlt1.mTimeAnim = 0.1;
+	wlt2.mPosScale = wlt1.mPosScale * 2.0;
+	wlt2.mTimeAnim = 0.1;
+	wlt3.mPosScale = wlt2.mPosScale * 2.0;
+	wlt3.mTimeAnim = 0.1;
+	FlagGrid flags(&sm);
+	MACGrid vel(&sm);
+	Grid<Real> density(&sm), pressure(&sm), energy(&sm);
+	const int bWidth = 0;
+	flags.initDomain(bWidth, "xXyYzZ", "      ", "      ", "      ", nullptr);
+	flags.fillGrid();
+	setOpenBound(flags, bWidth, "Y", FlagGrid::TypeOutflow | FlagGrid::TypeEmpty);
+	for (int t = 0; t < steps; t++) {
+		advectSemiLagrange(&flags, &vel, &density, 2, 1.0, 1, false, -1, 2, 1);
+		advectSemiLagrange(&flags, &vel, &vel, 2, 1.0, 1, false, -1, 2, 1);
+		bool applyInflow = false;
+		if (sm.getTime() >= 0 && sm.getTime() < 50.) {
+			densityInflow(flags, density, noise, &source, 1, 0.5);
+			shim_apply_to_mac(vel, sourceVel, velInflow * float(res));
+			applyInflow = true;
+		}
+		setWallBcs(flags, vel, nullptr, nullptr, nullptr, 0);
+		addBuoyancy(flags, density, vel, Vec3(0, -1e-3, 0), 1.0, true);
+		vorticityConfinement(vel, flags, 0.3, nullptr);
+		solvePressure(vel, pressure, flags, 0.01, nullptr, nullptr, nullptr, nullptr, 0.01, 1.0, true, 1, false, false, false, nullptr,
+		              0., nullptr);
+		setWallBcs(flags, vel, nullptr, nullptr, nullptr, 0);
+		computeEnergy(flags, vel, energy);
+		computeWaveletCoeffs(energy);
+		sm.step();
+		interpolateGrid(xl_weight, energy, Vec3(1.), Vec3(0.), Vec3i(-1, -1, -1), 1);
+		interpolateMACGrid(xl_vel, vel, Vec3(1.), Vec3(0.), Vec3i(-1, -1, -1), 1);
+		applyNoiseVec3(xl_flags, xl_vel, wlt1, wltStrength * 1.0, 1.0, &xl_weight, nullptr);
+		applyNoiseVec3(xl_flags, xl_vel, wlt2, wltStrength * 0.6, 1.0, &xl_weight, nullptr);
+		applyNoiseVec3(xl_flags, xl_vel, wlt3, wltStrength * 0.6 * 0.6, 1.0, &xl_weight, nullptr);
+		for (int sub = 0; sub < upres; sub++) advectSemiLagrange(&xl_flags, &xl_vel, &xl_density, 2, 1.0, 1, false, -1, 2, 1);
+		if (applyInflow) densityInflow(xl_flags, xl_density, xl_noise, &xl_source, 1, 0.5);
+		xl.step();
+	}
+	const int64_t n = (int64_t)gsi.x * gsi.y * gsi.z, nx = (int64_t)xlgsi.x * xlgsi.y * xlgsi.z;
+	for (int64_t i = 0; i < n; i++) {
+		density_out[i] = density[i];
+		vel_out[i] = vel[i].x;
+		vel_out[n + i] = vel[i].y;
+		vel_out[2 * n + i] = vel[i].z;
+	}
+	for (int64_t i = 0; i < nx; i++) {
+		xl_density_out[i] = xl_density[i];
+		xl_vel_out[i] = xl_vel[i].x;
+		xl_vel_out[nx + i] = xl_vel[i].y;
+		xl_vel_out[2 * nx + i] = xl_vel[i].z;
+	}
+	SHIM_CATCH
+}
+
 /* computeEnergy / computeWaveletCoeffs / vorticityConfinement / setOpenBound / applyNoiseVec3 */
 int ref_compute_energy(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* energy) {
 	SHIM_TRY

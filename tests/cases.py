@@ -683,6 +683,87 @@ def run_simpleplume_ref(res, steps, inflow_steps=100):
     return {"density": rd, "vel": rv}
 
 
+def run_wavelet_scene_pkg(res, dim, steps, upres=2):
+    """the main loop of scenes/waveletTurbulence.py through the package (same calls, arguments and order)"""
+    from mantaflow_amd import api as m
+    wltStrength = 0.4
+    gs = m.vec3(res, int(1.5 * res), res)
+    if dim == 2:
+        gs.z = 1
+    sm = m.Solver(name="main", gridSize=gs, dim=dim)
+    sm.timestep = 1.5
+    velInflow = m.vec3(0.025, 0, 0)
+    noise = m.NoiseField(parent=sm, fixedSeed=265, loadFromFile=True)
+    noise.posScale = m.vec3(20)
+    noise.clamp, noise.clampNeg, noise.clampPos = True, 0, 2
+    noise.valScale, noise.valOffset, noise.timeAnim = 1, 0.075, 0.3
+    source = m.Cylinder(parent=sm, center=gs * m.vec3(0.3, 0.2, 0.5), radius=res * 0.081, z=gs * m.vec3(0.081, 0, 0))
+    sourceVel = m.Cylinder(parent=sm, center=gs * m.vec3(0.3, 0.2, 0.5), radius=res * 0.15, z=gs * m.vec3(0.15, 0, 0))
+    xl_gs = m.vec3(upres * gs.x, upres * gs.y, upres * gs.z)
+    if dim == 2:
+        xl_gs.z = 1
+    xl = m.Solver(name="larger", gridSize=xl_gs, dim=dim)
+    xl.timestep = sm.timestep
+    xl_flags, xl_vel, xl_density, xl_weight = xl.create(m.FlagGrid), xl.create(m.MACGrid), xl.create(m.RealGrid), xl.create(m.RealGrid)
+    xl_flags.initDomain()
+    xl_flags.fillGrid()
+    xl_source = m.Cylinder(parent=xl, center=xl_gs * m.vec3(0.3, 0.2, 0.5), radius=xl_gs.x * 0.081, z=xl_gs * m.vec3(0.081, 0, 0))
+    xl_noise = m.NoiseField(parent=xl, fixedSeed=265, loadFromFile=True)
+    xl_noise.posScale, xl_noise.clamp, xl_noise.clampNeg, xl_noise.clampPos = noise.posScale, noise.clamp, noise.clampNeg, noise.clampPos
+    xl_noise.valScale, xl_noise.valOffset, xl_noise.timeAnim = noise.valScale, noise.valOffset, noise.timeAnim * upres
+    wlt = []
+    for lvl in range(3):
+        n = m.NoiseField(parent=xl, loadFromFile=True)
+        n.posScale = m.vec3(int(1.0 * gs.x)) * 0.5 if lvl == 0 else wlt[-1].posScale * 2.0
+        n.timeAnim = 0.1
+        wlt.append(n)
+    flags, vel, density, pressure, energy = (sm.create(t) for t in (m.FlagGrid, m.MACGrid, m.RealGrid, m.RealGrid, m.RealGrid))
+    flags.initDomain(boundaryWidth=0)
+    flags.fillGrid()
+    m.setOpenBound(flags, 0, "Y", m.FlagOutflow | m.FlagEmpty)
+    for t in range(steps):
+        m.advectSemiLagrange(flags=flags, vel=vel, grid=density, order=2)
+        m.advectSemiLagrange(flags=flags, vel=vel, grid=vel, order=2)
+        applyInflow = False
+        if sm.timeTotal >= 0 and sm.timeTotal < 50.:
+            m.densityInflow(flags=flags, density=density, noise=noise, shape=source, scale=1, sigma=0.5)
+            sourceVel.applyToGrid(grid=vel, value=(velInflow * float(res)))
+            applyInflow = True
+        m.setWallBcs(flags=flags, vel=vel)
+        m.addBuoyancy(density=density, vel=vel, gravity=m.vec3(0, -1e-3, 0), flags=flags)
+        m.vorticityConfinement(vel=vel, flags=flags, strength=0.3)
+        m.solvePressure(flags=flags, vel=vel, pressure=pressure, cgMaxIterFac=1.0, cgAccuracy=0.01)
+        m.setWallBcs(flags=flags, vel=vel)
+        m.computeEnergy(flags=flags, vel=vel, energy=energy)
+        m.computeWaveletCoeffs(energy)
+        sm.step()
+        m.interpolateGrid(target=xl_weight, source=energy)
+        m.interpolateMACGrid(source=vel, target=xl_vel)
+        m.applyNoiseVec3(flags=xl_flags, target=xl_vel, noise=wlt[0], scale=wltStrength * 1.0, weight=xl_weight)
+        m.applyNoiseVec3(flags=xl_flags, target=xl_vel, noise=wlt[1], scale=wltStrength * 0.6, weight=xl_weight)
+        m.applyNoiseVec3(flags=xl_flags, target=xl_vel, noise=wlt[2], scale=wltStrength * 0.6 * 0.6, weight=xl_weight)
+        for substep in range(upres):
+            m.advectSemiLagrange(flags=xl_flags, vel=xl_vel, grid=xl_density, order=2)
+        if applyInflow:
+            m.densityInflow(flags=xl_flags, density=xl_density, noise=xl_noise, shape=xl_source, scale=1, sigma=0.5)
+        xl.step()
+    sm.sync()
+    xl.sync()
+    return {"density": grid_to_soa(density), "vel": grid_to_soa(vel), "xl_density": grid_to_soa(xl_density), "xl_vel": grid_to_soa(xl_vel)}
+
+
+def run_wavelet_scene_ref(res, dim, steps, upres=2):
+    """scenes/waveletTurbulence.py through the compiled reference (oracle/ref_shim.cpp:ref_waveletturbulence)"""
+    gs = (res, int(1.5 * res), res if dim == 3 else 1)
+    xg = (upres * gs[0], upres * gs[1], upres * gs[2] if dim == 3 else 1)
+    d = np.zeros(gs[::-1], np.float32)
+    v = np.zeros((3,) + gs[::-1], np.float32)
+    xd = np.zeros(xg[::-1], np.float32)
+    xv = np.zeros((3,) + xg[::-1], np.float32)
+    refcall("ref_waveletturbulence", res, dim, steps, upres, d, v, xd, xv)
+    return {"density": d, "vel": v, "xl_density": xd, "xl_vel": xv}
+
+
 # ---- wavelet turbulence pieces (scenes/waveletTurbulence.py) ----
 def run_turb_pkg(dims, flags, vel, energy_in, weight_small, small_dims, t_total=2.5):
     from mantaflow_amd import core, plugins, scene
@@ -861,6 +942,9 @@ def golden_outputs(impl, deterministic_p2g=True):
     td, ts = (20, 14, 12), (10, 7, 6)
     for k, v in run_turb_pkg(td, *turb_inputs(td, ts, 91), ts).items():
         out["turb_" + k] = v
+    for tag, dim, res, steps in (("wlt2d_", 2, 32, 6), ("wlt3d_", 3, 16, 4)):
+        for k, v in run_wavelet_scene_pkg(res, dim, steps).items():
+            out[tag + k] = v
     return out
 
 

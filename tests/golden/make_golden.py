@@ -69,6 +69,10 @@ def main():
     td, ts = (20, 14, 12), (10, 7, 6)
     for k, v in cases.run_turb_ref(td, *cases.turb_inputs(td, ts, 91), ts).items():
         out["turb_" + k] = v
+    # scenes/waveletTurbulence.py end to end (2D res 32 x 6 steps, 3D res 16 x 4 steps) through the reference's own classes
+    for tag, dim, res, steps in (("wlt2d_", 2, 32, 6), ("wlt3d_", 3, 16, 4)):
+        for k, v in cases.run_wavelet_scene_ref(res, dim, steps).items():
+            out[tag + k] = v
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote %d arrays, %.1f KiB" % (len(out), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")) / 1024))
 

@@ -44,7 +44,7 @@ def test_golden_vectors(hip, hip_backend):
             assert got[k][0] == gold[k][0], "%s: iteration count %s vs %s" % (k, got[k][0], gold[k][0])
             _close(got[k][1:], gold[k][1:], k, 1e-4)
             continue
-        reduction_dependent = (k.startswith(("cg_", "sp_")) and not k.endswith("_rhs")) or k.startswith("plume_")
+        reduction_dependent = (k.startswith(("cg_", "sp_")) and not k.endswith("_rhs")) or k.startswith(("plume_", "wlt2d_", "wlt3d_"))
         if reduction_dependent:
             _close(got[k], gold[k], k)
             (exact if np.array_equal(got[k], gold[k]) else close).append(k)

@@ -89,3 +89,20 @@ def test_simpleplume_end_to_end_equals_reference(oracle_backend):
     assert rd.max() > 0.5 and np.abs(rv).max() > 1e-3
     util.assert_bitexact(d, rd, "simpleplume density after %d steps" % steps)
     util.assert_bitexact(np.ascontiguousarray(v.transpose(3, 0, 1, 2)), rv, "simpleplume velocity after %d steps" % steps)
+
+
+@pytest.mark.parametrize("dim,res,steps", [(2, 32, 6), (3, 16, 4)])
+def test_wavelet_turbulence_end_to_end_equals_reference(oracle_backend, dim, res, steps):
+    """scenes/waveletTurbulence.py (two solvers: coarse smoke solve + up-sampled grid with wavelet noise) unchanged through
+    `from manta import *` = the same scene driven through the compiled reference's own classes, bit for bit: coarse density and
+    velocity, up-sampled density and velocity.  Covers 2D (CG without MIC), open 'Y' boundary with outflow cells,
+    vorticityConfinement, computeEnergy/WaveletCoeffs, interpolate*Grid, applyNoiseVec3, Cylinder.applyToGrid on a MAC grid."""
+    import cases
+    import numpy as np
+    g = run_scene("waveletTurbulence.py", steps, [("res = 80", "res = %d" % res), ("dim = 2", "dim = %d" % dim)])
+    r = cases.run_wavelet_scene_ref(res, dim, steps)
+    assert r["xl_density"].sum() > 1 and np.abs(r["xl_vel"]).max() > 0.1
+    got = {"density": g["density"].to_numpy(), "vel": np.ascontiguousarray(g["vel"].to_numpy().transpose(3, 0, 1, 2)),
+           "xl_density": g["xl_density"].to_numpy(), "xl_vel": np.ascontiguousarray(g["xl_vel"].to_numpy().transpose(3, 0, 1, 2))}
+    for k in r:
+        util.assert_bitexact(got[k], r[k], "waveletTurbulence %s after %d steps" % (k, steps))

@@ -69,6 +69,7 @@ REF_PROTOS = {
     "ref_vorticity_confinement": [c_i, c_i, c_i, c_p, c_p, c_f, c_p],
     "ref_set_open_bound": [c_i, c_i, c_i, c_p, c_i, ctypes.c_char_p, c_i],
     "ref_apply_noise_vec3": [c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_i, c_i, c_i],
+    "ref_waveletturbulence": [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "ref_simpleplume": [c_i, c_i, c_i, c_p, c_p],
     "ref_shape_levelset": [c_i, c_i, c_i, c_i, c_p, c_p],
     "ref_noise_tile": [c_p],

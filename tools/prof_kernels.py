@@ -115,6 +115,20 @@ def main():
         print("dam break res %d: grid %s (%d cells), %d particles, %d steps: %.2f ms/step incl. set-up amortised, CG iterations %s"
               % (res, gs, ncell, out["pos"].shape[1], reps, el * 1e3 / reps, out["iters"]))
         plugins.Timings().display()
+    elif what == "wavelet":
+        # scenes/waveletTurbulence.py's loop (tests/cases.py:run_wavelet_scene_pkg), 3D, MF_RES = coarse resolution (scene default 80)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        import cases
+        res = int(os.environ.get("MF_RES", "80"))
+        cases.run_wavelet_scene_pkg(res, 3, 2)
+        plugins._timings.clear()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = cases.run_wavelet_scene_pkg(res, 3, reps)
+        torch.cuda.synchronize()
+        el = time.time() - t0
+        print("waveletTurbulence 3D res %d (xl grid %s), %d steps: %.2f ms/step incl. set-up amortised" % (res, out["xl_density"].shape[::-1], reps, el * 1e3 / reps))
+        plugins.Timings().display()
     elif what == "advect":
         vel, dens = core.MACGrid(s), core.Grid(s)
         vel.from_numpy(np.ascontiguousarray(bench.synthetic_velocity(n, n, n).transpose(1, 2, 3, 0)))
