@@ -205,6 +205,19 @@ int mf_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, in
 int mf_flip_velocity_update(int sx, int sy, int sz, const float* vel, const float* velOld, int64_t np,
                             int64_t pstride, const float* pos, const int32_t* pflag, float* pvel,
                             float flipRatio, const int32_t* ptype, int exclude, void* stream);
+/* APIC transfers, plugin/apic.cpp.  cpx/cpy/cpz: the affine rows, Vec3 pdata in SoA [3][pstride].
+ * apicMapPartsToMAC :92-110 -> knApicMapLinearVec3ToMACGrid :19-90 (KERNEL(pts, single)): clears vel+mass, per particle
+ * and face node  mass += w ; vel += w*v_c ; vel += w*dot(cp_c, node - pos), then mass.stomp(1e-6), vel.safeDivide(mass).
+ * Summed in particle-index order per node (bit-identical to the reference's serial scatter).  mass is required here
+ * (the Python layer passes a temporary MAC grid when the scene gives none). */
+int mf_apic_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* mass, int64_t np, int64_t pstride,
+                             const float* pos, const int32_t* pflag, const float* pvel, const float* cpx,
+                             const float* cpy, const float* cpz, const int32_t* ptype, int exclude, void* stream);
+/* apicMapMACGridToParts :175-181 -> knApicMapLinearMACGridToVec3 :112-173: pvel = trilinear face sample, cp_c = its
+ * gradient weights (gw = {-1, 1} on one axis) */
+int mf_apic_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t pstride, const float* pos,
+                             const int32_t* pflag, float* pvel, float* cpx, float* cpy, float* cpz,
+                             const int32_t* ptype, int exclude, void* stream);
 /* mapPartsToGrid / mapPartsToGridVec3, flip.cpp:663-687 (+ setInterpol interpol.h:96-113, knSafeDivReal
  * :607-615).  ncomp 1|3; target SoA; wtmp = zeroed Real scratch grid. */
 int mf_map_parts_to_grid(int sx, int sy, int sz, int ncomp, float* target, float* wtmp, int64_t np,

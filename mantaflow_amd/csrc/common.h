@@ -79,6 +79,10 @@ int p2g_ordered_mac(const Dim& d, float* vel, float* weight, int64_t np, int64_t
 int p2g_ordered_cell(const Dim& d, int ncomp, float* target, float* wsum, int64_t np, int64_t ps, const float* pos,
                      const int32_t* pflag, const float* psrc, hipStream_t st);
 
+int p2g_ordered_apic(const Dim& d, float* vel, float* mass, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
+                     const float* pvel, const float* cpx, const float* cpy, const float* cpz, const int32_t* ptype, int exclude,
+                     hipStream_t st);
+
 constexpr int BLOCK = 256;
 static inline int blocks_for(int64_t n, int per_block, int cap = MAX_BLOCKS) {
 	int64_t b = (n + per_block - 1) / per_block;
@@ -273,4 +277,41 @@ __device__ __forceinline__ void get_at_mac_z(const Dim& d, const float* __restri
 	vz = vel[2 * d.n + idx];
 }
 
+
+// ---- APIC (plugin/apic.cpp:29-33, 119-123): face index f = (IndexInt)pos, centre index c = (IndexInt)(pos - 0.5) with the
+// subtraction in double (double literal) and truncation toward zero; wf = clamp(pos - f, 0, 1) in fp32,
+// wc = clamp(Real(pos - c - 0.5), 0, 1) with the "- 0.5" in double.  apic_face: face COMP (0 u, 1 v, 2 w) -> flat base
+// index, position of the base node, per-axis weight pairs {1 - w, w}.
+struct ApicFace {
+	int64_t gidx;
+	float gpos[3];
+	float W[3][2];
+};
+__device__ __forceinline__ float apic_clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+template <int COMP>
+__device__ __forceinline__ ApicFace apic_face(const Dim& d, float px, float py, float pz) {
+	const float P[3] = {px, py, pz};
+	ApicFace a;
+	int64_t b[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		if (q == COMP) {
+			const int64_t f = (int64_t)P[q];
+			b[q] = f;
+			a.gpos[q] = (float)f;
+			const float w = apic_clamp01(P[q] - (float)f);
+			a.W[q][0] = 1.f - w;
+			a.W[q][1] = w;
+		} else {
+			const int64_t c = (int64_t)((double)P[q] - 0.5);
+			b[q] = c;
+			a.gpos[q] = (float)((double)c + 0.5);
+			const float w = apic_clamp01((float)((double)(P[q] - (float)c) - 0.5));
+			a.W[q][0] = 1.f - w;
+			a.W[q][1] = w;
+		}
+	}
+	a.gidx = b[0] + b[1] * d.Y + b[2] * d.Z;
+	return a;
+}
 }  // namespace mf

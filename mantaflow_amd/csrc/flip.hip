@@ -204,7 +204,7 @@ __global__ void k_p2g_mac_sequential(Dim d, float* vel, float* weight, int64_t n
 }
 // weight.stomp(1e-6) ; vel.safeDivide(weight) ; velOld.copyFrom(vel)  (flip.cpp:653-659) fused: 3n scalars
 __global__ void __launch_bounds__(BLOCK)
-k_p2g_mac_finish(int64_t n3, float* __restrict__ vel, float* __restrict__ velOld, float* __restrict__ weight) {
+k_p2g_mac_finish(int64_t n3, float* __restrict__ vel, float* __restrict__ velOld, float* __restrict__ weight) {   // velOld nullable (APIC)
 	for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n3; i += (int64_t)gridDim.x * BLOCK) {
 		float w = weight[i];
 		if (w < 1e-6f) w = 0.f;
@@ -212,8 +212,47 @@ k_p2g_mac_finish(int64_t n3, float* __restrict__ vel, float* __restrict__ velOld
 		float v = vel[i];
 		v = (w != 0.f) ? (v / w) : v;
 		vel[i] = v;
-		velOld[i] = v;
+		if (velOld) velOld[i] = v;
 	}
+}
+
+// knApicMapLinearMACGridToVec3, apic.cpp:112-173: per particle and face the trilinear sample and its gradient weights
+template <int COMP>
+__device__ __forceinline__ void apic_g2p_face(const Dim& d, const float* __restrict__ vg, float px, float py, float pz, float out[4]) {
+	const ApicFace a = apic_face<COMP>(d, px, py, pz);
+	float v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+	for (int i = 0; i < 2; i++)
+#pragma unroll
+		for (int j = 0; j < 2; j++)
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const int64_t node = a.gidx + i + j * d.Y + k * d.Z;
+				const float val = (node >= 0 && node < d.n) ? vg[node] : 0.f;
+				const float gi = i ? 1.f : -1.f, gj = j ? 1.f : -1.f, gk = k ? 1.f : -1.f;
+				v += a.W[0][i] * a.W[1][j] * a.W[2][k] * val;
+				g0 += gi * a.W[1][j] * a.W[2][k] * val;
+				g1 += a.W[0][i] * gj * a.W[2][k] * val;
+				g2 += a.W[0][i] * a.W[1][j] * gk * val;
+			}
+	out[0] = v; out[1] = g0; out[2] = g1; out[3] = g2;
+}
+__global__ void __launch_bounds__(BLOCK)
+k_g2p_apic(Dim d, const float* __restrict__ vel, int64_t np, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ pflag,
+           float* __restrict__ pvel, float* __restrict__ cpx, float* __restrict__ cpy, float* __restrict__ cpz,
+           const int32_t* __restrict__ ptype, int exclude) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) return;
+	const float px = pos[p], py = pos[ps + p], pz = pos[2 * ps + p];
+	float u[4], v[4], w[4] = {0.f, 0.f, 0.f, 0.f};
+	apic_g2p_face<0>(d, vel, px, py, pz, u);
+	apic_g2p_face<1>(d, vel + d.n, px, py, pz, v);
+	if (d.is3d) apic_g2p_face<2>(d, vel + 2 * d.n, px, py, pz, w);
+	pvel[p] = u[0]; pvel[ps + p] = v[0]; pvel[2 * ps + p] = w[0];
+	cpx[p] = u[1]; cpx[ps + p] = u[2]; cpx[2 * ps + p] = u[3];
+	cpy[p] = v[1]; cpy[ps + p] = v[2]; cpy[2 * ps + p] = v[3];
+	cpz[p] = w[1]; cpz[ps + p] = w[2]; cpz[2 * ps + p] = w[3];
 }
 
 // setInterpol, interpol.h:96-113 (cell-centred target, NCOMP planes, weights into a separate Real grid)
@@ -470,6 +509,30 @@ int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float
 			hipLaunchKernelGGL(k_p2g_mac_atomic, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude);
 	}
 	hipLaunchKernelGGL(k_p2g_mac_finish, dim3(blocks_for(3 * d.n, BLOCK, 2048)), dim3(BLOCK), 0, st, 3 * d.n, vel, velOld, weight);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_apic_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* mass, int64_t np, int64_t ps, const float* pos,
+                             const int32_t* pflag, const float* pvel, const float* cpx, const float* cpy, const float* cpz,
+                             const int32_t* ptype, int exclude, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (!mass) return fail("mf_apic_map_parts_to_mac: mass grid required");
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	MF_HIP(hipMemsetAsync(mass, 0, sizeof(float) * 3 * d.n, st));
+	MF_HIP(hipMemsetAsync(vel, 0, sizeof(float) * 3 * d.n, st));
+	if (np > 0) MF_TRY(p2g_ordered_apic(d, vel, mass, np, ps, pos, pflag, pvel, cpx, cpy, cpz, ptype, exclude, st));
+	hipLaunchKernelGGL(k_p2g_mac_finish, dim3(blocks_for(3 * d.n, BLOCK, 2048)), dim3(BLOCK), 0, st, 3 * d.n, vel, (float*)nullptr, mass);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_apic_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t ps, const float* pos,
+                             const int32_t* pflag, float* pvel, float* cpx, float* cpy, float* cpz, const int32_t* ptype,
+                             int exclude, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (np <= 0) return 0;
+	const Dim d = mkdim(sx, sy, sz);
+	hipLaunchKernelGGL(k_g2p_apic, dim3(nblk_n(np)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, np, ps, pos, pflag, pvel, cpx, cpy, cpz, ptype, exclude);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

@@ -132,6 +132,85 @@ k_gather(Dim d, int64_t ps, const float* __restrict__ pos, const float* __restri
 	for (int cc = 0; cc < NCOMP; cc++) ref[cc * rstride + node] = acc_v[cc];
 }
 
+// ---- APIC (knApicMapLinearVec3ToMACGrid, apic.cpp:19-90): same gather, other weights.  The reference addresses the 8 nodes
+// by FLAT index gidx + dX[i] + dY[j] + dZ[k] with no bounds check; the gather follows the flat arithmetic (a node n is fed by
+// the base indices n - (i + j*Y + k*Z)), faces whose base index lies outside [0, n) are skipped like in the oracle.
+template <int COMP>
+__global__ void __launch_bounds__(BLOCK)
+k_keys_apic(Dim d, int64_t np, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ pflag, const int32_t* __restrict__ ptype,
+            int exclude, int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ counts) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	int key = (int)d.n;
+	if (!((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude)))) {
+		const ApicFace a = apic_face<COMP>(d, pos[p], pos[ps + p], pos[2 * ps + p]);
+		if (a.gidx >= 0 && a.gidx < d.n) {
+			key = (int)a.gidx;
+			atomicAdd(&counts[key], 1);
+		}
+	}
+	keys[p] = key;
+	vals[p] = (int)p;
+}
+
+// one thread per node of face COMP: per particle (increasing index)  m += w ; v += w*vel_c ; v += w*dot(cp_c, node - pos)
+template <int COMP>
+__global__ void __launch_bounds__(BLOCK)
+k_gather_apic(Dim d, int64_t ps, const float* __restrict__ pos, const float* __restrict__ pvc, const float* __restrict__ cp,
+              const int32_t* __restrict__ order, const int32_t* __restrict__ start, float* __restrict__ vel, float* __restrict__ mass) {
+	const int64_t node = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (node >= d.n) return;
+	const int nlist = d.is3d ? 8 : 4;
+	int cur[8], end[8], head[8];
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		const int64_t base = node - ((q & 1) + ((q >> 1) & 1) * d.Y + (q >> 2) * d.Z);
+		int a = 0, e = 0;
+		if (q < nlist && base >= 0) {
+			a = start[base];
+			e = start[base + 1];
+		}
+		cur[q] = a;
+		end[q] = e;
+		head[q] = a < e ? order[a] : INT_MAX;
+	}
+	float acc_m = 0.f, acc_v = 0.f;
+	for (;;) {
+		int best = INT_MAX, bm = 0;
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			if (head[q] < best) {
+				best = head[q];
+				bm = q;
+			}
+		if (best == INT_MAX) break;
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			if (q == bm) {
+				cur[q]++;
+				head[q] = cur[q] < end[q] ? order[cur[q]] : INT_MAX;
+			}
+		const int p = best;
+		const float px = pos[p], py = pos[ps + p], pz = pos[2 * ps + p];
+		const ApicFace a = apic_face<COMP>(d, px, py, pz);
+		const int di = bm & 1, dj = (bm >> 1) & 1;
+		const float vc = pvc[p], c0 = cp[p], c1 = cp[ps + p], c2 = cp[2 * ps + p];
+		const float wij = (di ? a.W[0][1] : a.W[0][0]) * (dj ? a.W[1][1] : a.W[1][0]);
+		const float dx = (a.gpos[0] + (float)di) - px, dy = (a.gpos[1] + (float)dj) - py;
+		// 3D: the list fixes k; 2D (strideZ == 0): k = 0 then k = 1 land on this node, in the reference's loop order
+		const int k0 = d.is3d ? (bm >> 2) : 0, k1 = d.is3d ? (bm >> 2) : 1;
+		for (int k = k0; k <= k1; k++) {
+			const float w = wij * (k ? a.W[2][1] : a.W[2][0]);
+			const float dz = (a.gpos[2] + (float)k) - pz;
+			acc_m += w;
+			acc_v += w * vc;
+			acc_v += w * (c0 * dx + c1 * dy + c2 * dz);
+		}
+	}
+	mass[node] = acc_m;
+	vel[node] = acc_v;
+}
+
 struct Scratch {
 	int32_t* keys = nullptr;    // [2 * cap_p]
 	int32_t* vals = nullptr;    // [2 * cap_p]
@@ -191,6 +270,26 @@ int run(const Dim& d, int64_t np, int64_t ps, const float* pos, const int32_t* p
 	return 0;
 }
 
+template <int COMP>
+int run_apic(const Dim& d, int64_t np, int64_t ps, const float* pos, const int32_t* pflag, const int32_t* ptype, int exclude,
+             const float* pvc, const float* cp, float* vel, float* mass, hipStream_t st) {
+	if (np >= ((int64_t)1 << 31) - 1) return fail("ordered P2G: too many particles for 32-bit indices");
+	size_t scan_bytes = 0, sort_bytes = 0;
+	int end_bit = 1;
+	while (end_bit < 31 && (((int64_t)1 << end_bit) <= d.n)) end_bit++;
+	MF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)(d.n + 1), st));
+	MF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)np, 0, end_bit, st));
+	Scratch* s;
+	MF_TRY(get_scratch(np, d.n, (scan_bytes > sort_bytes ? scan_bytes : sort_bytes) + 256, &s));
+	MF_HIP(hipMemsetAsync(s->counts, 0, sizeof(int32_t) * (d.n + 1), st));
+	hipLaunchKernelGGL((k_keys_apic<COMP>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, np, ps, pos, pflag, ptype, exclude, s->keys, s->vals, s->counts);
+	MF_HIP(hipcub::DeviceScan::ExclusiveSum(s->tmp, scan_bytes, s->counts, s->start, (int)(d.n + 1), st));
+	MF_HIP(hipcub::DeviceRadixSort::SortPairs(s->tmp, sort_bytes, s->keys, s->keys + np, s->vals, s->vals + np, (int)np, 0, end_bit, st));
+	hipLaunchKernelGGL((k_gather_apic<COMP>), dim3(nblk_n(d.n)), dim3(BLOCK), 0, st, d, ps, pos, pvc, cp, s->vals + np, s->start, vel, mass);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
 }  // namespace
 
 namespace mf {
@@ -208,6 +307,16 @@ int p2g_ordered_cell(const Dim& d, int ncomp, float* target, float* wsum, int64_
                      const int32_t* pflag, const float* psrc, hipStream_t st) {
 	if (ncomp == 1) return run<3, 1>(d, np, ps, pos, pflag, nullptr, 0, psrc, ps, target, d.n, wsum, st);
 	return run<3, 3>(d, np, ps, pos, pflag, nullptr, 0, psrc, ps, target, d.n, wsum, st);
+}
+
+// vel / mass: SoA MAC grids; in 2-D the w face is not touched by the reference (apic.cpp:73) -> the caller's zeros stay
+int p2g_ordered_apic(const Dim& d, float* vel, float* mass, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
+                     const float* pvel, const float* cpx, const float* cpy, const float* cpz, const int32_t* ptype, int exclude,
+                     hipStream_t st) {
+	MF_TRY((run_apic<0>(d, np, ps, pos, pflag, ptype, exclude, pvel, cpx, vel, mass, st)));
+	MF_TRY((run_apic<1>(d, np, ps, pos, pflag, ptype, exclude, pvel + ps, cpy, vel + d.n, mass + d.n, st)));
+	if (d.is3d) MF_TRY((run_apic<2>(d, np, ps, pos, pflag, ptype, exclude, pvel + 2 * ps, cpz, vel + 2 * d.n, mass + 2 * d.n, st)));
+	return 0;
 }
 
 }  // namespace mf

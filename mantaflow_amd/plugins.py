@@ -306,6 +306,28 @@ def flipVelocityUpdate(flags, vel, velOld, parts, partVel, flipRatio, ptype=None
                partVel.ptr, float(flipRatio), pt, int(exclude), s.stream)
 
 
+@plugin
+def apicMapPartsToMAC(flags, vel, parts, partVel, cpx, cpy, cpz, mass=None, ptype=None, exclude=0):
+    """plugin/apic.cpp:92-110; the scatter is summed in particle-index order per node (= the reference's serial kernel)"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(vel, MACGrid, "MACGrid")
+    mass = _opt(mass, MACGrid, "MACGrid")
+    s = flags.parent
+    m = mass if mass is not None else MACGrid(s)
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_apic_map_parts_to_mac", flags.sx, flags.sy, flags.sz, vel.ptr, m.ptr, np_, cap, pos, pfl, partVel.ptr,
+               cpx.ptr, cpy.ptr, cpz.ptr, pt, int(exclude), s.stream)
+
+
+@plugin
+def apicMapMACGridToParts(partVel, cpx, cpy, cpz, parts, vel, flags, ptype=None, exclude=0):
+    """plugin/apic.cpp:175-181"""
+    _chk(vel, MACGrid, "MACGrid")
+    s = flags.parent
+    (np_, cap, pos, pfl), pt = _pargs(parts, ptype)
+    s.lib.call("mf_apic_map_mac_to_parts", flags.sx, flags.sy, flags.sz, vel.ptr, np_, cap, pos, pfl, partVel.ptr,
+               cpx.ptr, cpy.ptr, cpz.ptr, pt, int(exclude), s.stream)
+
+
 def _map_parts_to_grid(flags, target, parts, source, ncomp):
     s = flags.parent
     tmp = Grid(s)

@@ -1273,6 +1273,118 @@ int mf_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, in
 	}
 	return 0;
 }
+/* ---- APIC transfers, plugin/apic.cpp ------------------------------------------------------------------------
+ * Index/weight set-up shared by both directions (apic.cpp:29-33, 119-123): face index f* = (IndexInt)pos, centre index
+ * c* = (IndexInt)(pos - 0.5) with the subtraction in double (0.5 is a double literal) and truncation toward zero,
+ * wf = clamp(pos - f, 0, 1) in fp32, wc = clamp(Real(pos - c - 0.5), 0, 1) with the "- 0.5" in double. */
+typedef struct {
+	int64_t f[3], c[3];
+	float wf[3], wc[3];
+} ApicIdx;
+static inline float clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+static inline void apic_setup(const float pos[3], ApicIdx* a) {
+	for (int q = 0; q < 3; q++) {
+		a->f[q] = (int64_t)pos[q];
+		a->c[q] = (int64_t)((double)pos[q] - 0.5);
+		a->wf[q] = clamp01(pos[q] - (float)a->f[q]);
+		a->wc[q] = clamp01((float)((double)(pos[q] - (float)a->c[q]) - 0.5));
+	}
+}
+/* face comp (0 u, 1 v, 2 w): base index per axis, grid position of the base node, per-axis weight pairs */
+static inline void apic_face(const ApicIdx* a, int comp, int64_t b[3], float gpos[3], float W[3][2]) {
+	for (int q = 0; q < 3; q++) {
+		const int onface = (q == comp);
+		b[q] = onface ? a->f[q] : a->c[q];
+		gpos[q] = onface ? (float)a->f[q] : (float)((double)a->c[q] + 0.5);
+		const float w = onface ? a->wf[q] : a->wc[q];
+		W[q][0] = 1.f - w;
+		W[q][1] = w;
+	}
+}
+/* apicMapPartsToMAC, apic.cpp:92-110 (knApicMapLinearVec3ToMACGrid :19-90, KERNEL(pts, single)).  The reference does not
+ * bound-check the node index (":34 TODO"); a face whose base index falls outside the grid, and nodes past the end, are
+ * skipped here (out-of-bounds writes in the reference).  mass: MAC grid (SoA), always written. */
+int mf_apic_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* mass, int64_t np, int64_t ps, const float* pos,
+                             const int32_t* pflag, const float* pvel, const float* cpx, const float* cpy, const float* cpz,
+                             const int32_t* ptype, int exclude, void* st) {
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	const float* cp[3] = {cpx, cpy, cpz};
+	memset(mass, 0, sizeof(float) * 3 * n);
+	memset(vel, 0, sizeof(float) * 3 * n);
+	for (int64_t p = 0; p < np; p++) {
+		if (skip_particle(pflag, ptype, exclude, p)) continue;
+		const float P[3] = {pos[p], pos[ps + p], pos[2 * ps + p]};
+		ApicIdx a;
+		apic_setup(P, &a);
+		for (int comp = 0; comp < (d.is3d ? 3 : 2); comp++) {
+			int64_t b[3];
+			float gpos[3], W[3][2];
+			apic_face(&a, comp, b, gpos, W);
+			const int64_t gidx = b[0] + b[1] * d.Y + b[2] * d.Z;
+			if (gidx < 0 || gidx >= n) continue;
+			const float c0 = cp[comp][p], c1 = cp[comp][ps + p], c2 = cp[comp][2 * ps + p];
+			const float vc = pvel[comp * ps + p];
+			float* mg = mass + comp * n;
+			float* vg = vel + comp * n;
+			for (int i = 0; i < 2; i++)
+				for (int j = 0; j < 2; j++)
+					for (int k = 0; k < 2; k++) {
+						const int64_t node = gidx + i + j * d.Y + k * d.Z;
+						if (node >= n) continue;
+						const float w = W[0][i] * W[1][j] * W[2][k];
+						const float dx = (gpos[0] + (float)i) - P[0], dy = (gpos[1] + (float)j) - P[1], dz = (gpos[2] + (float)k) - P[2];
+						mg[node] += w;
+						vg[node] += w * vc;
+						vg[node] += w * (c0 * dx + c1 * dy + c2 * dz);
+					}
+		}
+	}
+	mf_grid_stomp(3 * n, mass, 1e-6f, st);     /* mass->stomp(VECTOR_EPSILON) */
+	mf_grid_safe_divide(3 * n, vel, mass, st); /* vel.safeDivide(*mass) */
+	return 0;
+}
+/* apicMapMACGridToParts, apic.cpp:175-181 (knApicMapLinearMACGridToVec3 :112-173) */
+int mf_apic_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t ps, const float* pos,
+                             const int32_t* pflag, float* pvel, float* cpx, float* cpy, float* cpz, const int32_t* ptype,
+                             int exclude, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	float* cp[3] = {cpx, cpy, cpz};
+	const float gw[2] = {-1.f, 1.f};
+#pragma omp parallel for
+	for (int64_t p = 0; p < np; p++) {
+		if (skip_particle(pflag, ptype, exclude, p)) continue;
+		const float P[3] = {pos[p], pos[ps + p], pos[2 * ps + p]};
+		ApicIdx a;
+		apic_setup(P, &a);
+		for (int comp = 0; comp < 3; comp++) {
+			float v = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+			if (comp < 2 || d.is3d) {
+				int64_t b[3];
+				float gpos[3], W[3][2];
+				apic_face(&a, comp, b, gpos, W);
+				const int64_t gidx = b[0] + b[1] * d.Y + b[2] * d.Z;
+				for (int i = 0; i < 2; i++)
+					for (int j = 0; j < 2; j++)
+						for (int k = 0; k < 2; k++) {
+							const int64_t node = gidx + i + j * d.Y + k * d.Z;
+							const float vg = (node >= 0 && node < n) ? vel[comp * n + node] : 0.f;
+							v += W[0][i] * W[1][j] * W[2][k] * vg;
+							g0 += gw[i] * W[1][j] * W[2][k] * vg;
+							g1 += W[0][i] * gw[j] * W[2][k] * vg;
+							g2 += W[0][i] * W[1][j] * gw[k] * vg;
+						}
+			}
+			pvel[comp * ps + p] = v;
+			cp[comp][p] = g0;
+			cp[comp][ps + p] = g1;
+			cp[comp][2 * ps + p] = g2;
+		}
+	}
+	return 0;
+}
 /* flipVelocityUpdate, flip.cpp:724-742: pvel = flipRatio*(v + delta) + (1.0 - flipRatio)*v2 ; the second
  * scalar is a double, so that product is rounded from fp64 (vectorbase.h:282-284) */
 int mf_flip_velocity_update(int sx, int sy, int sz, const float* vel, const float* velOld, int64_t np, int64_t ps,

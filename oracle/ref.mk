@@ -31,7 +31,7 @@ PP_CPP := general.cpp fluidsolver.cpp conjugategrad.cpp multigrid.cpp grid.cpp g
           fileio/ioutil.cpp fileio/iogrids.cpp fileio/iomeshes.cpp fileio/ioparticles.cpp fileio/iovdb.cpp \
           fileio/mantaio.cpp \
           plugin/advection.cpp plugin/extforces.cpp plugin/flip.cpp plugin/initplugins.cpp plugin/pressure.cpp \
-          plugin/ptsplugins.cpp plugin/waveletturbulence.cpp
+          plugin/ptsplugins.cpp plugin/waveletturbulence.cpp plugin/apic.cpp
 PP_H   := general.h commonkernels.h conjugategrad.h multigrid.h fastmarch.h fluidsolver.h grid.h grid4d.h \
           mesh.h particle.h levelset.h shapes.h noisefield.h vortexsheet.h kernel.h timing.h movingobs.h \
           fileio/mantaio.h edgecollapse.h vortexpart.h turbulencepart.h

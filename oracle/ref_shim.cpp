@@ -100,6 +100,12 @@ void applyNoiseVec3(const FlagGrid& flags, Grid<Vec3>& target, const WaveletNois
                     const Grid<Real>* weight, const Grid<Vec3>* uv);                                         // :156
 void vorticityConfinement(MACGrid& vel, const FlagGrid& flags, Real strength, const Grid<Real>* strengthCell);  // extforces.cpp:419
 void setOpenBound(FlagGrid& flags, int bWidth, std::string openBound, int type);                             // extforces.cpp:106
+void apicMapPartsToMAC(const FlagGrid& flags, MACGrid& vel, const BasicParticleSystem& parts, const ParticleDataImpl<Vec3>& partVel,
+                       const ParticleDataImpl<Vec3>& cpx, const ParticleDataImpl<Vec3>& cpy, const ParticleDataImpl<Vec3>& cpz,
+                       MACGrid* mass, const ParticleDataImpl<int>* ptype, const int exclude);                      // apic.cpp:92
+void apicMapMACGridToParts(ParticleDataImpl<Vec3>& partVel, ParticleDataImpl<Vec3>& cpx, ParticleDataImpl<Vec3>& cpy,
+                           ParticleDataImpl<Vec3>& cpz, const BasicParticleSystem& parts, const MACGrid& vel, const FlagGrid& flags,
+                           const ParticleDataImpl<int>* ptype, const int exclude);                                // apic.cpp:175
 void interpolateGrid(Grid<Real>& target, const Grid<Real>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);      // waveletturbulence.cpp:37
 void interpolateGridVec3(Grid<Vec3>& target, const Grid<Vec3>& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);  // :51
 void interpolateMACGrid(MACGrid& target, const MACGrid& source, Vec3 scale, Vec3 offset, Vec3i size, int orderSpace);         // :73
@@ -412,6 +418,55 @@ int ref_map_mac_to_parts(int sx, int sy, int sz, const int32_t* flags, const flo
 	}
 	mapMACToParts(fl, v.g, P.sys, pv.pd, pt ? &pt->pd : nullptr, exclude);
 	storeVec3(pv.pd, pvel, np, pstride);
+	SHIM_CATCH
+}
+
+/* apicMapPartsToMAC, apic.cpp:92-110 */
+int ref_apic_map_parts_to_mac(int sx, int sy, int sz, const int32_t* flags, float* vel, float* mass, int64_t np, int64_t pstride,
+                              const float* pos, const int32_t* pflag, const float* pvel, const float* cpx, const float* cpy,
+                              const float* cpz, const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, true), m(c, mass, true);
+	Parts P(c, np, pstride, pos, pflag);
+	Pdata<Vec3> pv(c, P), px(c, P), py(c, P), pz(c, P);
+	loadVec3(pv.pd, pvel, np, pstride);
+	loadVec3(px.pd, cpx, np, pstride);
+	loadVec3(py.pd, cpy, np, pstride);
+	loadVec3(pz.pd, cpz, np, pstride);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	apicMapPartsToMAC(fl, v.g, P.sys, pv.pd, px.pd, py.pd, pz.pd, &m.g, pt ? &pt->pd : nullptr, exclude);
+	SHIM_CATCH
+}
+/* apicMapMACGridToParts, apic.cpp:175-181 */
+int ref_apic_map_mac_to_parts(int sx, int sy, int sz, const int32_t* flags, const float* vel, int64_t np, int64_t pstride,
+                              const float* pos, const int32_t* pflag, float* pvel, float* cpx, float* cpy, float* cpz,
+                              const int32_t* ptype, int exclude) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	MacIO v(c, vel, false);
+	Parts P(c, np, pstride, pos, pflag);
+	Pdata<Vec3> pv(c, P), px(c, P), py(c, P), pz(c, P);
+	loadVec3(pv.pd, pvel, np, pstride);
+	loadVec3(px.pd, cpx, np, pstride);
+	loadVec3(py.pd, cpy, np, pstride);
+	loadVec3(pz.pd, cpz, np, pstride);
+	std::unique_ptr<Pdata<int> > pt;
+	if (ptype) {
+		pt.reset(new Pdata<int>(c, P));
+		for (int64_t i = 0; i < np; i++) pt->pd[i] = ptype[i];
+	}
+	apicMapMACGridToParts(pv.pd, px.pd, py.pd, pz.pd, P.sys, v.g, fl, pt ? &pt->pd : nullptr, exclude);
+	storeVec3(pv.pd, pvel, np, pstride);
+	storeVec3(px.pd, cpx, np, pstride);
+	storeVec3(py.pd, cpy, np, pstride);
+	storeVec3(pz.pd, cpz, np, pstride);
 	SHIM_CATCH
 }
 

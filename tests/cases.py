@@ -296,6 +296,57 @@ def run_flip_ref(dims, flags, vel, velOld, pos, pflag, pvel, ptype=None, exclude
     return out
 
 
+def apic_inputs(dims, seed, per_cell=3, include_border=False):
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=True)
+    vel = util.rand_vel(sx, sy, sz, seed + 1)
+    pos, pflag, pvel = util.make_particles(flags, per_cell, seed + 2, include_border=include_border)
+    rng = np.random.default_rng(seed + 3)
+    cp = [rng.normal(0, 0.3, pvel.shape).astype(np.float32) for _ in range(3)]
+    return flags, vel, pos, pflag, pvel, cp
+
+
+def run_apic_pkg(dims, flags, vel, pos, pflag, pvel, cp, ptype=None, exclude=0, with_mass=True):
+    """apicMapPartsToMAC -> (vel, mass); apicMapMACGridToParts -> (pvel, cpx, cpy, cpz)"""
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims)
+    fl = soa_to_grid(core.FlagGrid(s), flags)
+    pp = _mk_parts(s, pos, pflag)
+    pv = _pd_vec3(s, pp, pvel)
+    c = [_pd_vec3(s, pp, x) for x in cp]
+    pt = None
+    if ptype is not None:
+        pt = pp.create(core.PdataInt)
+        pt.data[:pp.np] = torch.from_numpy(ptype).to(pt.data.device)
+    out = {}
+    v, m = core.MACGrid(s), core.MACGrid(s)
+    soa_to_grid(v, util.rand_vel(*dims, 99)); soa_to_grid(m, util.rand_vel(*dims, 98))     # must be cleared by the plugin
+    plugins.apicMapPartsToMAC(fl, v, pp, pv, c[0], c[1], c[2], mass=m if with_mass else None, ptype=pt, exclude=exclude)
+    out["apic_vel"] = grid_to_soa(v)
+    if with_mass:
+        out["apic_mass"] = grid_to_soa(m)
+    gv = soa_to_grid(core.MACGrid(s), vel)
+    plugins.apicMapMACGridToParts(pv, c[0], c[1], c[2], pp, gv, fl, ptype=pt, exclude=exclude)
+    out["apic_pvel"] = _pd_get(pv, pp.np)
+    for q, nm in enumerate(("cpx", "cpy", "cpz")):
+        out["apic_" + nm] = _pd_get(c[q], pp.np)
+    s.sync()
+    return out
+
+
+def run_apic_ref(dims, flags, vel, pos, pflag, pvel, cp, ptype=None, exclude=0):
+    sx, sy, sz = dims
+    n = pos.shape[1]
+    out = {}
+    v, m = util.rand_vel(*dims, 99), util.rand_vel(*dims, 98)
+    refcall("ref_apic_map_parts_to_mac", sx, sy, sz, flags, v, m, n, n, pos, pflag, pvel, cp[0], cp[1], cp[2], ptype, exclude)
+    out["apic_vel"], out["apic_mass"] = v, m
+    pv, c = pvel.copy(), [x.copy() for x in cp]
+    refcall("ref_apic_map_mac_to_parts", sx, sy, sz, flags, vel, n, n, pos, pflag, pv, c[0], c[1], c[2], ptype, exclude)
+    out["apic_pvel"], out["apic_cpx"], out["apic_cpy"], out["apic_cpz"] = pv, c[0], c[1], c[2]
+    return out
+
+
 def run_advect_parts_pkg(dims, dt, flags, vel, pos, pflag, mode, deleteInObstacle, stopInObstacle=True, skipNew=False,
                          ptype=None, exclude=0):
     from mantaflow_amd import core
@@ -945,6 +996,8 @@ def golden_outputs(impl, deterministic_p2g=True):
     for tag, dim, res, steps in (("wlt2d_", 2, 32, 6), ("wlt3d_", 3, 16, 4)):
         for k, v in run_wavelet_scene_pkg(res, dim, steps).items():
             out[tag + k] = v
+    ad = (12, 10, 9)
+    out.update(run_apic_pkg(ad, *apic_inputs(ad, 61)))
     return out
 
 

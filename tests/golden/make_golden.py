@@ -73,6 +73,9 @@ def main():
     for tag, dim, res, steps in (("wlt2d_", 2, 32, 6), ("wlt3d_", 3, 16, 4)):
         for k, v in cases.run_wavelet_scene_ref(res, dim, steps).items():
             out[tag + k] = v
+    # APIC transfers (plugin/apic.cpp)
+    ad = (12, 10, 9)
+    out.update(cases.run_apic_ref(ad, *cases.apic_inputs(ad, 61)))
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote %d arrays, %.1f KiB" % (len(out), os.path.getsize(os.path.join(HERE, "reference_vectors.npz")) / 1024))
 

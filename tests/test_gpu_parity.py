@@ -301,6 +301,26 @@ def test_wavelet_turbulence_pieces(hip_backend, dims, small):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims,per_cell,border", [((12, 10, 9), 3, False), (cases.SIZE_2D, 3, True), ((33, 18, 9), 4, True), ((64, 48, 40), 8, True), ((40, 33, 27), 27, False)])
+@pytest.mark.parametrize("with_ptype", [False, True])
+def test_apic_transfers(hip_backend, dims, per_cell, border, with_ptype):
+    """apicMapPartsToMAC (ordered gather = the reference's serial scatter) / apicMapMACGridToParts: HIP bit-identical to the
+    oracle, itself pinned to the compiled reference (test_oracle_vs_reference.py::test_apic_transfers); `border` adds
+    particles in wall cells, whose face stencils wrap to the next grid row exactly as the reference's flat index does"""
+    from mantaflow_amd import _lib
+    flags, vel, pos, pflag, pvel, cp = cases.apic_inputs(dims, 61, per_cell, include_border=border)
+    ptype = (np.random.default_rng(18).integers(0, 4, pos.shape[1]) * 2).astype(np.int32) if with_ptype else None
+    ex = 4 if with_ptype else 0
+    a = cases.run_apic_pkg(dims, flags, vel, pos, pflag, pvel, cp, ptype, ex)
+    a2 = cases.run_apic_pkg(dims, flags, vel, pos, pflag, pvel, cp, ptype, ex, with_mass=False)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_apic_pkg(dims, flags, vel, pos, pflag, pvel, cp, ptype, ex)
+    _lib.reset()
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+    assert_bitexact(a2["apic_vel"], b["apic_vel"], "apic_vel without a mass grid")
+
+
 def test_dam_break_steps_match_oracle(hip_backend):
     """three steps of a ghost-fluid FLIP dam break (benchmark_dam.py's loop) on the GPU = the same steps on the oracle:
     flags and particle types bit-exact, CG iteration counts identical, fields within 1e-5 (deterministic P2G)"""

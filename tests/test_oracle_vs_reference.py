@@ -134,6 +134,21 @@ def test_flip_transfers(oracle_backend, dims, with_ptype):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D, (17, 9, 11)])
+@pytest.mark.parametrize("with_ptype", [False, True])
+def test_apic_transfers(oracle_backend, dims, with_ptype):
+    """apicMapPartsToMAC / apicMapMACGridToParts (plugin/apic.cpp) against the compiled reference, bit for bit"""
+    flags, vel, pos, pflag, pvel, cp = cases.apic_inputs(dims, 61)
+    ptype = None
+    if with_ptype:
+        ptype = (np.random.default_rng(18).integers(0, 4, pos.shape[1]) * 2).astype(np.int32)
+    a = cases.run_apic_pkg(dims, flags, vel, pos, pflag, pvel, cp, ptype, 4 if with_ptype else 0)
+    b = cases.run_apic_ref(dims, flags, vel, pos, pflag, pvel, cp, ptype, 4 if with_ptype else 0)
+    assert np.abs(b["apic_vel"]).max() > 0.1 and np.abs(b["apic_cpx"]).max() > 0.01
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 @pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("deleteInObstacle,stopInObstacle", [(False, True), (True, True), (False, False), (True, False)])

@@ -51,6 +51,16 @@ def test_flip01_simple_3d(oracle_backend):
     assert g["pp"].pySize() > 1000
 
 
+def test_apic01_simple(oracle_backend):
+    """scenes/apic01_simple.py (APIC dam break, 2D as shipped) unchanged"""
+    import numpy as np
+    g = run_scene("apic01_simple.py", 4)
+    assert g["pp"].pySize() > 1000
+    v = g["vel"].to_numpy()
+    assert np.isfinite(v).all() and np.abs(v).max() > 1e-3
+    assert np.abs(g["pCx"].to_numpy()).max() > 0
+
+
 def test_benchmark_dam(oracle_backend):
     """scenes/benchmark_dam.py (BASELINE config 4, ghost-fluid FLIP dam break) at its own reference resolution, 3 steps.
     The file carries no `from manta import *` (the fork's copy relies on the interpreter having it); the test supplies it.
