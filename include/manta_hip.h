@@ -300,6 +300,11 @@ int mf_update_velocity_from_delta_pos(int64_t np, int64_t pstride, const float* 
 /* eulerStep -> KnStepEuler, ptsplugins.cpp:43-53 */
 int mf_euler_step(int64_t np, int64_t pstride, float* pos, const float* pvel, float dt, const int32_t* ptype,
                   int exclude, void* stream);
+/* resetOutflow, extforces.cpp:134-161: outflow cells get (flags | Empty) & ~Fluid, phi = 0.5, real = 0 (phi / real
+ * nullable); active particles that lie inside the grid in an outflow cell are flagged PDELETE (np 0 / pos NULL: none).
+ * The reference then compacts the particle array (doCompress); here deleted particles stay flagged and are skipped. */
+int mf_reset_outflow(int sx, int sy, int sz, int32_t* flags, float* phi, float* real, int64_t np, int64_t pstride,
+                     const float* pos, int32_t* pflag, void* stream);
 /* LevelsetGrid::join -> KnJoin (min) / subtract -> KnSubtract (phi = -other where other < 0; flags nullable: only in
  * cells with flags & subtractType), levelset.cpp:107-118; Grid::setBound -> knSetBoundary grid.cpp:629-637 */
 int mf_levelset_join(int64_t n, float* phi, const float* other, void* stream);

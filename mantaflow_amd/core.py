@@ -437,6 +437,13 @@ class IntGrid(GridBase):
     def setConst(self, v): self._call("mf_fill_i32", self.n, self.ptr, int(v), self.parent.stream)
     def clear(self): self._call("mf_fill_i32", self.n, self.ptr, 0, self.parent.stream)
 
+    # scene-side conveniences of Grid<int> (grid.cpp:370-380): exact integer reductions on the device tensor
+    def _sync(self): self.parent.sync()
+    def getMin(self): self._sync(); return float(self.data.min().item())
+    def getMax(self): self._sync(); return float(self.data.max().item())
+    def getMaxAbs(self): return max(abs(self.getMin()), abs(self.getMax()))
+    def sub(self, a): self._check_same(a); self._sync(); self.data.sub_(a.data)
+
 
 class VecGrid(GridBase):
     """Grid<Vec3> (python: VecGrid / Vec3Grid), SoA storage."""
@@ -474,6 +481,18 @@ class VecGrid(GridBase):
         return r.value
 
     getMax = getMaxAbs
+
+    def getMin(self):
+        """sqrt(CompMinVec), grid.cpp:364-366: smallest normSquare (x*x + y*y + z*z in fp32)"""
+        self.parent.sync()
+        d, n = self.data, self.n
+        return float((d[:n] * d[:n] + d[n:2 * n] * d[n:2 * n] + d[2 * n:3 * n] * d[2 * n:3 * n]).min().sqrt().item())
+
+    def setBound(self, value, boundaryWidth=1):
+        """Grid<Vec3>::setBound -> knSetBoundary, grid.cpp:629-637"""
+        v = _to_vec3(value)
+        for c, x in enumerate((v.x, v.y, v.z)):
+            self._call("mf_grid_set_bound", self.sx, self.sy, self.sz, _ptr(self.data[c * self.n:]), float(x), int(boundaryWidth), self.parent.stream)
 
 
 Vec3Grid = VecGrid

@@ -171,6 +171,27 @@ __global__ void __launch_bounds__(BLOCK) k_set_bound(Dim d, float* __restrict__ 
 	if (bnd) g[idx] = value;
 }
 
+// resetOutflow, extforces.cpp:134-161
+__global__ void __launch_bounds__(BLOCK) k_reset_outflow_parts(Dim d, const int32_t* __restrict__ flags, int64_t np, int64_t ps,
+                                                               const float* __restrict__ pos, int32_t* __restrict__ pflag) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (p >= np) return;
+	const int pf = pflag[p];
+	if (pf & MF_PDELETE) return;
+	const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+	if (i < 0 || j < 0 || k < 0 || i >= d.sx || j >= d.sy || k >= d.sz) return;
+	if (flags[i + d.Y * j + d.Z * k] & MF_OUTFLOW) pflag[p] = pf | MF_PDELETE;
+}
+__global__ void __launch_bounds__(BLOCK) k_reset_outflow(int64_t n, int32_t* __restrict__ flags, float* __restrict__ phi, float* __restrict__ real) {
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (idx >= n) return;
+	const int f = flags[idx];
+	if (!(f & MF_OUTFLOW)) return;
+	flags[idx] = (f | MF_EMPTY) & ~MF_FLUID;
+	if (phi) phi[idx] = 0.5f;
+	if (real) real[idx] = 0.f;
+}
+
 // extrapolateLsSimple, fastmarch.cpp:472-522
 __global__ void __launch_bounds__(BLOCK) k_els_mark(Dim d, const float* __restrict__ phi, int32_t* __restrict__ tmp, int inside, int b) {
 	CELL_IJK(d)
@@ -404,6 +425,18 @@ int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boun
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	hipLaunchKernelGGL(k_set_bound, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, grid, value, boundaryWidth);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_reset_outflow(int sx, int sy, int sz, int32_t* flags, float* phi, float* real, int64_t np, int64_t ps, const float* pos,
+                     int32_t* pflag, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	if (np > 0 && pos && pflag)
+		hipLaunchKernelGGL(k_reset_outflow_parts, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, flags, np, ps, pos, pflag);
+	hipLaunchKernelGGL(k_reset_outflow, dim3(nblk_n(d.n)), dim3(BLOCK), 0, st, d.n, flags, phi, real);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

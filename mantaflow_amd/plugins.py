@@ -307,6 +307,17 @@ def flipVelocityUpdate(flags, vel, velOld, parts, partVel, flipRatio, ptype=None
 
 
 @plugin
+def resetOutflow(flags, phi=None, parts=None, real=None, index=None, indexSys=None):
+    """extforces.cpp:134-161 (index / indexSys only speed up the reference's particle loop; same result without)"""
+    _chk(flags, FlagGrid, "FlagGrid")
+    phi, real = _opt(phi, Grid, "Grid<Real>"), _opt(real, Grid, "Grid<Real>")
+    s = flags.parent
+    np_, cap, pos, pfl = (0, 0, None, None) if parts is None else _pargs(parts, None)[0]
+    s.lib.call("mf_reset_outflow", flags.sx, flags.sy, flags.sz, flags.ptr, None if phi is None else phi.ptr,
+               None if real is None else real.ptr, np_, cap, pos, pfl, s.stream)
+
+
+@plugin
 def apicMapPartsToMAC(flags, vel, parts, partVel, cpx, cpy, cpz, mass=None, ptype=None, exclude=0):
     """plugin/apic.cpp:92-110; the scatter is summed in particle-index order per node (= the reference's serial kernel)"""
     _chk(flags, FlagGrid, "FlagGrid"); _chk(vel, MACGrid, "MACGrid")

@@ -1990,6 +1990,27 @@ int mf_union_particle_levelset(int sx, int sy, int sz, int64_t np, int64_t ps, c
 	return mf_grid_set_bound(sx, sy, sz, phi, 0.5f, 0, st);
 }
 
+/* resetOutflow, extforces.cpp:134-161 (particles: flagged, not compacted) */
+int mf_reset_outflow(int sx, int sy, int sz, int32_t* flags, float* phi, float* real, int64_t np, int64_t ps, const float* pos,
+                     int32_t* pflag, void* st) {
+	(void)st;
+	Dim d = mkdim(sx, sy, sz);
+	if (pos && pflag)
+		for (int64_t p = 0; p < np; p++) {
+			if (pflag[p] & MF_PDELETE) continue;
+			const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+			if (i < 0 || j < 0 || k < 0 || i >= sx || j >= sy || k >= sz) continue;
+			if (flags[IDX(d, i, j, k)] & MF_OUTFLOW) pflag[p] |= MF_PDELETE;
+		}
+	for (int64_t idx = 0; idx < d.n; idx++)
+		if (flags[idx] & MF_OUTFLOW) {
+			flags[idx] = (flags[idx] | MF_EMPTY) & ~MF_FLUID;
+			if (phi) phi[idx] = 0.5f;
+			if (real) real[idx] = 0.f;
+		}
+	return 0;
+}
+
 /* knSetBoundary, grid.cpp:629-637 */
 int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int w, void* st) {
 	(void)st;

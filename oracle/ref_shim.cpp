@@ -99,7 +99,9 @@ void computeWaveletCoeffs(Grid<Real>& input);                                   
 void applyNoiseVec3(const FlagGrid& flags, Grid<Vec3>& target, const WaveletNoiseField& noise, Real scale, Real scaleSpatial,
                     const Grid<Real>* weight, const Grid<Vec3>* uv);                                         // :156
 void vorticityConfinement(MACGrid& vel, const FlagGrid& flags, Real strength, const Grid<Real>* strengthCell);  // extforces.cpp:419
-void setOpenBound(FlagGrid& flags, int bWidth, std::string openBound, int type);                             // extforces.cpp:106
+void setOpenBound(FlagGrid& flags, int bWidth, std::string openBound, int type);
+void resetOutflow(FlagGrid& flags, Grid<Real>* phi, BasicParticleSystem* parts, Grid<Real>* real, Grid<int>* index,
+                  ParticleIndexSystem* indexSys);                                                                // extforces.cpp:134                             // extforces.cpp:106
 void apicMapPartsToMAC(const FlagGrid& flags, MACGrid& vel, const BasicParticleSystem& parts, const ParticleDataImpl<Vec3>& partVel,
                        const ParticleDataImpl<Vec3>& cpx, const ParticleDataImpl<Vec3>& cpy, const ParticleDataImpl<Vec3>& cpz,
                        MACGrid* mass, const ParticleDataImpl<int>* ptype, const int exclude);                      // apic.cpp:92
@@ -797,6 +799,29 @@ int ref_levelset_subtract(int64_t n, float* phi, const float* other, const int32
 	std::unique_ptr<FlagGrid> fl;
 	if (flags) fl.reset(new FlagGrid(&c.solver, const_cast<int*>(flags)));
 	a.g->subtract(*b.g, fl.get(), subtractType);
+	SHIM_CATCH
+}
+/* resetOutflow, extforces.cpp:134-161.  The reference compacts the particle array afterwards; the survivors are returned
+ * in order (pos SoA [3][pstride], first *np_out entries), so the caller can compare them with its non-deleted particles. */
+int ref_reset_outflow(int sx, int sy, int sz, int32_t* flags, float* phi, float* real, int64_t np, int64_t pstride, float* pos,
+                      int32_t* pflag, int64_t* np_out) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, flags);
+	RealRef p(c, phi), r(c, real);
+	std::unique_ptr<Parts> P;
+	if (pos) P.reset(new Parts(c, np, pstride, pos, pflag));
+	resetOutflow(fl, p.ptr(), P ? &P->sys : nullptr, r.ptr(), nullptr, nullptr);
+	if (P) {
+		const int64_t m = P->sys.size();
+		for (int64_t i = 0; i < m; i++) {
+			pos[i] = P->sys[i].pos.x;
+			pos[pstride + i] = P->sys[i].pos.y;
+			pos[2 * pstride + i] = P->sys[i].pos.z;
+			pflag[i] = P->sys[i].flag;
+		}
+		*np_out = m;
+	}
 	SHIM_CATCH
 }
 int ref_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int w) {

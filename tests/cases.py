@@ -212,6 +212,11 @@ def _mk_parts(s, pos, pflag):
     return pp
 
 
+def _parts_get(pp):
+    a = pp.pos.detach().cpu().numpy()
+    return np.stack([a[c * pp.cap:c * pp.cap + pp.np] for c in range(3)], 0), pp.flag[:pp.np].cpu().numpy().copy()
+
+
 def _pd_vec3(s, pp, arr):
     from mantaflow_amd import core
     pd = pp.create(core.PdataVec3)
@@ -293,6 +298,60 @@ def run_flip_ref(dims, flags, vel, velOld, pos, pflag, pvel, ptype=None, exclude
     pv4 = pvel.copy()
     refcall("ref_map_grid_to_parts", sx, sy, sz, 3, vel, n, n, pos, pflag, pv4)
     out["g2p_vec3"] = pv4
+    return out
+
+
+def _sorted_parts(P, F):
+    """the reference's compress() moves tail particles into the holes (particle.h:614-633): compare as sets"""
+    o = np.lexsort((P[2], P[1], P[0]))
+    return np.ascontiguousarray(P[:, o]), F[o]
+
+
+def outflow_inputs(dims, seed):
+    """open (outflow) +-y faces as setOpenBound makes them, a random phi / density, particles everywhere"""
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, seed, empty_top=False)
+    flags[:, :2, 1:-1] = 16 | 4
+    flags[:, -2:, 1:-1] = 16 | 1            # outflow cells still marked fluid: resetOutflow must turn them empty
+    phi, real = util.rand_real((sz, sy, sx), seed + 1), util.rand_real((sz, sy, sx), seed + 2)
+    rng = np.random.default_rng(seed + 3)
+    n = 4000
+    pos = np.stack([rng.uniform(-0.5, sx + 0.5, n), rng.uniform(-0.5, sy + 0.5, n),
+                    rng.uniform(-0.5, sz + 0.5, n) if sz > 1 else np.full(n, 0.5)], 0).astype(np.float32)
+    pflag = np.zeros(n, np.int32)
+    pflag[rng.random(n) < 0.05] = 1 << 10
+    return flags, phi, real, pos, pflag
+
+
+def run_outflow_pkg(dims, flags, phi, real, pos, pflag):
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims)
+    fl = soa_to_grid(core.FlagGrid(s), flags)
+    p, r = soa_to_grid(core.Grid(s), phi), soa_to_grid(core.Grid(s), real)
+    pp = _mk_parts(s, pos, pflag)
+    plugins.resetOutflow(flags=fl, phi=p, parts=pp, real=r)
+    s.sync()
+    P, F = _parts_get(pp)
+    keep = (F & (1 << 10)) == 0
+    out = {"flags": grid_to_soa(fl), "phi": grid_to_soa(p), "real": grid_to_soa(r)}
+    out["pos"], out["pflag"] = _sorted_parts(P[:, keep], F[keep])
+    fl2 = soa_to_grid(core.FlagGrid(s), flags)
+    plugins.resetOutflow(flags=fl2)
+    out["flags_only"] = grid_to_soa(fl2)
+    return out
+
+
+def run_outflow_ref(dims, flags, phi, real, pos, pflag):
+    sx, sy, sz = dims
+    n = pos.shape[1]
+    f, p, r, P, F = flags.copy(), phi.copy(), real.copy(), pos.copy(), pflag.copy()
+    m = ctypes.c_int64(0)
+    refcall("ref_reset_outflow", sx, sy, sz, f, p, r, n, n, P, F, ctypes.byref(m))
+    out = {"flags": f, "phi": p, "real": r}
+    out["pos"], out["pflag"] = _sorted_parts(P[:, :m.value], F[:m.value])
+    f2 = flags.copy()
+    refcall("ref_reset_outflow", sx, sy, sz, f2, None, None, 0, 0, None, None, None)
+    out["flags_only"] = f2
     return out
 
 

@@ -321,6 +321,18 @@ def test_apic_transfers(hip_backend, dims, per_cell, border, with_ptype):
     assert_bitexact(a2["apic_vel"], b["apic_vel"], "apic_vel without a mass grid")
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
+def test_reset_outflow(hip_backend, dims):
+    from mantaflow_amd import _lib
+    inp = cases.outflow_inputs(dims, 71)
+    a = cases.run_outflow_pkg(dims, *inp)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_outflow_pkg(dims, *inp)
+    _lib.reset()
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 def test_dam_break_steps_match_oracle(hip_backend):
     """three steps of a ghost-fluid FLIP dam break (benchmark_dam.py's loop) on the GPU = the same steps on the oracle:
     flags and particle types bit-exact, CG iteration counts identical, fields within 1e-5 (deterministic P2G)"""

@@ -134,6 +134,17 @@ def test_flip_transfers(oracle_backend, dims, with_ptype):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
+def test_reset_outflow(oracle_backend, dims):
+    """resetOutflow (extforces.cpp:134-161): flags / phi / real bit for bit; the particles that survive the reference's
+    kill + compaction are exactly the package's non-deleted particles (as a set: compress() reorders)"""
+    inp = cases.outflow_inputs(dims, 71)
+    a, b = cases.run_outflow_pkg(dims, *inp), cases.run_outflow_ref(dims, *inp)
+    assert 0 < b["pos"].shape[1] < (inp[4] == 0).sum() and (b["flags"] != inp[0]).any()
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 @pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D, (17, 9, 11)])
 @pytest.mark.parametrize("with_ptype", [False, True])
 def test_apic_transfers(oracle_backend, dims, with_ptype):

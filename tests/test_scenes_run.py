@@ -51,6 +51,23 @@ def test_flip01_simple_3d(oracle_backend):
     assert g["pp"].pySize() > 1000
 
 
+def test_plume_2d(oracle_backend):
+    """scenes/plume_2d.py: open +-y boundaries (setOpenBound + resetOutflow + convective outflow BC in the MAC advection)"""
+    import numpy as np
+    g = run_scene("plume_2d.py", 6)
+    d = g["density"].to_numpy()
+    assert np.isfinite(d).all() and d.sum() > 10 and np.abs(g["vel"].to_numpy()).max() > 1e-3
+
+
+def test_numpy_write_read(oracle_backend, tmp_path, monkeypatch):
+    """scenes/numpy_write_read.py: APIC loop + .npz save/load round trips of Real / MAC / flag grids (differences must be 0)"""
+    monkeypatch.chdir(tmp_path)
+    g = run_scene("numpy_write_read.py", 3)
+    for a in ("pressure2", "vel2", "flags2"):      # each holds (loaded - original) at the end of the scene
+        assert g[a].getMaxAbs() == 0.0
+    assert g["pressure"].getMaxAbs() > 0
+
+
 def test_apic01_simple(oracle_backend):
     """scenes/apic01_simple.py (APIC dam break, 2D as shipped) unchanged"""
     import numpy as np
