@@ -368,9 +368,16 @@ int mf_grid_max_abs_dev(int64_t n, const float* a, float* out_dev, void* stream)
 int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out_dev, void* stream);
 /* scalar steps of GridCg::iterate (conjugategrad.cpp:250-291) on the all-gathered per-rank pairs
  * gathered[world][2] = {max|residual|, dot}: alpha = sigma / (Real)sum(dot) (0 if the sum is 0);
- * beta = (Real)sum(dot) / sigma, sigma := (Real)sum(dot), res = max over ranks.  Rows are combined in rank order. */
-int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, float* alpha_dev, void* stream);
-int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev, void* stream);
+ * beta = (Real)sum(dot) / sigma, sigma := (Real)sum(dot), res = max over ranks.  Rows are combined in rank order.
+ * state_dev (nullable) = int32[2] {stop, iteration}: the stopping test of GridCg::iterate (:262-272) evaluated on the
+ * device so that the host need not read a scalar every iteration.  beta sets {1, iter} the first time res < accuracy and
+ * {2, iter} when res is not < 1e35 (divergence); once stop != 0, beta leaves sigma/beta/res untouched and alpha returns 0,
+ * which turns the vector updates of any further (speculatively queued) iteration into no-ops: pressure and residual keep
+ * the values the reference stops with. */
+int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, float* alpha_dev,
+                     const int32_t* state_dev, void* stream);
+int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev,
+                    float accuracy, int iter, int32_t* state_dev, void* stream);
 /* me += (sign * factor_dev[0]) * other, sign = +-1 */
 int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor_dev, float sign, void* stream);
 /* dst = src + factor_dev[0] * dst */

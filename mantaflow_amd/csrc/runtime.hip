@@ -231,22 +231,39 @@ __global__ void __launch_bounds__(BLOCK) k_maxabs_finish(int nb, const float* __
 
 // z-slab PCG scalar steps on gathered per-rank reductions g[world][2] = {max|residual|, dot}: rows are summed / maxed in
 // rank order, so every rank computes the same bits (conjugategrad.cpp:250-291 for the formulas)
-__global__ void k_slab_alpha(const double* __restrict__ g, int world, const float* __restrict__ sigma, float* __restrict__ alpha) {
+__global__ void k_slab_alpha(const double* __restrict__ g, int world, const float* __restrict__ sigma, float* __restrict__ alpha,
+                             const int32_t* __restrict__ state) {
+	if (state && state[0]) {
+		alpha[0] = 0.f;
+		return;
+	}
 	double acc = 0.0;
 	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
 	const float dp = (float)acc;
 	alpha[0] = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
 }
-__global__ void k_slab_beta(const double* __restrict__ g, int world, float* __restrict__ sigma, float* __restrict__ beta, float* __restrict__ res) {
+__global__ void k_slab_beta(const double* __restrict__ g, int world, float* __restrict__ sigma, float* __restrict__ beta, float* __restrict__ res,
+                            float accuracy, int iter, int32_t* __restrict__ state) {
+	if (state && state[0]) return;
 	double acc = 0.0, mx = 0.0;
 	for (int r = 0; r < world; r++) {
 		acc += g[2 * r + 1];
 		mx = g[2 * r] > mx ? g[2 * r] : mx;
 	}
 	const float sigmaNew = (float)acc;
-	res[0] = (float)mx;
+	const float rn = (float)mx;
+	res[0] = rn;
 	beta[0] = sigmaNew / sigma[0];
 	sigma[0] = sigmaNew;
+	if (state) {
+		if (rn < accuracy) {
+			state[0] = 1;
+			state[1] = iter;
+		} else if (!(rn < 1e35f)) {
+			state[0] = 2;
+			state[1] = iter;
+		}
+	}
 }
 __global__ void __launch_bounds__(BLOCK) k_maxabs_finish64(int nb, const float* __restrict__ partials, double* __restrict__ out) {
 	float lo = FLT_MAX, hi = -FLT_MAX;
@@ -338,13 +355,14 @@ int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out_dev, void* s)
 	MF_LAUNCH_CHECK();
 	return 0;
 }
-int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, float* alpha_dev, void* s) {
-	hipLaunchKernelGGL(k_slab_alpha, dim3(1), dim3(1), 0, (hipStream_t)s, gathered, world, sigma_dev, alpha_dev);
+int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, float* alpha_dev, const int32_t* state_dev, void* s) {
+	hipLaunchKernelGGL(k_slab_alpha, dim3(1), dim3(1), 0, (hipStream_t)s, gathered, world, sigma_dev, alpha_dev, state_dev);
 	MF_LAUNCH_CHECK();
 	return 0;
 }
-int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev, void* s) {
-	hipLaunchKernelGGL(k_slab_beta, dim3(1), dim3(1), 0, (hipStream_t)s, gathered, world, sigma_dev, beta_dev, res_dev);
+int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev, float accuracy, int iter,
+                    int32_t* state_dev, void* s) {
+	hipLaunchKernelGGL(k_slab_beta, dim3(1), dim3(1), 0, (hipStream_t)s, gathered, world, sigma_dev, beta_dev, res_dev, accuracy, iter, state_dev);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

@@ -29,6 +29,7 @@ from . import core
 from .core import _ptr
 
 
+STOP_POLL = 4          # slab PCG: iterations between two host reads of the device-side stop state
 MIC_BLOCK_ROWS = 64   # y-extent of a preconditioner block when the domain is split over several ranks (0 = do not cut)
 
 
@@ -257,28 +258,40 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     dot_own(tmp, residual)
     sc[0] = 1.0                                                  # sigma := (Real)sum via the beta step (beta unused here)
     g0 = dom.comm.allgather_dev(red)          # (kept referenced until the kernel that reads it has been queued behind it)
-    lib.call("mf_cg_slab_beta", _ptr(g0), world, p_sigma, p_beta, p_res, st)
-    iters, resNorm = 0, 1e20
-    for _ in range(maxIter):
-        iters += 1
+    lib.call("mf_cg_slab_beta", _ptr(g0), world, p_sigma, p_beta, p_res, 0.0, 0, None, st)
+    # The stopping test runs on the device (state = {stop, iteration}); the host looks at it every STOP_POLL iterations.
+    # Iterations queued past the stop are no-ops for pressure and residual (alpha = 0), so the result is the one the
+    # reference stops with, and the host never drains the stream inside the loop.
+    state = torch.zeros(2, dtype=torch.int32, device=dev)
+    p_state = ctypes.c_void_p(state.data_ptr())
+    acc32 = float(np.float32(cgAccuracy))
+    keep = []
+    iters, resNorm, stop = 0, 1e20, 0
+    for it in range(1, maxIter + 1):
         dom.exchange(search, 1)
         lib.call("mf_apply_matrix", sx, sy, sz, flags.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)
         dot_own(tmp, search)
         g1 = dom.comm.allgather_dev(red)
-        lib.call("mf_cg_slab_alpha", _ptr(g1), world, p_sigma, p_alpha, st)   # conjugategrad.cpp:252-254
+        lib.call("mf_cg_slab_alpha", _ptr(g1), world, p_sigma, p_alpha, p_state, st)   # conjugategrad.cpp:252-254
         lib.call("mf_grid_scaled_add_dev", nown, _off(pressure.data, off), _off(search.data, off), p_alpha, 1.0, st)
         lib.call("mf_grid_scaled_add_dev", nown, _off(residual.data, off), _off(tmp.data, off), p_alpha, -1.0, st)
         mic(tmp, residual)
         lib.call("mf_grid_max_abs_dev_f64", nown, _off(residual.data, off), p_red0, st)
         dot_own(tmp, residual)
         g2 = dom.comm.allgather_dev(red)
-        lib.call("mf_cg_slab_beta", _ptr(g2), world, p_sigma, p_beta, p_res, st)
-        resNorm = float(sc[3])                                    # the one host read of the iteration
-        if np.float32(resNorm) < np.float32(cgAccuracy):
-            break
+        lib.call("mf_cg_slab_beta", _ptr(g2), world, p_sigma, p_beta, p_res, acc32, it, p_state, st)
         lib.call("mf_update_search_vec_dev", nown, _off(search.data, off), _off(tmp.data, off), p_beta, st)
-        if not (resNorm < 1e35):
-            raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
+        keep.append((g1, g2))                                     # gathered rows stay alive until the stream has consumed them
+        if it % STOP_POLL == 0 or it == maxIter:
+            stop, at = (int(v) for v in state.tolist())           # the one host read per STOP_POLL iterations
+            keep.clear()
+            if stop:
+                iters = at
+                break
+            iters = it
+    resNorm = float(sc[3])
+    if stop == 2:
+        raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     lib.call("mf_set_mic_blocking", 0)
     lib.call("mf_mic_check", st)
     if stats is not None:

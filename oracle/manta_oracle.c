@@ -2652,16 +2652,22 @@ int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out, void* s) {
 	*out = (double)maxabs(n, a);
 	return 0;
 }
-int mf_cg_slab_alpha(const double* g, int world, const float* sigma, float* alpha, void* s) {
+int mf_cg_slab_alpha(const double* g, int world, const float* sigma, float* alpha, const int32_t* state, void* s) {
 	(void)s;
+	if (state && state[0]) {
+		alpha[0] = 0.f;
+		return 0;
+	}
 	double acc = 0.0;
 	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
 	const float dp = (float)acc;
 	alpha[0] = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
 	return 0;
 }
-int mf_cg_slab_beta(const double* g, int world, float* sigma, float* beta, float* res, void* s) {
+int mf_cg_slab_beta(const double* g, int world, float* sigma, float* beta, float* res, float accuracy, int iter, int32_t* state,
+                    void* s) {
 	(void)s;
+	if (state && state[0]) return 0;
 	double acc = 0.0, mx = 0.0;
 	for (int r = 0; r < world; r++) {
 		acc += g[2 * r + 1];
@@ -2671,6 +2677,15 @@ int mf_cg_slab_beta(const double* g, int world, float* sigma, float* beta, float
 	res[0] = (float)mx;
 	beta[0] = sigmaNew / sigma[0];
 	sigma[0] = sigmaNew;
+	if (state) {
+		if (res[0] < accuracy) {
+			state[0] = 1;
+			state[1] = iter;
+		} else if (!(res[0] < 1e35f)) {
+			state[0] = 2;
+			state[1] = iter;
+		}
+	}
 	return 0;
 }
 int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor, float sign, void* s) {
