@@ -198,6 +198,14 @@ int mf_apply_outflow_bc(int sx, int sy, int sz, const int32_t* flags, float* vel
 int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight,
                         int64_t np, int64_t pstride, const float* pos, const int32_t* pflag, const float* pvel,
                         const int32_t* ptype, int exclude, int deterministic, void* stream);
+/* The two halves of mf_map_parts_to_mac, for a z-slab decomposition (SURVEY 8e "P2G scatter with reverse halo"): accum
+ * clears vel+weight and scatters this rank's particles (positions in global coordinates, mf_set_slab_window) into the local
+ * slab incl. one ghost plane per side; the caller adds the ghost-plane sums into the neighbour's boundary planes; finish
+ * applies weight.stomp(1e-6), vel.safeDivide(weight), velOld.copyFrom(vel) to n3 = 3*cells scalars (velOld nullable). */
+int mf_map_parts_to_mac_accum(int sx, int sy, int sz, float* vel, float* weight, int64_t np, int64_t pstride,
+                              const float* pos, const int32_t* pflag, const float* pvel, const int32_t* ptype,
+                              int exclude, int deterministic, void* stream);
+int mf_map_parts_to_mac_finish(int64_t n3, float* vel, float* velOld, float* weight, void* stream);
 /* mapMACToParts -> knMapLinearMACGridToVec3_PIC, flip.cpp:709-721 */
 int mf_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t pstride, const float* pos,
                         const int32_t* pflag, float* pvel, const int32_t* ptype, int exclude, void* stream);

@@ -378,13 +378,15 @@ __device__ __forceinline__ bool in_bounds_pos(const Dim& d, float x, float y, fl
 	const int i = (int)x, j = (int)y, k = (int)z;  // toVec3i truncation, grid.h:65
 	bool r = i >= bnd && j >= bnd && i < d.sx - bnd && j < d.sy - bnd;
 	if (d.is3d)
-		r = r && (k >= bnd && k < d.sz - bnd);
+		r = r && (k >= bnd && k < d.gsz - bnd);   // positions are global coordinates: the z extent is the whole domain's
 	else
 		r = r && (k == 0);
 	return r;
 }
 __device__ __forceinline__ int flag_at(const Dim& d, const int32_t* __restrict__ flags, float x, float y, float z) {
-	return flags[(int64_t)(int)x + d.Y * (int)y + d.Z * (int)z];  // FlagGrid::getAt, grid.h:324
+	int k = (int)z - d.zoff;                     // plane inside the slab window (identity without a window)
+	k = k < 0 ? 0 : (k > d.sz - 1 ? d.sz - 1 : k);
+	return flags[(int64_t)(int)x + d.Y * (int)y + d.Z * k];  // FlagGrid::getAt, grid.h:324
 }
 struct AdvArgs {
 	float dt;
@@ -455,7 +457,7 @@ k_advect_in_grid(Dim d, const int32_t* __restrict__ flags, const float* __restri
 				for (int c = 0; c < 3; c++) x[c] = x0[c];
 			} else {
 				if (!in_bounds_pos(d, x[0], x[1], x[2], 0)) {
-					const float hi[3] = {(float)d.sx - 1.f, (float)d.sy - 1.f, (float)d.sz - 1.f};
+					const float hi[3] = {(float)d.sx - 1.f, (float)d.sy - 1.f, (float)d.gsz - 1.f};
 					for (int c = 0; c < 3; c++) x[c] = x[c] < 0.f ? 0.f : (x[c] > hi[c] ? hi[c] : x[c]);
 				}
 				if (a.stopInObstacle && (flag_at(d, flags, x[0], x[1], x[2]) & MF_OBSTACLE)) {
@@ -489,9 +491,9 @@ k_advect_in_grid(Dim d, const int32_t* __restrict__ flags, const float* __restri
 
 extern "C" {
 
-int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight, int64_t np, int64_t ps,
-                        const float* pos, const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude,
-                        int deterministic, void* stream) {
+int mf_map_parts_to_mac_accum(int sx, int sy, int sz, float* vel, float* weight, int64_t np, int64_t ps, const float* pos,
+                              const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude, int deterministic,
+                              void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	hipStream_t st = (hipStream_t)stream;
@@ -508,9 +510,20 @@ int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float
 		else
 			hipLaunchKernelGGL(k_p2g_mac_atomic, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude);
 	}
-	hipLaunchKernelGGL(k_p2g_mac_finish, dim3(blocks_for(3 * d.n, BLOCK, 2048)), dim3(BLOCK), 0, st, 3 * d.n, vel, velOld, weight);
 	MF_LAUNCH_CHECK();
 	return 0;
+}
+int mf_map_parts_to_mac_finish(int64_t n3, float* vel, float* velOld, float* weight, void* stream) {
+	if (n3 <= 0) return 0;
+	hipLaunchKernelGGL(k_p2g_mac_finish, dim3(blocks_for(n3, BLOCK, 2048)), dim3(BLOCK), 0, (hipStream_t)stream, n3, vel, velOld, weight);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight, int64_t np, int64_t ps,
+                        const float* pos, const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude,
+                        int deterministic, void* stream) {
+	MF_TRY(mf_map_parts_to_mac_accum(sx, sy, sz, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude, deterministic, stream));
+	return mf_map_parts_to_mac_finish(3 * (int64_t)sx * sy * sz, vel, velOld, weight, stream);
 }
 int mf_apic_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* mass, int64_t np, int64_t ps, const float* pos,
                              const int32_t* pflag, const float* pvel, const float* cpx, const float* cpy, const float* cpz,

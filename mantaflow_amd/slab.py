@@ -307,6 +307,191 @@ def setWallBcs(dom, flags, vel):
 
 
 # =========================================================================================================
+# FLIP on slabs: particles live on the rank that owns the plane floor(z) of their cell, in GLOBAL coordinates
+# (mf_set_slab_window makes every interpolator / bounds test of the particle kernels work in global z).
+#   advectInGrid      : velocity ghosts to the advection ghost width, local RK step, then migration of the particles that left
+#                       the owned planes to the z-neighbour (one variable-size p2p message per side and direction)
+#   mapPartsToMAC     : local scatter (incl. one ghost plane per side) -> REVERSE halo: the ghost-plane sums of vel and weight
+#                       are added into the neighbour's boundary plane -> stomp / safeDivide / velOld copy
+#   mapMACToParts / flipVelocityUpdate : one-plane ghosts of vel (and velOld), then the local gather
+# =========================================================================================================
+def slab_ranges(NZ, P):
+    base, rem = divmod(NZ, P)
+    z0 = [r * base + min(r, rem) for r in range(P)]
+    return [(z0[r], z0[r] + base + (1 if r < rem else 0)) for r in range(P)]
+
+
+class SlabParticles(object):
+    """BasicParticleSystem of one slab + its pdata; every pdata created through `create` migrates with its particle"""
+
+    def __init__(self, dom):
+        self.dom = dom
+        self.pp = core.BasicParticleSystem(dom.solver)
+
+    def create(self, type):
+        return self.pp.create(type)
+
+    @property
+    def np(self): return self.pp.np
+
+    # ---- packing: a particle = 3 position floats + flag + the components of every pdata, as 4-byte columns -------------
+    def _columns(self):
+        pp = self.pp
+        cols = [pp.pos[c * pp.cap:c * pp.cap + pp.np] for c in range(3)] + [pp.flag[:pp.np].view(torch.float32)]
+        for pd in pp.pdata:
+            for c in range(pd._ncomp):
+                col = pd.data[c * pd.cap:c * pd.cap + pp.np]
+                cols.append(col if col.dtype == torch.float32 else col.view(torch.float32))
+        return cols
+
+    def _assign(self, packed):
+        """packed: [ncol][n] float32 (bit patterns)"""
+        pp = self.pp
+        n = packed.shape[1]
+        pp.resizeAll(n, cap=max(pp.cap, n + n // 8 + 16))
+        for c in range(3):
+            pp.pos[c * pp.cap:c * pp.cap + n] = packed[c]
+        pp.flag[:n] = packed[3].view(torch.int32)
+        q = 4
+        for pd in pp.pdata:
+            for c in range(pd._ncomp):
+                dst = pd.data[c * pd.cap:c * pd.cap + n]
+                dst.copy_(packed[q] if dst.dtype == torch.float32 else packed[q].view(dst.dtype))
+                q += 1
+
+    def scatter_global(self, pos, pflag, pdata=()):
+        """pos [3][n], pflag [n], pdata: list of (pdata object, array [ncomp][n] or [n]); keeps this rank's particles in order"""
+        dom = self.dom
+        k = np.floor(pos[2]).astype(np.int64)
+        lo = -(1 << 60) if dom.below is None else dom.z0
+        hi = (1 << 60) if dom.above is None else dom.z1
+        m = (k >= lo) & (k < hi)
+        self.pp.set_positions(np.ascontiguousarray(pos[:, m].T), pflag[m])
+        for pd, arr in pdata:
+            a = np.asarray(arr)
+            a = a[None] if a.ndim == 1 else a
+            for c in range(pd._ncomp):
+                pd.data[c * pd.cap:c * pd.cap + self.pp.np] = torch.from_numpy(np.ascontiguousarray(a[c][m])).to(pd.data.device)
+        return m
+
+    def gather(self):
+        """this rank's particles as numpy: pos [3][n], flag [n], one array per pdata"""
+        cols = [c.detach().cpu().numpy().copy() for c in self._columns()]
+        out = {"pos": np.stack(cols[:3]), "flag": cols[3].view(np.int32)}
+        q = 4
+        for i, pd in enumerate(self.pp.pdata):
+            a = np.stack(cols[q:q + pd._ncomp])
+            q += pd._ncomp
+            out["pdata%d" % i] = a if pd.data.dtype == torch.float32 else a.view(np.int32)
+        return out
+
+    def migrate(self):
+        """hand the particles whose cell plane is no longer owned to the z-neighbour; survivors keep their order, arrivals
+        are appended (from below first).  A particle may cross one slab face per step (checked)."""
+        dom, pp = self.dom, self.pp
+        if dom.comm.world == 1:
+            return 0
+        s = dom.solver
+        s.sync()
+        cols = self._columns()
+        packed = torch.stack(cols) if pp.np > 0 else torch.zeros((len(cols), 0), dtype=torch.float32, device=s.device)
+        k = torch.floor(packed[2]).to(torch.int64)
+        down = (k < dom.z0) if dom.below is not None else torch.zeros_like(k, dtype=torch.bool)
+        up = (k >= dom.z1) if dom.above is not None else torch.zeros_like(k, dtype=torch.bool)
+        ranges = slab_ranges(dom.NZ, dom.comm.world)
+        if bool(down.any()) and int(k[down].min()) < ranges[dom.comm.rank - 1][0] and dom.comm.rank - 1 > 0:
+            raise RuntimeError("slab FLIP: a particle crossed more than one slab in a step")
+        if bool(up.any()) and int(k[up].max()) >= ranges[dom.comm.rank + 1][1] and dom.comm.rank + 1 < dom.comm.world - 1:
+            raise RuntimeError("slab FLIP: a particle crossed more than one slab in a step")
+        send_dn, send_up, stay = packed[:, down].contiguous(), packed[:, up].contiguous(), packed[:, ~(down | up)]
+        # 1. counts
+        cnt = torch.tensor([send_dn.shape[1], send_up.shape[1]], dtype=torch.int64, device=s.device)
+        got = torch.zeros(2, dtype=torch.int64, device=s.device)
+        pairs = []
+        if dom.below is not None:
+            pairs.append((cnt[0:1], got[0:1], dom.below))
+        if dom.above is not None:
+            pairs.append((cnt[1:2], got[1:2], dom.above))
+        dom.comm.sendrecv(pairs)
+        # 2. payloads (only the non-empty ones; both sides know the counts)
+        ncol = packed.shape[0]
+        from_dn = torch.zeros((ncol, int(got[0])), dtype=torch.float32, device=s.device)
+        from_up = torch.zeros((ncol, int(got[1])), dtype=torch.float32, device=s.device)
+        pairs = []
+        if dom.below is not None and (send_dn.shape[1] or from_dn.shape[1]):
+            pairs.append((send_dn if send_dn.shape[1] else None, from_dn if from_dn.shape[1] else None, dom.below))
+        if dom.above is not None and (send_up.shape[1] or from_up.shape[1]):
+            pairs.append((send_up if send_up.shape[1] else None, from_up if from_up.shape[1] else None, dom.above))
+        dom.comm.sendrecv(pairs)
+        moved = send_dn.shape[1] + send_up.shape[1] + from_dn.shape[1] + from_up.shape[1]
+        if moved:
+            self._assign(torch.cat([stay, from_dn, from_up], dim=1))
+        return moved
+
+
+def reduce_ghosts(dom, grid, width=1):
+    """reverse halo: add my ghost-plane values into the neighbour's boundary planes (and receive theirs into mine)"""
+    if dom.comm.world == 1:
+        return
+    w = int(width)
+    top = dom.gl + dom.nown
+    pairs, adds = [], []
+    if dom.below is not None:
+        tmp = torch.empty_like(dom.planes(grid, dom.gl, dom.gl + w).contiguous())
+        pairs.append((dom.planes(grid, dom.gl - w, dom.gl), tmp, dom.below))
+        adds.append((dom.planes(grid, dom.gl, dom.gl + w), tmp))
+    if dom.above is not None:
+        tmp = torch.empty_like(dom.planes(grid, top - w, top).contiguous())
+        pairs.append((dom.planes(grid, top, top + w), tmp, dom.above))
+        adds.append((dom.planes(grid, top - w, top), tmp))
+    dom.solver.sync()
+    dom.comm.sendrecv(pairs)
+    for dst, tmp in adds:
+        dst.add_(tmp)
+
+
+def advectInGrid(dom, sp, flags, vel, integrationMode, deleteInObstacle=True, stopInObstacle=True, skipNew=False):
+    """ParticleSystem::advectInGrid on a slab (particle.h:526-550): ghosts of `vel` to the ghost width, local step, migration"""
+    s = dom.solver
+    if dom.comm.world > 1:
+        m = 0.0
+        for c in range(3):
+            m = max(m, dom.max_abs_owned(vel, comp=c))
+        reach = int(math.ceil(m * s.getDt())) + 2          # furthest sub-step position + trilinear/MAC-shift reach
+        if reach > dom.G:
+            raise RuntimeError("slab advectInGrid: max|v| dt = %.2f needs %d ghost planes, domain has %d" % (m * s.getDt(), reach, dom.G))
+    dom.exchange(vel)
+    sp.pp.advectInGrid(flags, vel, integrationMode, deleteInObstacle=deleteInObstacle, stopInObstacle=stopInObstacle, skipNew=skipNew)
+    return sp.migrate()
+
+
+def mapPartsToMAC(dom, flags, vel, velOld, sp, partVel, weight=None, deterministic=True):
+    """mapPartsToMAC (flip.cpp:637-661) on a slab: local scatter, reverse halo of the pre-division sums, then the division"""
+    s = dom.solver
+    w = weight if weight is not None else core.VecGrid(s)
+    pp = sp.pp
+    s.lib.call("mf_map_parts_to_mac_accum", dom.NX, dom.NY, dom.LZ, vel.ptr, w.ptr, pp.np, pp.cap, _ptr(pp.pos), _ptr(pp.flag),
+               partVel.ptr, None, 0, int(deterministic), s.stream)
+    reduce_ghosts(dom, vel, 1)
+    reduce_ghosts(dom, w, 1)
+    s.lib.call("mf_map_parts_to_mac_finish", 3 * vel.n, vel.ptr, velOld.ptr, w.ptr, s.stream)
+
+
+def mapMACToParts(dom, flags, vel, sp, partVel):
+    s, pp = dom.solver, sp.pp
+    dom.exchange(vel, 1)
+    s.lib.call("mf_map_mac_to_parts", dom.NX, dom.NY, dom.LZ, vel.ptr, pp.np, pp.cap, _ptr(pp.pos), _ptr(pp.flag), partVel.ptr, None, 0, s.stream)
+
+
+def flipVelocityUpdate(dom, flags, vel, velOld, sp, partVel, flipRatio):
+    s, pp = dom.solver, sp.pp
+    dom.exchange(vel, 1)
+    dom.exchange(velOld, 1)
+    s.lib.call("mf_flip_velocity_update", dom.NX, dom.NY, dom.LZ, vel.ptr, velOld.ptr, pp.np, pp.cap, _ptr(pp.pos), _ptr(pp.flag),
+               partVel.ptr, float(flipRatio), None, 0, s.stream)
+
+
+# =========================================================================================================
 # bench.py --gpus N>1
 # =========================================================================================================
 def global_flags(n):

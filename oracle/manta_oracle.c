@@ -1231,10 +1231,10 @@ static inline void scatter8(float* ref, float* sum, int64_t Y, int64_t Z, float 
 		ref[Z] += wz * val; ref[X + Z] += wxz * val; ref[Y + Z] += wyz * val; ref[X + Y + Z] += wxyz * val;
 	}
 }
-/* mapPartsToMAC, flip.cpp:637-661 */
-int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight, int64_t np, int64_t ps,
-                        const float* pos, const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude,
-                        int deterministic, void* st) {
+/* mapPartsToMAC, flip.cpp:637-661, in two halves (the slab decomposition adds ghost-plane sums in between) */
+int mf_map_parts_to_mac_accum(int sx, int sy, int sz, float* vel, float* weight, int64_t np, int64_t ps, const float* pos,
+                              const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude, int deterministic,
+                              void* st) {
 	(void)st;
 	(void)deterministic;
 	Dim d = mkdim(sx, sy, sz);
@@ -1252,10 +1252,19 @@ int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float
 		int64_t iz = ((int64_t)s.zi * sy + b.yi) * sx + b.xi;
 		scatter8(vel + 2 * n + iz, weight + 2 * n + iz, d.Y, d.Z, b.t0, b.t1, b.s0, b.s1, s.f0, s.f1, pvel[2 * ps + p], 0);
 	}
-	mf_grid_stomp(3 * n, weight, 1e-6f, st);       /* weight->stomp(Vec3(VECTOR_EPSILON)) */
-	mf_grid_safe_divide(3 * n, vel, weight, st);   /* vel.safeDivide(*weight) */
-	memcpy(velOld, vel, sizeof(float) * 3 * n);    /* velOld.copyFrom(vel) */
 	return 0;
+}
+int mf_map_parts_to_mac_finish(int64_t n3, float* vel, float* velOld, float* weight, void* st) {
+	mf_grid_stomp(n3, weight, 1e-6f, st);       /* weight->stomp(Vec3(VECTOR_EPSILON)) */
+	mf_grid_safe_divide(n3, vel, weight, st);   /* vel.safeDivide(*weight) */
+	if (velOld) memcpy(velOld, vel, sizeof(float) * n3); /* velOld.copyFrom(vel) */
+	return 0;
+}
+int mf_map_parts_to_mac(int sx, int sy, int sz, float* vel, float* velOld, float* weight, int64_t np, int64_t ps,
+                        const float* pos, const int32_t* pflag, const float* pvel, const int32_t* ptype, int exclude,
+                        int deterministic, void* st) {
+	mf_map_parts_to_mac_accum(sx, sy, sz, vel, weight, np, ps, pos, pflag, pvel, ptype, exclude, deterministic, st);
+	return mf_map_parts_to_mac_finish(3 * (int64_t)sx * sy * sz, vel, velOld, weight, st);
 }
 /* mapMACToParts, flip.cpp:709-721 */
 int mf_map_mac_to_parts(int sx, int sy, int sz, const float* vel, int64_t np, int64_t ps, const float* pos,
@@ -1467,13 +1476,15 @@ static inline int in_bounds_pos(const Dim* d, float x, float y, float z, int bnd
 	int i = (int)x, j = (int)y, k = (int)z;
 	int r = i >= bnd && j >= bnd && i < d->sx - bnd && j < d->sy - bnd;
 	if (d->is3d)
-		r &= (k >= bnd && k < d->sz - bnd);
+		r &= (k >= bnd && k < d->gsz - bnd); /* positions are global coordinates: the z extent is the whole domain's */
 	else
 		r &= (k == 0);
 	return r;
 }
 static inline int flag_at(const Dim* d, const int32_t* flags, float x, float y, float z) { /* FlagGrid::getAt, grid.h:324 */
-	return flags[IDX(*d, (int)x, (int)y, (int)z)];
+	int k = (int)z - d->zoff; /* plane inside the slab window (identity without a window) */
+	k = k < 0 ? 0 : (k > d->sz - 1 ? d->sz - 1 : k);
+	return flags[IDX(*d, (int)x, (int)y, k)];
 }
 /* GridAdvectKernel, particle.h:458-481 */
 static void grid_advect_kernel(const Dim* d, const int32_t* flags, const float* vel, int64_t np, int64_t ps,
@@ -1553,7 +1564,7 @@ int mf_advect_in_grid(int sx, int sy, int sz, const int32_t* flags, const float*
 #undef RUN
 	if (!deleteInObstacle) {
 		/* KnClampPositions, particle.h:507-523 */
-		const float hi[3] = {(float)sx - 1.f, (float)sy - 1.f, (float)sz - 1.f};
+		const float hi[3] = {(float)sx - 1.f, (float)sy - 1.f, (float)d.gsz - 1.f};
 #pragma omp parallel for
 		for (int64_t p = 0; p < np; p++) {
 			if (pflag[p] & MF_PDELETE) continue;

@@ -14,6 +14,38 @@ import util  # noqa: E402
 from mantaflow_amd import _lib  # noqa: E402
 
 
+def flip_case(out, dims):
+    """S-flip step on slabs: advectInGrid(RK4) + migration, mapPartsToMAC with the reverse halo, solvePressure,
+    flipVelocityUpdate.  Particles carry their global index (pid) so that the ranks' results can be put back in order."""
+    from mantaflow_amd import core, slab
+    NX, NY, NZ = dims
+    dom = slab.SlabDomain((NX, NY, NZ), slab.required_ghost(2.0))
+    s = dom.solver
+    s.timestep = 0.8
+    flags_g = util.make_flags(NX, NY, NZ, 61, obstacles=True, empty_top=True)
+    vel_g = util.smooth_vel(NX, NY, NZ, 62, 2.2)
+    pos, pflag, pvel = util.make_particles(flags_g, 2, 63, include_border=False)
+    pid = np.arange(pos.shape[1], dtype=np.int32)
+    flags, vel, velOld, pres, w = core.FlagGrid(s), core.MACGrid(s), core.MACGrid(s), core.Grid(s), core.VecGrid(s)
+    dom.scatter_global(flags, flags_g); dom.scatter_global(vel, vel_g)
+    sp = slab.SlabParticles(dom)
+    pv, pi = sp.create(core.PdataVec3), sp.create(core.PdataInt)
+    sp.scatter_global(pos, pflag, [(pv, pvel), (pi, pid)])
+    n0 = sp.np
+    moved = slab.advectInGrid(dom, sp, flags, vel, 2, deleteInObstacle=False)
+    adv = sp.gather()
+    slab.mapPartsToMAC(dom, flags, vel, velOld, sp, pv, w)
+    p2g_vel, p2g_w = dom.gather_owned(vel).copy(), dom.gather_owned(w).copy()
+    dom.exchange(vel, 1)
+    slab.setWallBcs(dom, flags, vel)
+    st = {}
+    slab.solvePressure(dom, vel, pres, flags, cgAccuracy=1e-5, stats=st)
+    slab.flipVelocityUpdate(dom, flags, vel, velOld, sp, pv, 0.97)
+    fin = sp.gather()
+    np.savez(out + ".%d.npz" % dom.comm.rank, n0=n0, moved=moved, adv_pos=adv["pos"], adv_flag=adv["flag"], adv_pid=adv["pdata1"][0],
+             p2g_vel=p2g_vel, p2g_w=p2g_w, pid=fin["pdata1"][0], pvel=fin["pdata0"], iters=st["iterations"])
+
+
 def main():
     out, backend = sys.argv[1], sys.argv[2]
     dims = tuple(int(v) for v in sys.argv[3].split("x"))
@@ -25,6 +57,12 @@ def main():
     else:
         torch.cuda.set_device(0)
         _lib.get()
+    if len(sys.argv) > 4 and sys.argv[4] == "flip":
+        flip_case(out, dims)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from mantaflow_amd import core, slab
     NX, NY, NZ = dims
     dom = slab.SlabDomain((NX, NY, NZ), slab.required_ghost(2.0))

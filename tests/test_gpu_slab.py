@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import util
-from test_slab_gloo import check_against_single, run_world
+from test_slab_gloo import check_against_single, check_flip_against_single, run_flip_world, run_world
 
 pytestmark = pytest.mark.gpu
 
@@ -19,3 +19,16 @@ def test_slab_two_ranks_on_hip(tmp_path):
     util.assert_bitexact(single["vel_adv"], ora["vel_adv"], "velocity hip vs oracle")
     assert single["iters"] == ora["iters"]
     assert util.rel_err(single["pres"], ora["pres"]) < 1e-5
+
+
+def test_flip_slab_two_ranks_on_hip(tmp_path):
+    """FLIP on slabs through the HIP library: migration + reverse halo with 2 ranks on the one GPU; the single-rank HIP run
+    equals the oracle's single-rank run bit for bit (positions, P2G sums)"""
+    single = run_flip_world(tmp_path, 1, "hip", dims="32x24x40")
+    multi = run_flip_world(tmp_path, 2, "hip", dims="32x24x40")
+    check_flip_against_single(single, multi)
+    ora = run_flip_world(tmp_path, 1, "oracle", dims="32x24x40")
+    util.assert_bitexact(single["adv_pos"], ora["adv_pos"], "advected positions hip vs oracle")
+    util.assert_bitexact(single["p2g_vel"], ora["p2g_vel"], "P2G velocity hip vs oracle")
+    util.assert_bitexact(single["p2g_w"], ora["p2g_w"], "P2G weight hip vs oracle")
+    assert single["iters"] == ora["iters"]
