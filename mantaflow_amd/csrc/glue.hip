@@ -191,7 +191,8 @@ k_mark_fluid(Dim d, int32_t* __restrict__ flags, int64_t np, int64_t ps, const f
 	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
 	if (p >= np) return;
 	if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) return;
-	const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];   // toVec3i truncation
+	const int i = (int)pos[p], j = (int)pos[ps + p];   // toVec3i truncation
+	const int k = (int)pos[2 * ps + p] - d.zoff;       // plane inside the slab window (global coordinates; identity without one)
 	if (i < 0 || j < 0 || k < 0 || i >= d.sx || j >= d.sy || k >= d.sz) return;
 	const int64_t idx = (int64_t)i + d.Y * j + d.Z * k;
 	const int f = flags[idx];

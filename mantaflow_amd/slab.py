@@ -120,6 +120,7 @@ class SlabDomain(object):
         self.LZ = self.hi - self.lo
         self.XY = self.NX * self.NY
         self.solver = core.Solver(gridSize=core.vec3(self.NX, self.NY, self.LZ), dim=3)
+        self.solver._global_max = max(self.NX, self.NY, self.NZ)       # getDx() of the undivided domain (gravity / buoyancy scaling)
         # positions handed to the interpolators are global coordinates -> bit-identical to the undivided domain
         self.solver.lib.call("mf_set_slab_window", self.lo, self.NZ)
         self.below = r - 1 if r > 0 else None
@@ -475,6 +476,41 @@ def mapPartsToMAC(dom, flags, vel, velOld, sp, partVel, weight=None, determinist
     reduce_ghosts(dom, vel, 1)
     reduce_ghosts(dom, w, 1)
     s.lib.call("mf_map_parts_to_mac_finish", 3 * vel.n, vel.ptr, velOld.ptr, w.ptr, s.stream)
+
+
+def markFluidCells(dom, sp, flags):
+    """markFluidCells (flip.cpp:166-188) on a slab: every rank marks the cells of its own particles, ghost flags come from
+    their owners"""
+    from . import plugins
+    plugins.markFluidCells(sp.pp, flags)
+    dom.exchange(flags)
+
+
+def _need_ghost(dom, passes, what):
+    if dom.comm.world > 1 and passes + 1 > dom.G:
+        raise RuntimeError("slab %s: %d passes need %d ghost planes, domain has %d" % (what, passes, passes + 1, dom.G))
+
+
+def extrapolateMACFromWeight(dom, vel, weight, distance=2):
+    """fastmarch.cpp:415-430: `distance` one-cell passes -> run on ghosts `distance`+1 deep, the owned planes come out exact"""
+    from . import plugins
+    _need_ghost(dom, distance, "extrapolateMACFromWeight")
+    dom.exchange(vel)
+    dom.exchange(weight)
+    plugins.extrapolateMACFromWeight(vel, weight, distance)
+
+
+def extrapolateMACSimple(dom, flags, vel, distance=4):
+    """fastmarch.cpp:337-376, same argument"""
+    from . import plugins
+    _need_ghost(dom, distance, "extrapolateMACSimple")
+    dom.exchange(vel)
+    plugins.extrapolateMACSimple(flags, vel, distance)
+
+
+def addGravity(dom, flags, vel, gravity):
+    from . import plugins
+    plugins.addGravity(flags, vel, gravity)
 
 
 def mapMACToParts(dom, flags, vel, sp, partVel):

@@ -1815,7 +1815,7 @@ int mf_mark_fluid_cells(int sx, int sy, int sz, int32_t* flags, int64_t np, int6
 		if (flags[idx] & MF_FLUID) flags[idx] = (flags[idx] | MF_EMPTY) & ~MF_FLUID;
 	for (int64_t p = 0; p < np; p++) {
 		if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) continue;
-		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p] - d.zoff; /* plane inside the slab window */
 		if (!in_bounds(&d, i, j, k)) continue;
 		int64_t idx = IDX(d, i, j, k);
 		if (flags[idx] & MF_EMPTY) flags[idx] = (flags[idx] | MF_FLUID) & ~MF_EMPTY;

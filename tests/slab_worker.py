@@ -46,6 +46,51 @@ def flip_case(out, dims):
              p2g_vel=p2g_vel, p2g_w=p2g_w, pid=fin["pdata1"][0], pvel=fin["pdata0"], iters=st["iterations"])
 
 
+def liquid_case(out, dims):
+    """two steps of the flip01_simple.py loop on slabs: advectInGrid, mapPartsToMAC, extrapolateMACFromWeight, markFluidCells,
+    addGravity, setWallBcs, solvePressure, extrapolateMACSimple, flipVelocityUpdate"""
+    from mantaflow_amd import core, slab
+    NX, NY, NZ = dims
+    dom = slab.SlabDomain((NX, NY, NZ), slab.required_ghost(2.0))
+    s = dom.solver
+    s.timestep = 0.8
+    flags_g = np.full((NZ, NY, NX), 4, np.int32)                    # empty box with a 1-cell wall
+    flags_g[:, :, 0] = flags_g[:, :, -1] = flags_g[:, 0, :] = flags_g[:, -1, :] = 2
+    flags_g[0] = flags_g[-1] = 2
+    fluid = np.zeros_like(flags_g, bool)
+    fluid[1:NZ - 1, 1:int(0.6 * NY), 1:int(0.5 * NX)] = True        # a liquid block spanning every slab
+    flags_g[fluid] = 1
+    pos, pflag, pvel = util.make_particles(flags_g, 2, 73, vel_scale=0.6, deleted_frac=0.0, include_border=False)
+    pid = np.arange(pos.shape[1], dtype=np.int32)
+    flags, vel, velOld, pres, w = core.FlagGrid(s), core.MACGrid(s), core.MACGrid(s), core.Grid(s), core.VecGrid(s)
+    dom.scatter_global(flags, flags_g)
+    sp = slab.SlabParticles(dom)
+    pv, pi = sp.create(core.PdataVec3), sp.create(core.PdataInt)
+    sp.scatter_global(pos, pflag, [(pv, pvel), (pi, pid)])
+    rec, moved, iters = {}, 0, []
+    for step in range(2):
+        moved += slab.advectInGrid(dom, sp, flags, vel, 2, deleteInObstacle=False)
+        slab.mapPartsToMAC(dom, flags, vel, velOld, sp, pv, w)
+        slab.extrapolateMACFromWeight(dom, vel, w, distance=2)
+        slab.markFluidCells(dom, sp, flags)
+        if step == 0:
+            rec["flags0"], rec["vel_ext0"] = dom.gather_owned(flags).copy(), dom.gather_owned(vel).copy()
+        slab.addGravity(dom, flags, vel, core.vec3(0, -0.01, 0))
+        dom.exchange(vel, 1)
+        slab.setWallBcs(dom, flags, vel)
+        st = {}
+        slab.solvePressure(dom, vel, pres, flags, cgAccuracy=1e-6, stats=st)
+        iters.append(st["iterations"])
+        dom.exchange(vel, 1)
+        slab.setWallBcs(dom, flags, vel)
+        slab.extrapolateMACSimple(dom, flags, vel, distance=4)
+        slab.flipVelocityUpdate(dom, flags, vel, velOld, sp, pv, 0.97)
+        s.step()
+    fin = sp.gather()
+    np.savez(out + ".%d.npz" % dom.comm.rank, moved=moved, pid=fin["pdata1"][0], pos=fin["pos"], pvel=fin["pdata0"], flags=dom.gather_owned(flags),
+             vel=dom.gather_owned(vel), iters=np.array(iters), **rec)
+
+
 def main():
     out, backend = sys.argv[1], sys.argv[2]
     dims = tuple(int(v) for v in sys.argv[3].split("x"))
@@ -57,8 +102,8 @@ def main():
     else:
         torch.cuda.set_device(0)
         _lib.get()
-    if len(sys.argv) > 4 and sys.argv[4] == "flip":
-        flip_case(out, dims)
+    if len(sys.argv) > 4 and sys.argv[4] in ("flip", "liquid"):
+        (flip_case if sys.argv[4] == "flip" else liquid_case)(out, dims)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -80,16 +80,20 @@ def test_slab_world(tmp_path, single, world):
 
 
 # ---- FLIP on slabs (P2G with reverse halo, G2P / advectInGrid with particle migration) ------------------------
-def run_flip_world(tmp_path, world, backend="oracle", dims="20x16x36"):
-    out = str(tmp_path / ("f%d" % world))
+def _run_case(tmp_path, world, backend, dims, case):
+    out = str(tmp_path / ("%s%d%s" % (case, world, backend)))
     env = dict(os.environ, OMP_NUM_THREADS="2")
     if world == 1:
-        cmd = [sys.executable, WORKER, out, backend, dims, "flip"]
+        cmd = [sys.executable, WORKER, out, backend, dims, case]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port()), WORKER, out, backend, dims, "flip"]
+               "--master-port", str(_free_port()), WORKER, out, backend, dims, case]
     subprocess.run(cmd, check=True, env=env, timeout=600)
-    parts = [dict(np.load(out + ".%d.npz" % r)) for r in range(world)]
+    return [dict(np.load(out + ".%d.npz" % r)) for r in range(world)]
+
+
+def run_flip_world(tmp_path, world, backend="oracle", dims="20x16x36"):
+    parts = _run_case(tmp_path, world, backend, dims, "flip")
     o = np.argsort(np.concatenate([p["adv_pid"] for p in parts]), kind="stable")
     o2 = np.argsort(np.concatenate([p["pid"] for p in parts]), kind="stable")
     return dict(adv_pos=np.concatenate([p["adv_pos"] for p in parts], axis=1)[:, o], adv_flag=np.concatenate([p["adv_flag"] for p in parts])[o],
@@ -146,3 +150,73 @@ def check_flip_against_single(flip_single, m):
 @pytest.mark.parametrize("world", [2, 3])
 def test_flip_slab_world(tmp_path, flip_single, world):
     check_flip_against_single(flip_single, run_flip_world(tmp_path, world))
+
+
+# ---- the whole flip01_simple.py loop on slabs ---------------------------------------------------------------------------
+def run_liquid_world(tmp_path, world, backend="oracle", dims="20x16x36"):
+    parts = _run_case(tmp_path, world, backend, dims, "liquid")
+    o = np.argsort(np.concatenate([p["pid"] for p in parts]), kind="stable")
+    cat = lambda k, ax: np.concatenate([p[k] for p in parts], axis=ax)
+    return dict(pid=cat("pid", 0)[o], pos=cat("pos", 1)[:, o], pvel=cat("pvel", 1)[:, o], flags=cat("flags", 0), flags0=cat("flags0", 0),
+                vel=cat("vel", 1), vel_ext0=cat("vel_ext0", 1), moved=sum(int(p["moved"]) for p in parts), iters=[list(p["iters"]) for p in parts])
+
+
+def check_liquid_against_single(one, m):
+    assert (m["pid"] == one["pid"]).all() and m["moved"] > 0
+    # step 1 up to the solve: flags from particles are bit-exact, extrapolated P2G velocity within the P2G tolerance
+    assert (m["flags0"] == one["flags0"]).all()
+    assert util.rel_err(m["vel_ext0"], one["vel_ext0"]) <= 1e-5
+    # after two steps (two block-Jacobi-preconditioned solves to 1e-6): converged-solution level
+    assert all(it == m["iters"][0] for it in m["iters"])
+    assert (m["flags"] != one["flags"]).mean() < 2e-3
+    scale = max(np.abs(one["pvel"]).max(), 1.0)
+    assert np.abs(m["pvel"] - one["pvel"]).max() < 5e-3 * scale
+    assert np.abs(m["pos"] - one["pos"]).max() < 5e-3
+    assert np.abs(m["vel"] - one["vel"]).max() < 5e-3 * max(np.abs(one["vel"]).max(), 1.0)
+
+
+@pytest.fixture(scope="module")
+def liquid_single(tmp_path_factory):
+    return run_liquid_world(tmp_path_factory.mktemp("liq1"), 1)
+
+
+def test_liquid_single_rank_slab_equals_plugin_path(liquid_single, oracle_backend):
+    """world 1: two steps of the flip01 loop through the slab operators = the same loop through the plugins, bit for bit"""
+    import cases
+    from mantaflow_amd import core, plugins
+    dims = (20, 16, 36)
+    NX, NY, NZ = dims
+    s = cases._mk_solver(dims, 0.8)
+    flags_g = np.full((NZ, NY, NX), 4, np.int32)
+    flags_g[:, :, 0] = flags_g[:, :, -1] = flags_g[:, 0, :] = flags_g[:, -1, :] = 2
+    flags_g[0] = flags_g[-1] = 2
+    fluid = np.zeros_like(flags_g, bool)
+    fluid[1:NZ - 1, 1:int(0.6 * NY), 1:int(0.5 * NX)] = True
+    flags_g[fluid] = 1
+    pos, pflag, pvel = util.make_particles(flags_g, 2, 73, vel_scale=0.6, deleted_frac=0.0, include_border=False)
+    fl, v, vo, w, pr = core.FlagGrid(s), core.MACGrid(s), core.MACGrid(s), core.VecGrid(s), core.Grid(s)
+    cases.soa_to_grid(fl, flags_g)
+    pp = cases._mk_parts(s, pos, pflag)
+    pv = cases._pd_vec3(s, pp, pvel)
+    for step in range(2):
+        pp.advectInGrid(fl, v, 2, deleteInObstacle=False)
+        plugins.mapPartsToMAC(fl, v, vo, pp, pv, w)
+        plugins.extrapolateMACFromWeight(v, w, distance=2)
+        plugins.markFluidCells(pp, fl)
+        plugins.addGravity(fl, v, core.vec3(0, -0.01, 0))
+        plugins.setWallBcs(fl, v)
+        plugins.solvePressure(v, pr, fl, cgAccuracy=1e-6)
+        plugins.setWallBcs(fl, v)
+        plugins.extrapolateMACSimple(fl, v, distance=4)
+        plugins.flipVelocityUpdate(fl, v, vo, pp, pv, 0.97)
+        s.step()
+    P, F = cases._parts_get(pp)
+    util.assert_bitexact(liquid_single["pos"], P, "positions after two steps")
+    assert (liquid_single["flags"] == cases.grid_to_soa(fl)).all()
+    assert util.rel_err(liquid_single["vel"], cases.grid_to_soa(v)) <= 1e-5
+    assert util.rel_err(liquid_single["pvel"], cases._pd_get(pv, pp.np)) <= 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_liquid_slab_world(tmp_path, liquid_single, world):
+    check_liquid_against_single(liquid_single, run_liquid_world(tmp_path, world))
