@@ -529,8 +529,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-           const CgScalars* __restrict__ sc, long long* trace, int trace_ticket, int trace_ticket2) {
+           const CgScalars* __restrict__ sc, double* __restrict__ dotpart, long long* trace, int trace_ticket, int trace_ticket2) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
+	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
+	// write-back wave, one partial per bundle at dotpart[tkl * nbj + tjl] -- the sum the PCG needs right after this sweep
+	const bool with_dot = (MODE == 2) && dotpart != nullptr;
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
@@ -540,6 +543,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	else __builtin_amdgcn_s_setprio(0);
 	__shared__ float4 sA[32 * 64];   // {fluid ? rhs : dst  (-> result), Ai, Aj, Ak}     index = ((h + 2) & 31) * 64 + lane
 	__shared__ float2 sB[32 * 64];   // {Aprecond, fluid}
+	__shared__ float sR[MODE == 2 ? 32 * 64 : 1];   // with_dot: var1 of the cell
 	__shared__ __attribute__((aligned(16))) float sFj[2][8][8];
 	__shared__ __attribute__((aligned(16))) float sFk[2][8][8];   // face values of a block [block parity][face lane][step]
 	__shared__ int s_ready[3], s_done, s_flushed, s_faces, s_ticket;
@@ -654,7 +658,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					int nv;
 					chunk_geom(m, rowidx, nv);
 					load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
-					if (MODE == 1) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
+					if (MODE == 1 || with_dot) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
 					load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
 					load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
 					load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
@@ -673,6 +677,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						const int idx = ((p0 + a) & 31) * 64 + lane;
 						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], r.Ai[a], r.Aj[a], r.Ak[a]);
 						sB[idx] = make_float2(r.P[a], fl ? 1.f : 0.f);
+						if (MODE == 2 && with_dot) sR[idx] = r.V[a];     // 0 outside the grid (load_row8)
 					}
 				};
 				// one chunk in flight per loader wave: its loads are issued as soon as the previous chunk of this wave is
@@ -688,6 +693,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					__hip_atomic_store(&s_ready[w], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 			} else {
+				double dacc = 0.0;
 #pragma unroll 1
 				for (int q = 0; q < nchunks; q++) {
 					wait_for(&s_done, q + 3);   // chunk q is complete once block q+2 is finished
@@ -697,7 +703,12 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					const int p0 = 8 * q + skew + 2;
 					float w[8];
 #pragma unroll
-					for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sA[((p0 + e) & 31) * 64 + lane].x;
+					for (int e = 0; e < 8; e++) {
+						const int slot = ((p0 + e) & 31) * 64 + lane;
+						const float res = sA[slot].x;
+						w[REV ? 7 - e : e] = res;
+						if (MODE == 2 && with_dot) dacc += (double)(res * sR[slot]);
+					}
 					__hip_atomic_store(&s_flushed, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 					if (VEC) {
 						if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
@@ -707,6 +718,12 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						for (int e = 0; e < 8; e++)
 							if (e < nv) dst[rowidx + e] = w[e];
 					}
+				}
+				if (MODE == 2 && with_dot) {
+					// fixed butterfly over the 64 rows of the bundle: the same bits on every run
+#pragma unroll
+					for (int o = 32; o >= 1; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
+					if (lane == 0) dotpart[(int64_t)tkl * nbj + tjl] = dacc;
 				}
 			}
 		} else {
@@ -1020,6 +1037,9 @@ static int mic_mode_() {
 	return g_mic_mode;
 }
 
+// set by mic_launch_dot for the duration of one backward-sweep launch
+static thread_local double* g_dot_request = nullptr;
+static thread_local int g_dot_count = 0;
 template <int MODE>
 static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                       const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
@@ -1060,10 +1080,12 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 12 * 4096));
 				}
 			}
+			double* dotp = (MODE == 2 && al16(var1) && f->nblocks <= MAX_BLOCKS) ? g_dot_request : nullptr;
+			g_dot_count = dotp ? f->nblocks : 0;
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, trace, trace_ticket, trace_ticket2);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, trace, trace_ticket, trace_ticket2);
 			MF_LAUNCH_CHECK();
 			if (trace) {
 				static int printed = 0;
@@ -1150,6 +1172,18 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 	if (mode == 0) return launch_mic<0>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
 	if (mode == 1) return launch_mic<1>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
 	return launch_mic<2>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
+}
+// backward sweep with GridDotProduct(dst, var1) fused: *ndot = number of partials written to dotpart (0: not fused in
+// this mode -- the caller runs its own dot kernel)
+int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st) {
+	static const bool off = getenv("MF_MIC_NODOT") != nullptr;
+	g_dot_request = off ? nullptr : dotpart;
+	g_dot_count = 0;
+	const int rc = launch_mic<2>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
+	g_dot_request = nullptr;
+	*ndot = g_dot_count;
+	return rc;
 }
 int mic_flow_error() {
 	if (mic_mode_() < 1) return 0;

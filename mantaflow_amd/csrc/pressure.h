@@ -14,6 +14,10 @@ namespace mf {
 // of ApplyPreconditionModifiedIncompCholesky2.  sc (nullable): skip when sc->done.
 int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st);
+// backward substitution with GridDotProduct(dst, var1) fused into the sweep ("rows" mode): *ndot partials in dotpart, summed in
+// index order by the caller; *ndot == 0 when the active mode cannot fuse it (the caller then runs its own dot kernel)
+int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st);
 int mic_mode();          // 0 levels, 1 tiles, 2 rows
 int mic_flow_error();    // reads (and clears) the deadlock-guard flag of the single-launch sweeps; needs a synchronised stream
 }  // namespace mf

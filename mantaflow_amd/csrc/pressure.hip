@@ -890,18 +890,22 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	while (issued < maxIter) {
 		const int todo = (maxIter - issued < batch) ? (maxIter - issued) : batch;
 		for (int it = 0; it < todo; it++) {
-			int nba = 0;
+			int nba = 0, nsig = 0;
 			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
 				hipLaunchKernelGGL((k_cg_axpy2<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
-				MF_TRY(mic_launch(2, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
+				// sigma_new = dot(tmp, residual) comes out of the backward sweep's write-back (one partial per row bundle)
+				MF_TRY(mic_launch_dot(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, p_sig, &nsig, st));
 			} else {
 				hipLaunchKernelGGL((k_cg_axpy2<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
 			}
-			hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
-			hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nbs, p_sig);
+			if (nsig == 0) {
+				hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
+				nsig = nbs;
+			}
+			hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
 			hipLaunchKernelGGL(k_cg_update_search, dim3(nbs), dim3(BLOCK), 0, st, n, sc, search, tmp);
 			hipLaunchKernelGGL(k_cg_latch_diverged, dim3(1), dim3(1), 0, st, sc);
 		}
