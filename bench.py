@@ -219,11 +219,18 @@ def main():
         torch.cuda.synchronize()
         mic_us = e0.elapsed_time(e1) * 1e3 / 50
         mic_bytes = 60 * n ** 3
+        mic_traffic = None
+        tp = os.path.join(ROOT, "profiles", "mic_traffic.json")
+        if os.path.exists(tp) and n == GRID:
+            try:
+                mic_traffic = json.load(open(tp)).get("hbm_bytes_per_apply")     # PMC counters, see profiles/README.md
+            except Exception:
+                mic_traffic = None
         result["roofline_mic"] = {"kernel": "k_mic_rows<1> + k_mic_rows<2> (ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159)",
                                   "bound": "dependency chain (serial sweep in the reference), hbm if it were free",
                                   "achieved": round(mic_bytes / (mic_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(mic_bytes / (mic_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_apply_us": round(mic_us, 1),
-                                  "algorithmic_bytes_per_apply": mic_bytes}
+                                  "algorithmic_bytes_per_apply": mic_bytes, "traffic": mic_traffic}
         del A0, Ai, Aj, Ak, src, dst, ap
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline((n, n, max(16, n // 4)), v_np, d_np, None, dt)
