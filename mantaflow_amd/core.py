@@ -120,10 +120,13 @@ class PbClass(object):
     def getParent(self): return self.parent
     def setName(self, n): self.name = n
     def getName(self): return self.name
+    # introspection attributes of every wrapped object (registry.cpp:123-133, 320-326): C class name without / with template
     @property
-    def _class(self): return type(self)._cname_py
+    def _class(self): return type(self)._cname_cpp
     @property
-    def _cname(self): return type(self)._cname_cpp
+    def _cname(self):
+        t = getattr(type(self), "_T", "")
+        return type(self)._cname_cpp + ("<%s>" % t if t else "")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -443,6 +446,10 @@ class IntGrid(GridBase):
     def getMax(self): self._sync(); return float(self.data.max().item())
     def getMaxAbs(self): return max(abs(self.getMin()), abs(self.getMax()))
     def sub(self, a): self._check_same(a); self._sync(); self.data.sub_(a.data)
+    def add(self, a): self._check_same(a); self._sync(); self.data.add_(a.data)
+    def addConst(self, v): self._sync(); self.data.add_(int(v))
+    def multConst(self, v): self._sync(); self.data.mul_(int(v))
+    def addScaled(self, a, f): self._check_same(a); self._sync(); self.data.add_(a.data * int(f))
 
 
 class VecGrid(GridBase):
@@ -464,6 +471,13 @@ class VecGrid(GridBase):
         v = _to_vec3(v)
         for c, x in enumerate((v.x, v.y, v.z)):
             self._call("mf_grid_add_const", self.n, _ptr(self.data[c * self.n:]), float(x), self.parent.stream)
+
+    def addScaled(self, a, f):
+        """Grid<Vec3>::addScaled(a, Vec3 factor): me += a * factor, component-wise (grid.cpp:283-285)"""
+        self._check_same(a)
+        f = _to_vec3(f)
+        for c, x in enumerate((f.x, f.y, f.z)):
+            self._call("mf_grid_scaled_add", self.n, _ptr(self.data[c * self.n:]), _ptr(a.data[c * a.n:]), float(x), self.parent.stream)
 
     def add(self, a): self._check_same(a); self._call("mf_grid_add", 3 * self.n, self.ptr, a.ptr, self.parent.stream)
     def sub(self, a): self._check_same(a); self._call("mf_grid_sub", 3 * self.n, self.ptr, a.ptr, self.parent.stream)

@@ -307,6 +307,22 @@ def flipVelocityUpdate(flags, vel, velOld, parts, partVel, flipRatio, ptype=None
 
 
 @plugin
+def getComponent(source, target, component):
+    """grid.cpp:743-746: target = source[component] (a plane copy in the SoA layout)"""
+    _chk(source, VecGrid, "Grid<Vec3>"); _chk(target, Grid, "Grid<Real>")
+    s = source.parent
+    s.lib.call("mf_copy_f32", target.n, target.ptr, _ptr(source.data[int(component) * source.n:]), s.stream)
+
+
+@plugin
+def setComponent(source, target, component):
+    """grid.cpp:748-751: target[component] = source"""
+    _chk(source, Grid, "Grid<Real>"); _chk(target, VecGrid, "Grid<Vec3>")
+    s = source.parent
+    s.lib.call("mf_copy_f32", source.n, _ptr(target.data[int(component) * target.n:]), source.ptr, s.stream)
+
+
+@plugin
 def resetOutflow(flags, phi=None, parts=None, real=None, index=None, indexSys=None):
     """extforces.cpp:134-161 (index / indexSys only speed up the reference's particle loop; same result without)"""
     _chk(flags, FlagGrid, "FlagGrid")
