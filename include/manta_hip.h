@@ -114,6 +114,11 @@ int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, co
  * fractions: nullable SoA MAC grid. */
 int mf_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj,
                            float* Ak, const float* fractions, void* stream);
+/* matrix set-up of cgSolveDiffusion, conjugategrad.cpp:359-375, applied to the Laplace matrix of an all-fluid dummy flag grid
+ * (mf_make_laplace_matrix on TypeFluid everywhere): obstacle cells get the identity row (Ai=Aj=Ak=0, A0=1), all other cells
+ * A* *= alpha, A0 += 1.  The solve itself is mf_cg_solve without preconditioner (GridCg<ApplyMatrix/2D>). */
+int mf_diffusion_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak,
+                        float alpha, void* stream);
 /* MakeRhs, plugin/pressure.cpp:32-84.  rhs border cells are left untouched (bnd=1 kernel).
  * perCellCorr/fractions/obvel/phi/curv nullable.  cnt/sum returned through host pointers (nullable). */
 int mf_make_rhs(int sx, int sy, int sz, const int32_t* flags, float* rhs, const float* vel,

@@ -4,7 +4,7 @@ import sys
 
 from .core import (BasicParticleSystem, FlagGrid, FluidSolver, Grid, IntGrid, LevelsetGrid, MACGrid, Mesh, ParticleIndexSystem,
                    PdataInt, PdataReal, PdataVec3, RealGrid, Solver, Vec3Grid, VecGrid, vec3)
-from .plugins import (Timings, getComponent, setComponent, resetOutflow, apicMapPartsToMAC, apicMapMACGridToParts, extrapolateMACFromWeight, extrapolateMACSimple, markFluidCells, addBuoyancy, addGravity, addGravityNoScale, advectSemiLagrange, computePressureRhs,
+from .plugins import (Timings, cgSolveDiffusion, getComponent, setComponent, resetOutflow, apicMapPartsToMAC, apicMapMACGridToParts, extrapolateMACFromWeight, extrapolateMACSimple, markFluidCells, addBuoyancy, addGravity, addGravityNoScale, advectSemiLagrange, computePressureRhs,
                       correctVelocity, flipVelocityUpdate, lastCgStats, mapGridToParts, mapGridToPartsVec3, mapMACToParts,
                       mapPartsToGrid, mapPartsToGridVec3, mapPartsToMAC, setDeterministicP2G, setWallBcs, solvePressure,
                       solvePressureSystem, pushOutofObs, gridParticleIndex, unionParticleLevelset, extrapolateLsSimple,

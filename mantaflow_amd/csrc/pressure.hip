@@ -738,6 +738,23 @@ __global__ void k_cg_latch_diverged(CgScalars* sc) {
 	if (sc->diverged) sc->done = 1;
 }
 
+// cgSolveDiffusion matrix set-up, conjugategrad.cpp:364-375
+__global__ void __launch_bounds__(BLOCK)
+k_diffusion_matrix(int64_t n, const int32_t* __restrict__ flags, float* __restrict__ A0, float* __restrict__ Ai, float* __restrict__ Aj,
+                   float* __restrict__ Ak, float alpha) {
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (idx >= n) return;
+	if (flags[idx] & MF_OBSTACLE) {
+		Ai[idx] = Aj[idx] = Ak[idx] = 0.f;
+		A0[idx] = 1.f;
+	} else {
+		Ai[idx] *= alpha;
+		Aj[idx] *= alpha;
+		Ak[idx] *= alpha;
+		A0[idx] = A0[idx] * alpha + 1.f;      // two roundings (-ffp-contract=off), as "A0 *= alpha; A0 += 1." in the reference
+	}
+}
+
 extern "C" {
 
 int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
@@ -835,6 +852,15 @@ int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float*
 	const Dim d = mkdim(sx, sy, sz);
 	if (fixPidx - d.Y < 0 || fixPidx + d.Y >= d.n || fixPidx - d.Z < 0 || fixPidx + d.Z >= d.n) return fail("fixPressure: cell %lld on the domain border", (long long)fixPidx);
 	hipLaunchKernelGGL(k_fix_pressure, dim3(1), dim3(1), 0, (hipStream_t)stream, d, fixPidx, value, rhs, A0, Ai, Aj, Ak);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int mf_diffusion_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak, float alpha,
+                        void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const int64_t n = (int64_t)sx * sy * sz;
+	hipLaunchKernelGGL(k_diffusion_matrix, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, n, flags, A0, Ai, Aj, Ak, alpha);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

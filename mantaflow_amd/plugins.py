@@ -196,6 +196,42 @@ def solvePressureSystem(rhs, vel, pressure, flags, cgAccuracy=1e-3, phi=None, pe
     _last_cg["iterations"], _last_cg["residual"] = int(out[0]), float(out[1])
 
 
+@plugin
+def cgSolveDiffusion(flags, grid, alpha=0.25, cgMaxIterFac=1.0, cgAccuracy=1e-4):
+    """conjugategrad.cpp:350-423: (I + alpha*L) u = grid, unpreconditioned GridCg<ApplyMatrix/2D>; Vec3 / MAC grids component by
+    component (2 components in 2-D)"""
+    _chk(flags, FlagGrid, "FlagGrid"); _chk(grid, GridBase, "GridBase")
+    s = flags.parent
+    lib, st = s.lib, s.stream
+    sx, sy, sz = flags.dims
+    rhs, residual, search, tmp, A0, Ai, Aj, Ak = (Grid(s) for _ in range(8))
+    dummy = FlagGrid(s)
+    dummy.setConst(core.TypeFluid)
+    lib.call("mf_make_laplace_matrix", sx, sy, sz, dummy.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, st)
+    lib.call("mf_diffusion_matrix", sx, sy, sz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, float(alpha), st)
+    maxIter = int(np.float32(cgMaxIterFac) * np.float32(max(sx, sy, sz))) * (1 if flags.is3D() else 4)
+    out = (ctypes.c_float * 3)()
+    none = Grid(s)
+
+    def solve(u):
+        rhs.copyFrom(u)
+        lib.call("mf_cg_solve", sx, sy, sz, flags.ptr, u.ptr, rhs.ptr, residual.ptr, search.ptr, tmp.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr,
+                 none.ptr, PcNone, float(cgAccuracy), int(maxIter), 1, out, st)   # GridCgInterface() : mUseL2Norm(true), conjugategrad.h:31
+        _last_cg["iterations"], _last_cg["residual"] = int(out[0]), float(out[1])
+
+    t = grid.getType()
+    if t & GridBase.TypeReal:
+        solve(grid)
+    elif t & (GridBase.TypeVec3 | GridBase.TypeMAC):
+        u = Grid(s)
+        for comp in range(3 if grid.is3D() else 2):
+            lib.call("mf_copy_f32", u.n, u.ptr, _ptr(grid.data[comp * grid.n:]), st)
+            solve(u)
+            lib.call("mf_copy_f32", u.n, _ptr(grid.data[comp * grid.n:]), u.ptr, st)
+    else:
+        raise RuntimeError("cgSolveDiffusion: Grid Type is not supported (only Real, Vec3, MAC, or Levelset)")
+
+
 def _fix_pressure(flags, rhs, A0, Ai, Aj, Ak):
     """zero-pressure fixing, pressure.cpp:349-390"""
     s = flags.parent

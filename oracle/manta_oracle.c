@@ -2663,6 +2663,25 @@ int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out, void* s) {
 	*out = (double)maxabs(n, a);
 	return 0;
 }
+/* cgSolveDiffusion matrix set-up, conjugategrad.cpp:364-375 */
+int mf_diffusion_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak, float alpha,
+                        void* st) {
+	(void)st;
+	const int64_t n = (int64_t)sx * sy * sz;
+	for (int64_t idx = 0; idx < n; idx++) {
+		if (flags[idx] & MF_OBSTACLE) {
+			Ai[idx] = Aj[idx] = Ak[idx] = 0.f;
+			A0[idx] = 1.f;
+		} else {
+			Ai[idx] *= alpha;
+			Aj[idx] *= alpha;
+			Ak[idx] *= alpha;
+			A0[idx] *= alpha;
+			A0[idx] = (float)((double)A0[idx] + 1.);
+		}
+	}
+	return 0;
+}
 int mf_cg_slab_alpha(const double* g, int world, const float* sigma, float* alpha, const int32_t* state, void* s) {
 	(void)s;
 	if (state && state[0]) {

@@ -99,6 +99,7 @@ void computeWaveletCoeffs(Grid<Real>& input);                                   
 void applyNoiseVec3(const FlagGrid& flags, Grid<Vec3>& target, const WaveletNoiseField& noise, Real scale, Real scaleSpatial,
                     const Grid<Real>* weight, const Grid<Vec3>* uv);                                         // :156
 void vorticityConfinement(MACGrid& vel, const FlagGrid& flags, Real strength, const Grid<Real>* strengthCell);  // extforces.cpp:419
+void cgSolveDiffusion(const FlagGrid& flags, GridBase& grid, Real alpha, Real cgMaxIterFac, Real cgAccuracy);   // conjugategrad.cpp:350
 void setOpenBound(FlagGrid& flags, int bWidth, std::string openBound, int type);
 void resetOutflow(FlagGrid& flags, Grid<Real>* phi, BasicParticleSystem* parts, Grid<Real>* real, Grid<int>* index,
                   ParticleIndexSystem* indexSys);                                                                // extforces.cpp:134                             // extforces.cpp:106
@@ -821,6 +822,21 @@ int ref_reset_outflow(int sx, int sy, int sz, int32_t* flags, float* phi, float*
 			pflag[i] = P->sys[i].flag;
 		}
 		*np_out = m;
+	}
+	SHIM_CATCH
+}
+/* cgSolveDiffusion, conjugategrad.cpp:350-423.  kind 1: Real grid [n]; 3: MAC grid SoA [3][n] */
+int ref_cg_solve_diffusion(int sx, int sy, int sz, const int32_t* flags, float* grid, int kind, float alpha, float cgMaxIterFac,
+                           float cgAccuracy) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	FlagGrid fl(&c.solver, const_cast<int*>(flags));
+	if (kind == 1) {
+		RealRef g(c, grid);
+		cgSolveDiffusion(fl, g.ref(), alpha, cgMaxIterFac, cgAccuracy);
+	} else {
+		MacIO v(c, grid, true);
+		cgSolveDiffusion(fl, v.g, alpha, cgMaxIterFac, cgAccuracy);
 	}
 	SHIM_CATCH
 }

@@ -355,6 +355,28 @@ def run_outflow_ref(dims, flags, phi, real, pos, pflag):
     return out
 
 
+def run_diffusion_pkg(dims, flags, real, vel, alpha=0.4, fac=1.0, acc=1e-5):
+    """cgSolveDiffusion on a Real grid and on a MAC grid"""
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims)
+    fl = soa_to_grid(core.FlagGrid(s), flags)
+    r, v = soa_to_grid(core.Grid(s), real), soa_to_grid(core.MACGrid(s), vel)
+    plugins.cgSolveDiffusion(fl, r, alpha, fac, acc)
+    it_r = plugins.lastCgStats()["iterations"]
+    plugins.cgSolveDiffusion(fl, v, alpha, fac, acc)
+    s.sync()
+    return {"real": grid_to_soa(r), "mac": grid_to_soa(v), "iters": np.array([it_r, plugins.lastCgStats()["iterations"]])}
+
+
+def run_diffusion_ref(dims, flags, real, vel, alpha=0.4, fac=1.0, acc=1e-5):
+    sx, sy, sz = dims
+    r, v = real.copy(), vel.copy()
+    cf = ctypes.c_float
+    refcall("ref_cg_solve_diffusion", sx, sy, sz, flags, r, 1, cf(alpha), cf(fac), cf(acc))
+    refcall("ref_cg_solve_diffusion", sx, sy, sz, flags, v, 3, cf(alpha), cf(fac), cf(acc))
+    return {"real": r, "mac": v}
+
+
 def apic_inputs(dims, seed, per_cell=3, include_border=False):
     sx, sy, sz = dims
     flags = util.make_flags(sx, sy, sz, seed, empty_top=True)

@@ -321,6 +321,22 @@ def test_apic_transfers(hip_backend, dims, per_cell, border, with_ptype):
     assert_bitexact(a2["apic_vel"], b["apic_vel"], "apic_vel without a mass grid")
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 18, 9), (64, 48, 40)])
+def test_cg_solve_diffusion(hip_backend, dims):
+    """cgSolveDiffusion: same iteration counts as the oracle, fields within 1e-5 (fp64 partial sums combined in another order)"""
+    from mantaflow_amd import _lib
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 81, obstacles=True)
+    real, vel = util.rand_real((sz, sy, sx), 82), util.rand_vel(sx, sy, sz, 83)
+    a = cases.run_diffusion_pkg(dims, flags, real, vel)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_diffusion_pkg(dims, flags, real, vel)
+    _lib.reset()
+    assert (a["iters"] == b["iters"]).all(), (a["iters"], b["iters"])
+    _close(a["real"], b["real"], "diffused Real grid")
+    _close(a["mac"], b["mac"], "diffused MAC grid")
+
+
 @pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
 def test_reset_outflow(hip_backend, dims):
     from mantaflow_amd import _lib

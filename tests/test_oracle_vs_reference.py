@@ -134,6 +134,19 @@ def test_flip_transfers(oracle_backend, dims, with_ptype):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (17, 9, 11)])
+def test_cg_solve_diffusion(oracle_backend, dims):
+    """cgSolveDiffusion (conjugategrad.cpp:350-423): the unpreconditioned GridCg<ApplyMatrix / ApplyMatrix2D> on (I + alpha L),
+    Real grid and MAC grid (component by component) -- SURVEY 8c names it as the Python-level pin of ApplyMatrix"""
+    sx, sy, sz = dims
+    flags = util.make_flags(sx, sy, sz, 81, obstacles=True)
+    real, vel = util.rand_real((sz, sy, sx), 82), util.rand_vel(sx, sy, sz, 83)
+    a, b = cases.run_diffusion_pkg(dims, flags, real, vel), cases.run_diffusion_ref(dims, flags, real, vel)
+    assert a["iters"].min() > 3 and np.abs(b["real"] - real).max() > 1e-3
+    for k in b:
+        assert_bitexact(a[k], b[k], k)
+
+
 @pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
 def test_reset_outflow(oracle_backend, dims):
     """resetOutflow (extforces.cpp:134-161): flags / phi / real bit for bit; the particles that survive the reference's
