@@ -529,7 +529,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-           const CgScalars* __restrict__ sc, double* __restrict__ dotpart, long long* trace, int trace_ticket, int trace_ticket2) {
+           const CgScalars* __restrict__ sc, double* __restrict__ dotpart, const int* __restrict__ bempty, long long* trace,
+           int trace_ticket, int trace_ticket2) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
 	// write-back wave, one partial per bundle at dotpart[tkl * nbj + tjl] -- the sum the PCG needs right after this sweep
@@ -585,9 +586,29 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		// jb = bundles per independent j-block (mf_set_mic_blocking: the caller has zeroed the Aj coupling across block
 		// faces, so nothing crosses them); jb == nbj: one block = the reference algorithm
 		const int tj_pred = REV ? tj + 1 : tj - 1, tj_succ = REV ? tj - 1 : tj + 1;
-		const bool has_pj = (tjl > 0) && (tj / jb == tj_pred / jb) && (b == 0), has_pk = (tkl > 0) && (c == 0);
-		const bool has_sj = (tjl + 1 < nbj) && (tj / jb == tj_succ / jb) && (b == 7), has_sk = (tkl + 1 < nbk) && (c == 7);
+		const int tk_pred = REV ? tk + 1 : tk - 1, tk_succ = REV ? tk - 1 : tk + 1;
 		const int64_t sid = (int64_t)tkl * nbj + tjl;
+		// A bundle without fluid cells (bempty, k_bundle_empty) is not swept: its cells pass through unchanged and everything it
+		// would hand to its neighbours multiplies a zero coefficient there, so neighbours neither wait for it nor publish to it.
+		if (bempty && bempty[tk * nbj + tj]) {
+			if (MODE == 2 && with_dot && wave == 0) {
+				// its share of dot(dst, var1), summed like the write-back wave sums it (x descending, then the butterfly)
+				double dacc = 0.0;
+				if (row_in)
+					for (int x = d.sx - 1; x >= 0; x--) dacc += (double)(dst[rowbase + x] * var1[rowbase + x]);
+#pragma unroll
+				for (int o = 32; o >= 1; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
+				if (lane == 0) dotpart[sid] = dacc;
+			}
+			__syncthreads();
+			continue;
+		}
+		const bool pj_live = (tjl > 0) && (tj / jb == tj_pred / jb) && !(bempty && bempty[tk * nbj + tj_pred]);
+		const bool pk_live = (tkl > 0) && !(bempty && bempty[tk_pred * nbj + tj]);
+		const bool sj_live = (tjl + 1 < nbj) && (tj / jb == tj_succ / jb) && !(bempty && bempty[tk * nbj + tj_succ]);
+		const bool sk_live = (tkl + 1 < nbk) && !(bempty && bempty[tk_succ * nbj + tj]);
+		const bool has_pj = pj_live && (b == 0), has_pk = pk_live && (c == 0);
+		const bool has_sj = sj_live && (b == 7), has_sk = sk_live && (c == 7);
 		const int64_t XP = X8 + 2 * ROWS_PAD;
 		if (wave == 5) {
 			// ================= face poller: the only wave that loads granules (and it never stores to global memory) =====
@@ -729,7 +750,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		} else {
 			// ================= compute wave: LDS in, LDS + face granules out =================
 			// Lane 0 stands in for lane 63's k face (same step, but its own x' runs 14 ahead of lane 63's)
-			const bool corner_proxy = (lane == 0) && (tkl + 1 < nbk);
+			const bool corner_proxy = (lane == 0) && sk_live;
 			const bool face_lane = has_sj || (has_sk && lane != 63) || corner_proxy;
 			const int fskew = corner_proxy ? -14 : 0;
 			unsigned long long* out_f = has_sj ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
@@ -846,6 +867,34 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	}
 }
 
+// bempty[tk * nbj + tj] = 1 when the 8x8 bundle of x-rows (tj, tk) needs no sweep: it has no fluid cell, and nothing couples
+// into it -- the rows just below it in j and k carry Aj == 0 / Ak == 0 (what the backward substitution multiplies the bundle's
+// pass-through values with; MakeLaplaceMatrix writes exactly that next to non-fluid cells).  In the forward substitution the
+// bundle's faces are (val * A) * Aprecond with Aprecond == 0 in every non-fluid cell (mf_mic_init clears the grid and
+// writes fluid cells only).  One workgroup per bundle.
+__global__ void __launch_bounds__(BLOCK)
+k_bundle_empty(Dim d, int nbj, const int32_t* __restrict__ flags, const float* __restrict__ Aj, const float* __restrict__ Ak,
+               int* __restrict__ bempty) {
+	const int tj = blockIdx.x % nbj, tk = blockIdx.x / nbj;
+	const int j0 = tj * 8, k0 = tk * 8;
+	__shared__ int s_live;
+	if (threadIdx.x == 0) s_live = 0;
+	__syncthreads();
+	bool live = false;
+	const int cells = 64 * d.sx;
+	for (int q = threadIdx.x; q < cells && !live; q += BLOCK) {
+		const int x = q % d.sx, r = q / d.sx, j = j0 + (r & 7), k = k0 + (r >> 3);
+		if (j >= d.sy || k >= d.sz) continue;
+		const int64_t idx = (int64_t)x + d.Y * j + d.Z * k;
+		if (flags[idx] & MF_FLUID) live = true;
+		if ((r & 7) == 0 && j0 > 0 && Aj[idx - d.Y] != 0.f) live = true;
+		if ((r >> 3) == 0 && k0 > 0 && Ak[idx - d.Z] != 0.f) live = true;
+	}
+	if (live) s_live = 1;
+	__syncthreads();
+	if (threadIdx.x == 0) bempty[blockIdx.x] = s_live ? 0 : 1;
+}
+
 // host-side state of the dataflow sweeps (per device): tile order for the current grid, exchange buffer, generation
 struct FlowState {
 	int nti = 0, ntj = 0, ntk = 0, ntiles = 0;
@@ -854,6 +903,11 @@ struct FlowState {
 	int jb = 0;                  // bundles per j-block the order was built for
 	int nq = 0;                  // ticket queues (1 or 8)
 	int* rows_xt = nullptr;      // [2][18]: tickets, queue bounds, queue count -- forward sweep, backward sweep
+	// bundles without a fluid cell (and without coupling into them) need no sweep at all: built by mf_mic_init for the grids
+	// it was given, used by the apply sweeps only when they are given the same grids
+	int* bempty = nullptr;
+	int bempty_cap = 0;
+	const void *be_flags = nullptr, *be_Ap = nullptr, *be_Aj = nullptr, *be_Ak = nullptr;
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
@@ -1080,12 +1134,14 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 12 * 4096));
 				}
 			}
+			static const bool noskip = getenv("MF_MIC_NOSKIP") != nullptr;
+			const int* be = (!noskip && f->bempty && f->be_flags == flags && f->be_Ap == Ap && f->be_Aj == Aj && f->be_Ak == Ak) ? f->bempty : nullptr;
 			double* dotp = (MODE == 2 && al16(var1) && f->nblocks <= MAX_BLOCKS) ? g_dot_request : nullptr;
 			g_dot_count = dotp ? f->nblocks : 0;
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, trace, trace_ticket, trace_ticket2);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, trace, trace_ticket, trace_ticket2);
 			MF_LAUNCH_CHECK();
 			if (trace) {
 				static int printed = 0;
@@ -1209,7 +1265,25 @@ int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, c
 	const Dim d = mkdim(sx, sy, sz);
 	if (!d.is3d) return fail("mICP only supports 3D grids so far");
 	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, (hipStream_t)stream));
-	return mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
+	MF_TRY(mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream));
+	if (mic_mode_() == 2) {
+		// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
+		FlowState* f;
+		MF_TRY(rows_prepare(d, &f, (hipStream_t)stream));
+		if (f->nblocks > f->bempty_cap) {
+			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
+			if (f->bempty) MF_HIP(hipFree(f->bempty));
+			MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * f->nblocks));
+			f->bempty_cap = f->nblocks;
+		}
+		hipLaunchKernelGGL(k_bundle_empty, dim3(f->nblocks), dim3(BLOCK), 0, (hipStream_t)stream, d, f->nbj, flags, Aj, Ak, f->bempty);
+		MF_LAUNCH_CHECK();
+		f->be_flags = flags;
+		f->be_Ap = Aprecond;
+		f->be_Aj = Aj;
+		f->be_Ak = Ak;
+	}
+	return 0;
 }
 int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
                  const float* Ai, const float* Aj, const float* Ak, void* stream) {
