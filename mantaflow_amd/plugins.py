@@ -25,14 +25,48 @@ _timings = {}
 _last_cg = {}
 
 
+def _coerce(v, default):
+    """fromPy<bool> / fromPy<int>, pconvert.cpp:170-181, 212-215: a bool parameter takes a Python bool only; an int parameter
+    takes an int, or a float within 1e-5 of an integer"""
+    if isinstance(default, bool):
+        if not isinstance(v, bool):
+            raise RuntimeError("argument is not a boolean")
+        return v
+    if isinstance(default, int):
+        if isinstance(v, (int, np.integer)):
+            return int(v)
+        if isinstance(v, (float, np.floating)):
+            a = float(v)
+            if abs(a - np.floor(a + 0.5)) > 1e-5:
+                raise RuntimeError("argument is not an int")
+            return int(a + 0.5)
+        raise RuntimeError("argument is not an int")
+    return v
+
+
 def plugin(fn):
     """Wrapper every PYTHON() symbol gets in the reference (codegen_python.cpp:32-58): universal kwargs, per-plugin
-    wall timer (pclass.cpp:36-41), unknown arguments -> RuntimeError (pconvert.cpp:460-474)."""
+    wall timer (pclass.cpp:36-41), unknown arguments -> RuntimeError (pconvert.cpp:460-474), bool / int argument conversion
+    rules (typed by the parameter's default value)."""
+    import inspect
+    params = list(inspect.signature(fn).parameters.values())
+    typed = {p.name: p.default for p in params if isinstance(p.default, (bool, int)) and p.default is not None}
+    pos_typed = [(i, p.default) for i, p in enumerate(params) if p.name in typed]
+
     @functools.wraps(fn)
     def w(*args, **kw):
         notiming = kw.pop("notiming", False)
         for k in _UNIVERSAL[1:]:
             kw.pop(k, None)
+        if typed:
+            if any(i < len(args) for i, _ in pos_typed):
+                args = list(args)
+                for i, d in pos_typed:
+                    if i < len(args):
+                        args[i] = _coerce(args[i], d)
+            for k in kw:
+                if k in typed:
+                    kw[k] = _coerce(kw[k], typed[k])
         t0 = time.time()
         try:
             r = fn(*args, **kw)
@@ -457,7 +491,7 @@ def markFluidCells(parts, flags, phiObs=None, ptype=None, exclude=0):
 
 
 @plugin
-def pushOutofObs(parts, flags, phiObs, shift=0, thresh=0, ptype=None, exclude=0):
+def pushOutofObs(parts, flags, phiObs, shift=0., thresh=0., ptype=None, exclude=0):
     """flip.cpp:584-602"""
     _chk(flags, FlagGrid, "FlagGrid"); _chk(phiObs, Grid, "Grid<Real>")
     s = flags.parent
@@ -620,7 +654,7 @@ def computeWaveletCoeffs(input):
 
 
 @plugin
-def vorticityConfinement(vel, flags, strength=0, strengthCell=None):
+def vorticityConfinement(vel, flags, strength=0., strengthCell=None):
     """extforces.cpp:409-428"""
     _chk(vel, MACGrid, "MACGrid"); _chk(flags, FlagGrid, "FlagGrid")
     strengthCell = _opt(strengthCell, Grid, "Grid<Real>")
