@@ -144,7 +144,10 @@ int mf_count_empty_cells(int64_t n, const int32_t* flags, int32_t* result_host, 
 int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float* rhs, float* A0, float* Ai,
                     float* Aj, float* Ak, void* stream);
 
-/* InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97 (3-D only) */
+/* InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97 (3-D only).  Also records, for exactly these grids, which
+ * 8x8 bundles of x-rows hold no fluid cell and have no coupling into them: mf_mic_apply leaves those out when it is called
+ * with the same flags / Aprecond / Aj / Ak pointers (as GridCg does); with other pointers it sweeps everything.  Changing the
+ * contents of these grids between mf_mic_init and mf_mic_apply is a caller error (the reference's Aprecond would be stale too). */
 int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0,
                 const float* Ai, const float* Aj, const float* Ak, void* stream);
 /* ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159 (3-D only).
