@@ -64,6 +64,9 @@ int mf_set_mic_mode(const char* name);
  * faces (the values exchanged there are multiplied by 0 anyway), which shortens the dependency chain.  The arithmetic
  * is unchanged: results equal the serial sweep with the same (cut) coefficients bit for bit.  0 = off (default). */
 int mf_set_mic_blocking(int rows_j);
+/* the same along x: independent x-blocks of cells_x cells (a non-negative multiple of 8; 0 = whole rows).  The caller has
+ * zeroed the Ai coupling across the block faces in the preconditioner's copy of the matrix. */
+int mf_set_mic_blocking_x(int cells_x);
 /* Synchronises the stream and reports whether any MIC sweep since the last check gave up waiting for a neighbouring
  * workgroup (a deadlock guard of the single-launch sweeps; never seen in practice).  mf_cg_solve checks by itself; callers
  * that drive mf_mic_apply directly call this once per solve.  The oracle returns 0. */

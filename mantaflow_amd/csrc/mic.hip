@@ -533,7 +533,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            int trace_ticket, int trace_ticket2) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
-	// write-back wave, one partial per bundle at dotpart[tkl * nbj + tjl] -- the sum the PCG needs right after this sweep
+	// write-back wave, one partial per bundle (and x-block) at dotpart[sid] -- the sum the PCG needs right after this sweep
 	const bool with_dot = (MODE == 2) && dotpart != nullptr;
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
@@ -574,11 +574,15 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		const int t = s_ticket;
 		if (t >= nstreams) break;
 		const int pk = order[t];
-		const int tjl = pk & 0xffff, tkl = pk >> 16;
+		const int tjl = pk & 0xfff, tkl = (pk >> 12) & 0xfff, xb = pk >> 24;
 		const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
 		const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
 		const bool row_in = (j < d.sy) && (k < d.sz);
-		const int64_t rowbase = d.Y * j + d.Z * k;
+		// x-block xb (mf_set_mic_blocking_x: the caller has zeroed the Ai coupling across the block faces): an independent
+		// system of X8 cells starting at xoff; one x-block = the whole row = the reference algorithm
+		const int xoff = xb * X8;
+		const int xlim = d.sx - xoff < X8 ? d.sx - xoff : X8;          // cells of this x-block that exist
+		const int64_t rowbase = d.Y * j + d.Z * k + xoff;
 
 		// face granules: per bundle and face an array [producer step h + 2][face lane]: the 8 face lanes of one step (one
 		// store instruction) fill exactly one 64-byte line, and a consumer lane's 8-step window maps to 8 consecutive lines
@@ -587,7 +591,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		// faces, so nothing crosses them); jb == nbj: one block = the reference algorithm
 		const int tj_pred = REV ? tj + 1 : tj - 1, tj_succ = REV ? tj - 1 : tj + 1;
 		const int tk_pred = REV ? tk + 1 : tk - 1, tk_succ = REV ? tk - 1 : tk + 1;
-		const int64_t sid = (int64_t)tkl * nbj + tjl;
+		const int64_t sid = ((int64_t)xb * nbk + tkl) * nbj + tjl;
 		// A bundle without fluid cells (bempty, k_bundle_empty) is not swept: its cells pass through unchanged and everything it
 		// would hand to its neighbours multiplies a zero coefficient there, so neighbours neither wait for it nor publish to it.
 		if (bempty && bempty[tk * nbj + tj]) {
@@ -595,7 +599,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				// its share of dot(dst, var1), summed like the write-back wave sums it (x descending, then the butterfly)
 				double dacc = 0.0;
 				if (row_in)
-					for (int x = d.sx - 1; x >= 0; x--) dacc += (double)(dst[rowbase + x] * var1[rowbase + x]);
+					for (int x = xlim - 1; x >= 0; x--) dacc += (double)(dst[rowbase + x] * var1[rowbase + x]);
 #pragma unroll
 				for (int o = 32; o >= 1; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
 				if (lane == 0) dotpart[sid] = dacc;
@@ -663,7 +667,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			// loads and stores in flight ends up waiting for all of them)
 			auto chunk_geom = [&](int m, int64_t& rowidx, int& nv) {
 				const int x0 = (REV ? nchunks - 1 - m : m) * 8;
-				const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
+				const int nvx = xlim - x0 < 8 ? xlim - x0 : 8;             // <= 0 past the end of the row
 				nv = row_in ? nvx : 0;
 				rowidx = rowbase + x0;
 			};
@@ -744,7 +748,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					// fixed butterfly over the 64 rows of the bundle: the same bits on every run
 #pragma unroll
 					for (int o = 32; o >= 1; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
-					if (lane == 0) dotpart[(int64_t)tkl * nbj + tjl] = dacc;
+					if (lane == 0) dotpart[sid] = dacc;
 				}
 			}
 		} else {
@@ -901,6 +905,7 @@ struct FlowState {
 	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;   // streaming form
 	int* border = nullptr;       // ticket order of the forward sweep, then of the backward sweep (nblocks entries each)
 	int jb = 0;                  // bundles per j-block the order was built for
+	int nxb = 0;                 // x-blocks per row (1 = whole rows)
 	int nq = 0;                  // ticket queues (1 or 8)
 	int* rows_xt = nullptr;      // [2][18]: tickets, queue bounds, queue count -- forward sweep, backward sweep
 	// bundles without a fluid cell (and without coupling into them) need no sweep at all: built by mf_mic_init for the grids
@@ -993,12 +998,16 @@ static bool xcd_round_robin_ok() {
 	return state == 1;
 }
 static thread_local int g_mic_jblock_rows = 0;   // mf_set_mic_blocking
+static thread_local int g_mic_xblock_cells = 0;  // mf_set_mic_blocking_x
 static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
-	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8, nchunks = (d.sx + 7) / 8;
-	if (nbj > 65535 || nbk > 32767) return fail("grid too large for the MIC bundle order table");
+	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8;
+	// x-blocks of g_mic_xblock_cells cells (independent systems, the caller has cut Ai) -- or the whole row
+	const int xcells = (g_mic_xblock_cells > 0 && g_mic_xblock_cells < d.sx) ? g_mic_xblock_cells : ((d.sx + 7) / 8) * 8;
+	const int nchunks = xcells / 8, nxb = (d.sx + xcells - 1) / xcells;
+	if (nbj > 4095 || nbk > 4095 || nxb > 127) return fail("grid too large for the MIC bundle order table");
 	int jb = g_mic_jblock_rows > 0 ? g_mic_jblock_rows / 8 : nbj;
 	if (jb < 1 || jb > nbj) jb = nbj;
 	static const int use_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : 0;
@@ -1007,9 +1016,9 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 	}
-	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != nq) {
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != nq || f.nxb != nxb) {
 		MF_HIP(hipStreamSynchronize(st));
-		const int nb = nbj * nbk;
+		const int nb = nbj * nbk * nxb;
 		int* h = (int*)malloc(sizeof(int) * 2 * nb);
 		int xt[2][18];
 		memset(xt, 0, sizeof xt);
@@ -1027,7 +1036,8 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 								const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
 								const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
 								const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
-								if (posj + bk == L) h[rev * nb + q++] = bjl | (bk << 16);
+								if (posj + bk == L)
+									for (int xb = 0; xb < nxb; xb++) h[rev * nb + q++] = bjl | (bk << 12) | (xb << 24);
 							}
 						}
 			}
@@ -1059,6 +1069,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
 		f.nchunks = nchunks;
 		f.jb = jb;
 		f.nq = nq;
+		f.nxb = nxb;
 	}
 	*out = &f;
 	return 0;
@@ -1076,6 +1087,11 @@ extern "C" int mf_set_mic_mode(const char* name) {
 	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
 	else if (!strcmp(name, "rows")) g_mic_mode = 2;
 	else return fail("mf_set_mic_mode: unknown mode (rows | tiles | levels)");
+	return 0;
+}
+extern "C" int mf_set_mic_blocking_x(int cells_x) {
+	if (cells_x < 0 || (cells_x % 8) != 0) return fail("mf_set_mic_blocking_x: cells must be a non-negative multiple of 8");
+	g_mic_xblock_cells = cells_x;
 	return 0;
 }
 extern "C" int mf_set_mic_blocking(int rows_j) {
@@ -1276,7 +1292,7 @@ int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, c
 			MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * f->nblocks));
 			f->bempty_cap = f->nblocks;
 		}
-		hipLaunchKernelGGL(k_bundle_empty, dim3(f->nblocks), dim3(BLOCK), 0, (hipStream_t)stream, d, f->nbj, flags, Aj, Ak, f->bempty);
+		hipLaunchKernelGGL(k_bundle_empty, dim3(f->nbj * f->nbk), dim3(BLOCK), 0, (hipStream_t)stream, d, f->nbj, flags, Aj, Ak, f->bempty);
 		MF_LAUNCH_CHECK();
 		f->be_flags = flags;
 		f->be_Ap = Aprecond;

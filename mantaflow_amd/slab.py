@@ -19,6 +19,7 @@ The reference has no multi-device code at all, so this layer is new
 No data-path collective other than these; FLIP particles across slabs (reverse halo + migration) are "next".
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -30,6 +31,7 @@ from .core import _ptr
 
 
 STOP_POLL = 4          # slab PCG: iterations between two host reads of the device-side stop state
+MIC_BLOCK_CELLS_X = int(os.environ.get("MF_SLAB_XBLOCK", "128"))   # x-extent of a preconditioner block for P > 1 (0 = whole rows)
 MIC_BLOCK_ROWS = 64   # y-extent of a preconditioner block when the domain is split over several ranks (0 = do not cut)
 
 
@@ -225,6 +227,16 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         ajv = Ajm.data.view(sz, sy, sx)
         for jc in range(jblock, sy, jblock):
             ajv[:, jc - 1, :] = 0
+    # ... and along x (blocks of MIC_BLOCK_CELLS_X cells): a bundle of rows then streams half a row, two to a row
+    Aim = Ai
+    xblock = 0
+    if dom.comm.world > 1 and MIC_BLOCK_CELLS_X > 0 and sx >= 2 * MIC_BLOCK_CELLS_X:
+        xblock = MIC_BLOCK_CELLS_X
+        Aim = G(s)
+        Aim.copyFrom(Ai)
+        aiv = Aim.data.view(sz, sy, sx)
+        for ic in range(xblock, sx, xblock):
+            aiv[:, :, ic - 1] = 0
     # rhs must vanish outside the owned planes for the local sweeps to be well defined
     rv = rhs.data.view(sz, XY)
     if dom.gl:
@@ -245,15 +257,16 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         lib.call("mf_grid_dot_dev", nown, _off(a.data, off), _off(b.data, off), p_red1, st)
 
     def mic(dst, src):
-        lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Ai.ptr, Ajm.ptr, Akm.ptr, st)
+        lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, st)
 
     lib.call("mf_set_mic_blocking", jblock)
+    lib.call("mf_set_mic_blocking_x", xblock)
     # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather whose
     # rows are combined in rank order by a one-thread kernel; the host reads one number per iteration (the stopping test).
     # doInit, conjugategrad.cpp:210-235
     pressure.clear()
     residual.copyFrom(rhs)
-    lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Ai.ptr, Ajm.ptr, Akm.ptr, st)
+    lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, st)
     mic(tmp, residual)
     search.copyFrom(tmp)
     dot_own(tmp, residual)
@@ -294,6 +307,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     if stop == 2:
         raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     lib.call("mf_set_mic_blocking", 0)
+    lib.call("mf_set_mic_blocking_x", 0)
     lib.call("mf_mic_check", st)
     if stats is not None:
         stats["iterations"], stats["residual"] = iters, float(resNorm)

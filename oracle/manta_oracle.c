@@ -43,6 +43,10 @@ int mf_mic_check(void* stream) {
 	(void)stream;
 	return 0;
 }
+int mf_set_mic_blocking_x(int cells_x) {
+	(void)cells_x; /* the serial sweep needs no schedule: it runs over whatever coefficients it is given */
+	return 0;
+}
 int mf_set_mic_blocking(int rows_j) {
 	(void)rows_j;
 	return 0;

@@ -136,6 +136,31 @@ def test_mic_blocked_sweeps_equal_serial_sweep_of_cut_system(hip, oracle, dims, 
     assert hip.lib.cdll.mf_set_mic_blocking(12) != 0
 
 
+@pytest.mark.parametrize("dims,rows,cells", [((64, 64, 24), 16, 32), ((72, 40, 17), 0, 24), ((100, 48, 16), 24, 48), ((256, 64, 16), 32, 64)])
+def test_mic_x_blocked_sweeps_equal_serial_sweep_of_cut_system(hip, oracle, dims, rows, cells):
+    """mf_set_mic_blocking_x: independent x-blocks (Ai zeroed at the block faces), alone and together with the y-blocking; the
+    last x-block may be shorter than the others"""
+    sx, sy, sz = dims
+    flags, A, src = cases.system_inputs(dims, 9)
+    A = [a.copy() for a in A]
+    for ic in range(cells, sx, cells):
+        A[1][:, :, ic - 1] = 0          # Ai couples cells i and i+1
+    if rows:
+        for jc in range(rows, sy, rows):
+            A[2][:, jc - 1, :] = 0
+    ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
+    assert hip.lib.cdll.mf_set_mic_blocking_x(cells) == 0 and hip.lib.cdll.mf_set_mic_blocking(rows) == 0
+    try:
+        ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
+        ap2, dst2 = cases.run_mic_impl(hip, dims, flags, A, src)
+    finally:
+        assert hip.lib.cdll.mf_set_mic_blocking_x(0) == 0 and hip.lib.cdll.mf_set_mic_blocking(0) == 0
+    assert_bitexact(ap, ap_o, "Aprecond (cut)")
+    assert_bitexact(dst, dst_o, "x-blocked mic apply")
+    assert_bitexact(dst, dst2, "x-blocked mic apply re-run")
+    assert hip.lib.cdll.mf_set_mic_blocking_x(12) != 0
+
+
 def test_mic_mode_rejects_unknown_name(hip):
     assert hip.lib.cdll.mf_set_mic_mode(b"diagonal") != 0
     assert b"unknown mode" in hip.lib.cdll.mf_last_error()

@@ -30,6 +30,7 @@ def main():
         lib.call("mf_make_laplace_matrix", nx, ny, nz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, s.stream)
         src.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (nz, ny, nx)).astype(np.float32))
         lib.call("mf_set_mic_blocking", int(os.environ.get("MF_MIC_BLOCK", "0")))   # timing only unless Aj is cut as well
+        lib.call("mf_set_mic_blocking_x", int(os.environ.get("MF_MIC_BLOCK_X", "0")))
         lib.call("mf_mic_init", nx, ny, nz, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
