@@ -535,6 +535,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
 	// write-back wave, one partial per bundle (and x-block) at dotpart[sid] -- the sum the PCG needs right after this sweep
 	const bool with_dot = (MODE == 2) && dotpart != nullptr;
+	if (bempty && bempty[nbj * nbk] == 0) bempty = nullptr;     // no empty bundle (smoke scenes): no per-bundle look-ups
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
@@ -896,7 +897,10 @@ k_bundle_empty(Dim d, int nbj, const int32_t* __restrict__ flags, const float* _
 	}
 	if (live) s_live = 1;
 	__syncthreads();
-	if (threadIdx.x == 0) bempty[blockIdx.x] = s_live ? 0 : 1;
+	if (threadIdx.x == 0) {
+		bempty[blockIdx.x] = s_live ? 0 : 1;
+		if (!s_live) atomicAdd(&bempty[gridDim.x], 1);      // number of empty bundles (slot behind the map)
+	}
 }
 
 // host-side state of the dataflow sweeps (per device): tile order for the current grid, exchange buffer, generation
@@ -1286,12 +1290,13 @@ int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, c
 		// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
 		FlowState* f;
 		MF_TRY(rows_prepare(d, &f, (hipStream_t)stream));
-		if (f->nblocks > f->bempty_cap) {
+		if (f->nblocks + 1 > f->bempty_cap) {
 			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
 			if (f->bempty) MF_HIP(hipFree(f->bempty));
-			MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * f->nblocks));
-			f->bempty_cap = f->nblocks;
+			MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * (f->nblocks + 1)));
+			f->bempty_cap = f->nblocks + 1;
 		}
+		MF_HIP(hipMemsetAsync(f->bempty + f->nbj * f->nbk, 0, sizeof(int), (hipStream_t)stream));
 		hipLaunchKernelGGL(k_bundle_empty, dim3(f->nbj * f->nbk), dim3(BLOCK), 0, (hipStream_t)stream, d, f->nbj, flags, Aj, Ak, f->bempty);
 		MF_LAUNCH_CHECK();
 		f->be_flags = flags;
