@@ -585,6 +585,12 @@ __global__ void __launch_bounds__(BLOCK) k_cg_begin(CgScalars* sc, int nb, const
 // alpha = sigma / dp, conjugategrad.cpp:250-252
 __global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const double* __restrict__ partials) {
 	if (sc->done) return;
+	if (sc->diverged) {
+		// the iteration that diverged has finished its search update (the reference throws after it): stop everything queued
+		// behind it.  (This iteration's ApplyMatrix has already run; it only wrote tmp.)
+		if (threadIdx.x == 0) sc->done = 1;
+		return;
+	}
 	double acc = strided_sum(partials, nb);
 	acc = block_sum(acc);
 	if (threadIdx.x == 0) {
@@ -733,9 +739,6 @@ k_cg_update_search(int64_t n, CgScalars* __restrict__ sc, float* __restrict__ se
 		const int64_t i = (n4 << 2) + threadIdx.x;
 		search[i] = tmp[i] + beta * search[i];
 	}
-}
-__global__ void k_cg_latch_diverged(CgScalars* sc) {
-	if (sc->diverged) sc->done = 1;
 }
 
 // cgSolveDiffusion matrix set-up, conjugategrad.cpp:364-375
@@ -933,7 +936,6 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 			}
 			hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
 			hipLaunchKernelGGL(k_cg_update_search, dim3(nbs), dim3(BLOCK), 0, st, n, sc, search, tmp);
-			hipLaunchKernelGGL(k_cg_latch_diverged, dim3(1), dim3(1), 0, st, sc);
 		}
 		MF_LAUNCH_CHECK();
 		issued += todo;
@@ -942,7 +944,7 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 		if (pending >= 0) {
 			MF_HIP(hipEventSynchronize(ev[pending]));
 			memcpy(&h, &hslot[pending], sizeof h);
-			if (h.done) break;
+			if (h.done || h.diverged) break;
 		}
 		pending = slot;
 		slot ^= 1;
