@@ -521,6 +521,7 @@ constexpr int ROWS_PAD = 16;
 struct RowsChunk {
 	int F[8];
 	float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
+	unsigned long long W;     // packed path: 8 cells x {fluid, Ai == -1, Aj == -1, Ak == -1} bits
 };
 constexpr int ROWS_THREADS = 384;   // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the faces
 template <int MODE, bool VEC>
@@ -529,13 +530,19 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
-           const CgScalars* __restrict__ sc, double* __restrict__ dotpart, const int* __restrict__ bempty, long long* trace,
-           int trace_ticket, int trace_ticket2) {
+           const CgScalars* __restrict__ sc, double* __restrict__ dotpart, const int* __restrict__ bempty,
+           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok, long long* trace, int trace_ticket,
+           int trace_ticket2) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
 	// write-back wave, one partial per bundle (and x-block) at dotpart[sid] -- the sum the PCG needs right after this sweep
 	const bool with_dot = (MODE == 2) && dotpart != nullptr;
 	if (bempty && bempty[nbj * nbk] == 0) bempty = nullptr;     // no empty bundle (smoke scenes): no per-bundle look-ups
+	// packed operands (k_mic_pack, built by mf_mic_init when every Ai / Aj / Ak is exactly 0 or -1, as MakeLaplaceMatrix writes
+	// them): one byte per cell replaces the flags + Ai + Aj + Ak streams (16 B per cell) of both sweeps; the values are rebuilt
+	// exactly, so the arithmetic is unchanged.  What the sweeps wait for is the hand-off between bundles, and that waits behind
+	// the operand stream of its own CU -- fewer outstanding HBM requests make every hand-off shorter.
+	const bool packed = pack != nullptr && pack_ok[0] != 0;
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
@@ -683,11 +690,15 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					int64_t rowidx;
 					int nv;
 					chunk_geom(m, rowidx, nv);
-					load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
+					if (packed) {
+						r.W = nv > 0 ? *(const unsigned long long*)(pack + rowidx) : 0ull;     // sx % 8 == 0: nv is 8 or <= 0
+					} else {
+						load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
+						load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
+						load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
+						load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
+					}
 					if (MODE == 1 || with_dot) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
-					load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
-					load_row8<VEC, REV>(Aj, rowidx, nv, r.Aj);
-					load_row8<VEC, REV>(Ak, rowidx, nv, r.Ak);
 					load_row8<VEC, REV>(Ap, rowidx, nv, r.P);
 					load_row8<VEC, REV>(dst, rowidx, nv, r.D);
 				};
@@ -699,9 +710,22 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 #pragma unroll
 					for (int a = 0; a < 8; a++) {
 						const bool in = ((REV ? 7 - a : a) < nv);
-						const bool fl = in && (r.F[a] & MF_FLUID);
+						bool fl;
+						float cai, caj, cak;
+						if (packed) {
+							const unsigned bits = (unsigned)(r.W >> (8 * (REV ? 7 - a : a))) & 0xffu;
+							fl = (bits & 1u) != 0;
+							cai = (bits & 2u) ? -1.f : 0.f;
+							caj = (bits & 4u) ? -1.f : 0.f;
+							cak = (bits & 8u) ? -1.f : 0.f;
+						} else {
+							fl = in && (r.F[a] & MF_FLUID);
+							cai = r.Ai[a];
+							caj = r.Aj[a];
+							cak = r.Ak[a];
+						}
 						const int idx = ((p0 + a) & 31) * 64 + lane;
-						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], r.Ai[a], r.Aj[a], r.Ak[a]);
+						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], cai, caj, cak);
 						sB[idx] = make_float2(r.P[a], fl ? 1.f : 0.f);
 						if (MODE == 2 && with_dot) sR[idx] = r.V[a];     // 0 outside the grid (load_row8)
 					}
@@ -872,6 +896,20 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	}
 }
 
+// one byte per cell: bit 0 fluid, bits 1..3 "Ai / Aj / Ak is -1"; ok[0] is cleared when a coefficient is neither +0 nor -1
+// (second-order boundaries, a caller's own matrix): the sweeps then read the four arrays themselves
+__global__ void __launch_bounds__(BLOCK)
+k_mic_pack(int64_t n, const int32_t* __restrict__ flags, const float* __restrict__ Ai, const float* __restrict__ Aj,
+           const float* __restrict__ Ak, unsigned char* __restrict__ pack, int* __restrict__ ok) {
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (idx >= n) return;
+	const unsigned ui = __float_as_uint(Ai[idx]), uj = __float_as_uint(Aj[idx]), uk = __float_as_uint(Ak[idx]);
+	const unsigned M1 = 0xBF800000u;   // -1.0f
+	const bool good = (ui == 0u || ui == M1) && (uj == 0u || uj == M1) && (uk == 0u || uk == M1);
+	if (!good) ok[0] = 0;
+	pack[idx] = (unsigned char)(((flags[idx] & MF_FLUID) ? 1u : 0u) | (ui == M1 ? 2u : 0u) | (uj == M1 ? 4u : 0u) | (uk == M1 ? 8u : 0u));
+}
+
 // bempty[tk * nbj + tj] = 1 when the 8x8 bundle of x-rows (tj, tk) needs no sweep: it has no fluid cell, and nothing couples
 // into it -- the rows just below it in j and k carry Aj == 0 / Ak == 0 (what the backward substitution multiplies the bundle's
 // pass-through values with; MakeLaplaceMatrix writes exactly that next to non-fluid cells).  In the forward substitution the
@@ -917,6 +955,11 @@ struct FlowState {
 	int* bempty = nullptr;
 	int bempty_cap = 0;
 	const void *be_flags = nullptr, *be_Ap = nullptr, *be_Aj = nullptr, *be_Ak = nullptr;
+	// packed operands of the apply sweeps (k_mic_pack), valid for the grids mf_mic_init was given
+	unsigned char* pack = nullptr;
+	int* pack_ok = nullptr;
+	size_t pack_cap = 0;
+	const void *pk_flags = nullptr, *pk_Ai = nullptr, *pk_Aj = nullptr, *pk_Ak = nullptr;
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
@@ -1156,12 +1199,15 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			}
 			static const bool noskip = getenv("MF_MIC_NOSKIP") != nullptr;
 			const int* be = (!noskip && f->bempty && f->be_flags == flags && f->be_Ap == Ap && f->be_Aj == Aj && f->be_Ak == Ak) ? f->bempty : nullptr;
+			static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
+			const bool use_pack = !nopack && f->pack && (d.sx % 8 == 0) && f->pk_flags == flags && f->pk_Ai == Ai && f->pk_Aj == Aj && f->pk_Ak == Ak;
+			const unsigned char* pk = use_pack ? f->pack : nullptr;
 			double* dotp = (MODE == 2 && al16(var1) && f->nblocks <= MAX_BLOCKS) ? g_dot_request : nullptr;
 			g_dot_count = dotp ? f->nblocks : 0;
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, trace, trace_ticket, trace_ticket2);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, trace, trace_ticket, trace_ticket2);
 			MF_LAUNCH_CHECK();
 			if (trace) {
 				static int printed = 0;
@@ -1303,6 +1349,21 @@ int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, c
 		f->be_Ap = Aprecond;
 		f->be_Aj = Aj;
 		f->be_Ak = Ak;
+		// packed operands for the apply sweeps
+		if ((size_t)d.n > f->pack_cap) {
+			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
+			if (f->pack) MF_HIP(hipFree(f->pack));
+			MF_HIP(hipMalloc((void**)&f->pack, (size_t)d.n + 64));
+			f->pack_cap = (size_t)d.n;
+		}
+		if (!f->pack_ok) MF_HIP(hipMalloc((void**)&f->pack_ok, sizeof(int)));
+		MF_HIP(hipMemsetAsync(f->pack_ok, 1, sizeof(int), (hipStream_t)stream));     // non-zero = valid until k_mic_pack clears it
+		hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d.n, flags, Ai, Aj, Ak, f->pack, f->pack_ok);
+		MF_LAUNCH_CHECK();
+		f->pk_flags = flags;
+		f->pk_Ai = Ai;
+		f->pk_Aj = Aj;
+		f->pk_Ak = Ak;
 	}
 	return 0;
 }
