@@ -1307,6 +1307,23 @@ int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* 
 	*ndot = g_dot_count;
 	return rc;
 }
+// the packed flags/Ai/Aj/Ak bytes mf_mic_init built for exactly these grids, if every coefficient was +0 or -1 (one small
+// device-to-host read, i.e. a stream synchronisation: call it once per solve); *pack = nullptr otherwise
+int mic_pack_query(const Dim& d, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, const unsigned char** pack,
+                   hipStream_t st) {
+	*pack = nullptr;
+	static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
+	if (nopack || mic_mode_() != 2 || !d.is3d) return 0;
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	if (!f.pack || !f.pack_ok || f.pk_flags != flags || f.pk_Ai != Ai || f.pk_Aj != Aj || f.pk_Ak != Ak) return 0;
+	int ok = 0;
+	MF_HIP(hipMemcpyAsync(&ok, f.pack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	if (ok) *pack = f.pack;
+	return 0;
+}
 int mic_flow_error() {
 	if (mic_mode_() < 1) return 0;
 	int dev = 0;

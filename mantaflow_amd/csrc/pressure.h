@@ -18,6 +18,10 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 // index order by the caller; *ndot == 0 when the active mode cannot fuse it (the caller then runs its own dot kernel)
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                    const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st);
+// packed {fluid, Ai, Aj, Ak} bytes built by the last mf_mic_init for exactly these grids (nullptr when unavailable / not exact);
+// synchronises the stream once
+int mic_pack_query(const Dim& d, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, const unsigned char** pack,
+                   hipStream_t st);
 int mic_mode();          // 0 levels, 1 tiles, 2 rows
 int mic_flow_error();    // reads (and clears) the deadlock-guard flag of the single-launch sweeps; needs a synchronised stream
 }  // namespace mf

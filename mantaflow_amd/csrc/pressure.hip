@@ -107,11 +107,22 @@ __device__ __forceinline__ float wave_shr1(float v) {  // lane l gets lane l-1 (
 __device__ __forceinline__ float wave_shl1(float v) {  // lane l gets lane l+1 (lane 63: unchanged)
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
-template <bool DOT, bool IS3D, int R>
+// PACKED: flags + Ai + Aj + Ak come as one byte per cell (k_mic_pack: fluid bit, "coefficient is -1" bits; only offered by the
+// host when every coefficient is exactly +0 or -1): 5 four-byte loads per thread replace 11 sixteen-byte loads, the values
+// are rebuilt exactly and everything after the load section is shared
+__device__ __forceinline__ int4 unpack_flags(unsigned w) {
+	return make_int4((w & 0x1u) ? MF_FLUID : 0, (w & 0x100u) ? MF_FLUID : 0, (w & 0x10000u) ? MF_FLUID : 0, (w & 0x1000000u) ? MF_FLUID : 0);
+}
+template <unsigned BIT>
+__device__ __forceinline__ float4 unpack_coef(unsigned w) {
+	return make_float4((w & BIT) ? -1.f : 0.f, (w & (BIT << 8)) ? -1.f : 0.f, (w & (BIT << 16)) ? -1.f : 0.f, (w & (BIT << 24)) ? -1.f : 0.f);
+}
+template <bool DOT, bool IS3D, int R, bool PACKED>
 __global__ void __launch_bounds__(BLOCK)
 k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
                   const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
-                  const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb) {
+                  const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb,
+                  const unsigned char* __restrict__ pack) {
 	if (DOT && sc->done) return;
 	const int qx = d.sx >> 2;
 	const int64_t nthr = (int64_t)qx * jgroups * d.sz;
@@ -137,21 +148,35 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	{
 		const int jm = (j0 > 0) ? -1 : 0;
 		sv[0] = *(const float4*)(src + row0 + jm * Y);
-		ajv[0] = *(const float4*)(Aj + row0 + jm * Y);
+		if (PACKED) ajv[0] = unpack_coef<4u>(*(const unsigned*)(pack + row0 + jm * Y));
+		else ajv[0] = *(const float4*)(Aj + row0 + jm * Y);
 	}
 #pragma unroll
 	for (int r = 0; r < R; r++) {
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
 		const int64_t idx = row0 + jr * Y;
-		f[r] = *(const int4*)(flags + idx);
 		sv[r + 1] = *(const float4*)(src + idx);
-		ajv[r + 1] = *(const float4*)(Aj + idx);
 		a0[r] = *(const float4*)(A0 + idx);
-		ai[r] = *(const float4*)(Ai + idx);
+		unsigned pw = 0;
+		if (PACKED) {
+			pw = *(const unsigned*)(pack + idx);
+			f[r] = unpack_flags(pw);
+			ajv[r + 1] = unpack_coef<4u>(pw);
+			ai[r] = unpack_coef<2u>(pw);
+		} else {
+			f[r] = *(const int4*)(flags + idx);
+			ajv[r + 1] = *(const float4*)(Aj + idx);
+			ai[r] = *(const float4*)(Ai + idx);
+		}
 		if (IS3D) {
-			ak[r] = *(const float4*)(Ak + idx);
 			const int64_t im = (k > 0) ? idx - Z : idx, ip = (k < d.sz - 1) ? idx + Z : idx;
-			akm[r] = *(const float4*)(Ak + im);
+			if (PACKED) {
+				ak[r] = unpack_coef<8u>(pw);
+				akm[r] = unpack_coef<8u>(*(const unsigned*)(pack + im));
+			} else {
+				ak[r] = *(const float4*)(Ak + idx);
+				akm[r] = *(const float4*)(Ak + im);
+			}
 			szm[r] = *(const float4*)(src + im);
 			szp[r] = *(const float4*)(src + ip);
 		}
@@ -171,7 +196,8 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 		sr[r] = wave_shl1(sv[r + 1].x);
 		if (edge_l) {
 			sl[r] = (idx > 0) ? src[idx - 1] : 0.f;
-			al[r] = (idx > 0) ? Ai[idx - 1] : 0.f;
+			if (PACKED) al[r] = (idx > 0 && (pack[idx - 1] & 2u)) ? -1.f : 0.f;
+			else al[r] = (idx > 0) ? Ai[idx - 1] : 0.f;
 		}
 		if (edge_r) sr[r] = (idx + 4 < d.n) ? src[idx + 4] : 0.f;
 	}
@@ -272,7 +298,7 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <bool DOT>
 static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, const float* src, const float* A0,
                                const float* Ai, const float* Aj, const float* Ak, double* partials,
-                               const CgScalars* sc, hipStream_t st, int* nblocks) {
+                               const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr) {
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
 	static const int am_rows = [] {
@@ -286,10 +312,12 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
 		const int tpb = (int)((vblocks + MAX_BLOCKS - 1) / MAX_BLOCKS);
 		nb = (int)((vblocks + tpb - 1) / tpb);
 #define AM5(RR)                                                                                                                                   \
-	if (d.is3d)                                                                                                                                   \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb); \
+	if (d.is3d && pack)                                                                                                                           \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack); \
+	else if (d.is3d)                                                                                                                              \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack); \
 	else                                                                                                                                          \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb);
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack);
 		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
 #undef AM5
 	} else if (vec) {
@@ -901,6 +929,9 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
 	hipLaunchKernelGGL(k_cg_begin, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_sig, accuracy, useL2Norm);
 	MF_LAUNCH_CHECK();
+	// ApplyMatrix reads the same packed coefficient bytes as the MIC sweeps when mf_mic_init found the matrix packable
+	const unsigned char* am_pack = nullptr;
+	if (pc == MF_PC_MICP && maxIter > 0) MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &am_pack, st));
 
 	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done`, one batch behind the batch it has just queued
 	// (every kernel of an iteration returns at once when `done` is already set, so running ahead costs a few empty
@@ -920,7 +951,7 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 		const int todo = (maxIter - issued < batch) ? (maxIter - issued) : batch;
 		for (int it = 0; it < todo; it++) {
 			int nba = 0, nsig = 0;
-			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba));
+			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
 				hipLaunchKernelGGL((k_cg_axpy2<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
