@@ -686,12 +686,30 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				}
 			};
 			if (wave <= 3) {
+				// forward sweep, packed operands: a chunk whose 8 cells are all fluid does not need the old dst (it only passes
+				// through non-fluid cells).  Its packed word is fetched one round ahead (wnext, with the previous chunk of this
+				// wave), so the decision costs no extra round trip; the first chunk of a wave loads dst unconditionally.
+				unsigned long long wnext = 0ull;
+				bool have_wnext = false;
 				auto issue = [&](RowsChunk& r, int m) {
 					int64_t rowidx;
 					int nv;
 					chunk_geom(m, rowidx, nv);
+					bool need_dst = true;
 					if (packed) {
-						r.W = nv > 0 ? *(const unsigned long long*)(pack + rowidx) : 0ull;     // sx % 8 == 0: nv is 8 or <= 0
+						if (MODE == 1 && have_wnext) {
+							r.W = wnext;
+							need_dst = (r.W & 0x0101010101010101ull) != 0x0101010101010101ull;
+						} else {
+							r.W = nv > 0 ? *(const unsigned long long*)(pack + rowidx) : 0ull;     // sx % 8 == 0: nv is 8 or <= 0
+						}
+						if (MODE == 1 && m + 3 < nchunks) {
+							int64_t ridx3;
+							int nv3;
+							chunk_geom(m + 3, ridx3, nv3);
+							wnext = nv3 > 0 ? *(const unsigned long long*)(pack + ridx3) : 0ull;
+							have_wnext = true;
+						}
 					} else {
 						load_row8i<VEC, REV>(flags, rowidx, nv, r.F);
 						load_row8<VEC, REV>(Ai, rowidx, nv, r.Ai);
@@ -700,7 +718,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					}
 					if (MODE == 1 || with_dot) load_row8<VEC, REV>(var1, rowidx, nv, r.V);
 					load_row8<VEC, REV>(Ap, rowidx, nv, r.P);
-					load_row8<VEC, REV>(dst, rowidx, nv, r.D);
+					if (need_dst) load_row8<VEC, REV>(dst, rowidx, nv, r.D);
 				};
 				auto commit = [&](const RowsChunk& r, int m) {
 					int64_t rowidx;
