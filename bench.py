@@ -199,7 +199,7 @@ def main():
         apk = core.Grid(s)
         lib.call("mf_mic_init", n, n, n, flags.ptr, apk.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
         us_pk = ctypes.c_double()
-        lib.call("mf_time_apply_matrix", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, 200, ctypes.byref(us_pk), s.stream)
+        lib.call("mf_time_apply_matrix_packed", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, 200, ctypes.byref(us_pk), s.stream)
         del apk
         traffic = None
         tp = os.path.join(ROOT, "profiles", "apply_matrix_traffic.json")

@@ -406,12 +406,15 @@ int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const floa
  * HIP-only helpers (return an error in the CPU libraries)
  * ---------------------------------------------------------------------------------------------- */
 /* average duration in microseconds of `reps` back-to-back launches of the named kernel on `stream`,
- * measured with hipEvents on that stream (used by bench.py for the roofline object).  After mf_mic_init on exactly these
- * flags / Ai / Aj / Ak (and a matrix whose off-diagonals are all +0 or -1) it times the packed-coefficient variant the PCG
- * loop runs; otherwise the general kernel. */
+ * measured with hipEvents on that stream (used by bench.py for the roofline object).  mf_time_apply_matrix times the general
+ * kernel (any matrix); _packed times the packed-coefficient variant the PCG loop runs after mf_mic_init on exactly these
+ * flags / Ai / Aj / Ak when every off-diagonal is +0 or -1, and fails if those packed bytes do not exist. */
 int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src,
                          const float* A0, const float* Ai, const float* Aj, const float* Ak, int reps,
                          double* avg_us_host, void* stream);
+int mf_time_apply_matrix_packed(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src,
+                                const float* A0, const float* Ai, const float* Aj, const float* Ak, int reps,
+                                double* avg_us_host, void* stream);
 
 #ifdef __cplusplus
 }

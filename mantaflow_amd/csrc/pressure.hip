@@ -795,17 +795,19 @@ int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, co
 	return launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, (hipStream_t)stream, nullptr);
 }
 
-int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
-                         const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* stream) {
+static int time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                             const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* stream, bool packed) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	hipStream_t st = (hipStream_t)stream;
+	const unsigned char* pack = nullptr;
+	if (packed) {
+		MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &pack, st));
+		if (!pack) return fail("mf_time_apply_matrix_packed: no packed coefficients for these grids (call mf_mic_init on them; the off-diagonals must all be +0 or -1)");
+	}
 	hipEvent_t e0, e1;
 	MF_HIP(hipEventCreate(&e0));
 	MF_HIP(hipEventCreate(&e1));
-	// after mf_mic_init on exactly these grids (and a packable matrix) this times the variant the PCG loop runs
-	const unsigned char* pack = nullptr;
-	MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &pack, st));
 	for (int i = 0; i < 3; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr, pack));
 	MF_HIP(hipEventRecord(e0, st));
 	for (int i = 0; i < reps; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr, pack));
@@ -817,6 +819,14 @@ int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* ds
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
 	return 0;
+}
+int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                         const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* stream) {
+	return time_apply_matrix(sx, sy, sz, flags, dst, src, A0, Ai, Aj, Ak, reps, avg_us, stream, false);
+}
+int mf_time_apply_matrix_packed(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                                const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* stream) {
+	return time_apply_matrix(sx, sy, sz, flags, dst, src, A0, Ai, Aj, Ak, reps, avg_us, stream, true);
 }
 
 int mf_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj, float* Ak,

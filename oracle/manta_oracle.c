@@ -2735,3 +2735,9 @@ int mf_time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* ds
 	(void)avg_us; (void)st;
 	return fail("mf_time_apply_matrix: HIP only");
 }
+int mf_time_apply_matrix_packed(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                                const float* Ai, const float* Aj, const float* Ak, int reps, double* avg_us, void* st) {
+	(void)sx; (void)sy; (void)sz; (void)flags; (void)dst; (void)src; (void)A0; (void)Ai; (void)Aj; (void)Ak; (void)reps;
+	(void)avg_us; (void)st;
+	return fail("mf_time_apply_matrix_packed: HIP only");
+}
