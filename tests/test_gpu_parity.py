@@ -114,6 +114,32 @@ def test_mic_every_sweep_mode(hip, oracle, dims, mode):
     _close(x, xo, "cg solution " + mode)
 
 
+@pytest.mark.parametrize("dims", [(32, 24, 40), (64, 48, 24)])
+@pytest.mark.parametrize("variant", ["scaled", "one_cell", "minus_zero"])
+def test_mic_and_cg_with_a_matrix_that_cannot_be_packed(hip, oracle, dims, variant):
+    """the packed-operand path (flags + Ai + Aj + Ak as one byte per cell) is taken only when every off-diagonal is exactly +0
+    or -1; a matrix with other values (second-order boundaries scale them by face fractions) must go through the four-array
+    path and still give the serial sweep's bits -- also when a single cell is off, or when a coefficient is -0"""
+    flags, A, src = cases.system_inputs(dims, 5)
+    A = [a.copy() for a in A]
+    if variant == "scaled":
+        A[1] *= np.float32(0.75); A[2] *= np.float32(0.5); A[3] *= np.float32(0.875)
+    elif variant == "one_cell":
+        kk, jj, ii = np.argwhere(A[2] != 0)[len(np.argwhere(A[2] != 0)) // 2]
+        A[2][kk, jj, ii] = np.float32(-0.5)
+    else:
+        A[3][A[3] == 0] = np.float32(-0.0)
+    rhs = cases.cg_rhs(dims, flags, 5)
+    ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
+    xo, sto = cases.run_cg_impl(oracle, dims, flags, A, rhs, 2, 1e-4, 40, 0)
+    ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
+    x, st = cases.run_cg_impl(hip, dims, flags, A, rhs, 2, 1e-4, 40, 0)
+    assert_bitexact(ap, ap_o, "Aprecond")
+    assert_bitexact(dst, dst_o, "mic apply")
+    assert st[0] == sto[0], (st, sto)
+    _close(x, xo, "cg solution")
+
+
 @pytest.mark.parametrize("dims,rows", [((32, 64, 24), 16), ((24, 100, 40), 32), ((40, 72, 17), 24)])
 def test_mic_blocked_sweeps_equal_serial_sweep_of_cut_system(hip, oracle, dims, rows):
     """mf_set_mic_blocking (multi-GPU block-Jacobi in y): with the Aj coupling zeroed at the block faces the row-streaming
