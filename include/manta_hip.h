@@ -113,6 +113,12 @@ int mf_grid_mult(int64_t n, float* me, const float* other, void* stream);
 /* ApplyMatrix / ApplyMatrix2D (sz==1), conjugategrad.h:118-151.  28 B/cell algorithmic traffic. */
 int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src,
                     const float* A0, const float* Ai, const float* Aj, const float* Ak, void* stream);
+/* Optional accelerator for repeated mf_apply_matrix calls on one matrix: packs flags + Ai + Aj + Ak into one byte per cell
+ * (valid only if every off-diagonal is exactly +0 or -1, checked here; one stream synchronisation).  Later mf_apply_matrix
+ * calls with exactly these pointers read 13 instead of 28 B per cell; results are bit-identical.  The grids must not change
+ * while the packed bytes are in use; a new call replaces them. */
+int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak,
+                   void* stream);
 /* MakeLaplaceMatrix, conjugategrad.h:154-187.  A0..Ak must be zeroed by the caller (fresh temp grids).
  * fractions: nullable SoA MAC grid. */
 int mf_make_laplace_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0, float* Ai, float* Aj,

@@ -978,6 +978,12 @@ struct FlowState {
 	int* pack_ok = nullptr;
 	size_t pack_cap = 0;
 	const void *pk_flags = nullptr, *pk_Ai = nullptr, *pk_Aj = nullptr, *pk_Ak = nullptr;
+	// a second set of packed bytes, built on request (mf_pack_matrix) for the plain mf_apply_matrix entry point
+	unsigned char* upack = nullptr;
+	int* upack_ok = nullptr;
+	size_t upack_cap = 0;
+	int upack_ok_host = 0;
+	const void *up_flags = nullptr, *up_Ai = nullptr, *up_Aj = nullptr, *up_Ak = nullptr;
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
@@ -1152,6 +1158,36 @@ extern "C" int mf_set_mic_mode(const char* name) {
 	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
 	else if (!strcmp(name, "rows")) g_mic_mode = 2;
 	else return fail("mf_set_mic_mode: unknown mode (rows | tiles | levels)");
+	return 0;
+}
+extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	hipStream_t st = (hipStream_t)stream;
+	f.upack_ok_host = 0;
+	static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
+	if (nopack || !d.is3d || (d.sx % 4) != 0) return 0;
+	if ((size_t)d.n > f.upack_cap) {
+		MF_HIP(hipStreamSynchronize(st));
+		if (f.upack) MF_HIP(hipFree(f.upack));
+		MF_HIP(hipMalloc((void**)&f.upack, (size_t)d.n + 64));
+		f.upack_cap = (size_t)d.n;
+	}
+	if (!f.upack_ok) MF_HIP(hipMalloc((void**)&f.upack_ok, sizeof(int)));
+	MF_HIP(hipMemsetAsync(f.upack_ok, 1, sizeof(int), st));
+	hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, flags, Ai, Aj, Ak, f.upack, f.upack_ok);
+	MF_LAUNCH_CHECK();
+	int ok = 0;
+	MF_HIP(hipMemcpyAsync(&ok, f.upack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+	MF_HIP(hipStreamSynchronize(st));
+	f.upack_ok_host = ok != 0;
+	f.up_flags = flags;
+	f.up_Ai = Ai;
+	f.up_Aj = Aj;
+	f.up_Ak = Ak;
 	return 0;
 }
 extern "C" int mf_set_mic_blocking_x(int cells_x) {
@@ -1341,6 +1377,14 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* Ai, const fl
 	MF_HIP(hipStreamSynchronize(st));
 	if (ok) *pack = f.pack;
 	return 0;
+}
+// packed bytes built by mf_pack_matrix for exactly these grids (no synchronisation: the verdict was read when they were built)
+const unsigned char* mic_pack_user(const int32_t* flags, const float* Ai, const float* Aj, const float* Ak) {
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+	FlowState& f = g_flow[dev];
+	if (!f.upack || !f.upack_ok_host || f.up_flags != flags || f.up_Ai != Ai || f.up_Aj != Aj || f.up_Ak != Ak) return nullptr;
+	return f.upack;
 }
 int mic_flow_error() {
 	if (mic_mode_() < 1) return 0;

@@ -22,6 +22,8 @@ int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* 
 // synchronises the stream once
 int mic_pack_query(const Dim& d, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, const unsigned char** pack,
                    hipStream_t st);
+// packed bytes built by mf_pack_matrix for exactly these grids, or nullptr (no synchronisation)
+const unsigned char* mic_pack_user(const int32_t* flags, const float* Ai, const float* Aj, const float* Ak);
 int mic_mode();          // 0 levels, 1 tiles, 2 rows
 int mic_flow_error();    // reads (and clears) the deadlock-guard flag of the single-launch sweeps; needs a synchronised stream
 }  // namespace mf

@@ -792,7 +792,7 @@ int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, co
                     const float* Ai, const float* Aj, const float* Ak, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
-	return launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, (hipStream_t)stream, nullptr);
+	return launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, (hipStream_t)stream, nullptr, mic_pack_user(flags, Ai, Aj, Ak));
 }
 
 static int time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,

@@ -43,6 +43,10 @@ int mf_mic_check(void* stream) {
 	(void)stream;
 	return 0;
 }
+int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, void* st) {
+	(void)sx; (void)sy; (void)sz; (void)flags; (void)Ai; (void)Aj; (void)Ak; (void)st; /* an accelerator of the HIP library only */
+	return 0;
+}
 int mf_set_mic_blocking_x(int cells_x) {
 	(void)cells_x; /* the serial sweep needs no schedule: it runs over whatever coefficients it is given */
 	return 0;

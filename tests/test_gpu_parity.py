@@ -114,6 +114,35 @@ def test_mic_every_sweep_mode(hip, oracle, dims, mode):
     _close(x, xo, "cg solution " + mode)
 
 
+@pytest.mark.parametrize("dims", [(32, 24, 40), (64, 48, 24), (36, 20, 17)])
+def test_apply_matrix_with_packed_coefficients(hip, oracle, dims):
+    """mf_pack_matrix: mf_apply_matrix on the packed {fluid, Ai, Aj, Ak} bytes gives the bits of the general kernel and of the
+    oracle; a matrix that is not all 0 / -1 is refused (the general kernel keeps running), other pointers are not affected"""
+    sx, sy, sz = dims
+    flags, A, src = cases.system_inputs(dims, 6)
+    want = cases.run_apply_matrix_impl(oracle, dims, flags, A, src)
+    f, s_, dA = hip.dev(flags), hip.dev(src), [hip.dev(a) for a in A]
+    dst = hip.dev(np.full((sz, sy, sx), 7.0, np.float32))
+    hip.call("mf_apply_matrix", sx, sy, sz, f, dst, s_, *dA, None)
+    hip.sync()
+    assert_bitexact(hip.host(dst), want, "general kernel")
+    hip.call("mf_pack_matrix", sx, sy, sz, f, dA[1], dA[2], dA[3], None)
+    dst2 = hip.dev(np.full((sz, sy, sx), 7.0, np.float32))
+    hip.call("mf_apply_matrix", sx, sy, sz, f, dst2, s_, *dA, None)
+    hip.sync()
+    assert_bitexact(hip.host(dst2), want, "packed kernel")
+    # a matrix with other values: the packed bytes are refused, the result is still right
+    B = [a.copy() for a in A]
+    B[2] *= np.float32(0.5)
+    wantB = cases.run_apply_matrix_impl(oracle, dims, flags, B, src)
+    dB = [hip.dev(b) for b in B]
+    hip.call("mf_pack_matrix", sx, sy, sz, f, dB[1], dB[2], dB[3], None)
+    dst3 = hip.dev(np.full((sz, sy, sx), 7.0, np.float32))
+    hip.call("mf_apply_matrix", sx, sy, sz, f, dst3, s_, *dB, None)
+    hip.sync()
+    assert_bitexact(hip.host(dst3), wantB, "scaled matrix after mf_pack_matrix")
+
+
 @pytest.mark.parametrize("dims", [(32, 24, 40), (64, 48, 24)])
 @pytest.mark.parametrize("variant", ["scaled", "one_cell", "minus_zero"])
 def test_mic_and_cg_with_a_matrix_that_cannot_be_packed(hip, oracle, dims, variant):
