@@ -163,6 +163,11 @@ int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, c
  * dst keeps its previous content in non-fluid cells, exactly like the reference. */
 int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1,
                  const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, void* stream);
+/* mf_mic_apply followed by dot_dev[0] = GridDotProduct(dst, var1) over the whole grid (fp32 products, fp64 sum), the sum
+ * coming out of the backward sweep when the active sweep mode can fuse it */
+int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1,
+                         const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
+                         void* stream);
 
 /* GridCg<ApplyMatrix>::doInit + iterate loop, conjugategrad.cpp:210-307, driven like
  * solvePressureSystem's loop (plugin/pressure.cpp:438-441).
@@ -392,7 +397,8 @@ int mf_grid_dot_dev(int64_t n, const float* a, const float* b, double* out_dev, 
 int mf_grid_max_abs_dev(int64_t n, const float* a, float* out_dev, void* stream);
 int mf_grid_max_abs_dev_f64(int64_t n, const float* a, double* out_dev, void* stream);
 /* scalar steps of GridCg::iterate (conjugategrad.cpp:250-291) on the all-gathered per-rank pairs
- * gathered[world][2] = {max|residual|, dot}: alpha = sigma / (Real)sum(dot) (0 if the sum is 0);
+ * gathered[world][2] = {max|residual|, dot}: alpha = sigma / (Real)sum(dot) (0 if the sum is 0), also stored negated at
+ * alpha_dev[1];
  * beta = (Real)sum(dot) / sigma, sigma := (Real)sum(dot), res = max over ranks.  Rows are combined in rank order.
  * state_dev (nullable) = int32[2] {stop, iteration}: the stopping test of GridCg::iterate (:262-272) evaluated on the
  * device so that the host need not read a scalar every iteration.  beta sets {1, iter} the first time res < accuracy and
@@ -403,6 +409,17 @@ int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, 
                      const int32_t* state_dev, void* stream);
 int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev,
                     float accuracy, int iter, int32_t* state_dev, void* stream);
+/* fused pieces of one slab PCG iteration.  `scalars` points to a device block laid out as
+ *   float sigma, alpha, nalpha, beta, resNorm, dp, sigmaNew, accuracy; int32 iterations, done, diverged, useL2
+ * (zero-initialised by the caller; mf_cg_slab_alpha writes alpha and nalpha = -alpha, mf_cg_slab_beta sigma / beta / resNorm):
+ *   mf_apply_matrix_dot_dev : dst = A src (mf_apply_matrix) and dot_dev[0] = sum over the planes [k0, k1) of dst*src (fp32
+ *                             products summed in fp64, GridDotProduct) -- a slab's own planes, not its ghosts
+ *   mf_cg_slab_axpy2        : x += alpha*search ; residual += nalpha*tmp ; maxabs_dev[0] = max |residual| over the n cells */
+int mf_apply_matrix_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src,
+                            const float* A0, const float* Ai, const float* Aj, const float* Ak, int k0, int k1,
+                            const void* scalars, double* dot_dev, void* stream);
+int mf_cg_slab_axpy2(int64_t n, const void* scalars, float* x, const float* search, float* residual,
+                     const float* tmp, double* maxabs_dev, void* stream);
 /* me += (sign * factor_dev[0]) * other, sign = +-1 */
 int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor_dev, float sign, void* stream);
 /* dst = src + factor_dev[0] * dst */

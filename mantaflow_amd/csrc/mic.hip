@@ -1455,6 +1455,39 @@ int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const
 	return mic_launch(2, d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
 }
 
+// one-block sum of the per-bundle dot partials (index order) -- or, without fusion, a plain dot over the grid
+__global__ void __launch_bounds__(BLOCK) k_mic_fin_sum(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+	double acc = strided_sum(partials, nb);
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) out[0] = acc;
+}
+__global__ void __launch_bounds__(BLOCK) k_mic_plain_dot(int64_t n, const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ partials) {
+	double acc = 0.0;
+	for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) acc += (double)(a[i] * b[i]);
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
+                         const float* Ai, const float* Aj, const float* Ak, double* dot_dev, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (!d.is3d) return fail("mICP only supports 3D grids so far");
+	hipStream_t st = (hipStream_t)stream;
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	double* part = ws->partials + 2 * MAX_BLOCKS;
+	MF_TRY(mic_launch(1, d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, st));
+	int nsig = 0;
+	MF_TRY(mic_launch_dot(d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, part, &nsig, st));
+	if (nsig == 0) {
+		nsig = blocks_for(d.n, BLOCK * 4, 2048);
+		hipLaunchKernelGGL(k_mic_plain_dot, dim3(nsig), dim3(BLOCK), 0, st, d.n, dst, var1, part);
+	}
+	hipLaunchKernelGGL(k_mic_fin_sum, dim3(1), dim3(BLOCK), 0, st, nsig, part, dot_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
 // a dataflow sweep that gives up waiting for a face (FLOW_SPIN_LIMIT) latches an error flag on the device; mf_cg_solve
 // looks at it itself, callers that drive mf_mic_apply directly (the z-slab solver) ask here once per solve
 int mf_mic_check(void* stream) {

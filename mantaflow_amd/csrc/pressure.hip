@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
                   const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
                   const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb,
-                  const unsigned char* __restrict__ pack) {
+                  const unsigned char* __restrict__ pack, int dk0, int dk1) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
 	if (DOT && sc->done) return;
 	const int qx = d.sx >> 2;
 	const int64_t nthr = (int64_t)qx * jgroups * d.sz;
@@ -241,7 +241,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 		}
 		if (live) {
 			*(float4*)(dst + row0 + r * Y) = res;
-			if (DOT) {
+			if (DOT && k >= dk0 && k < dk1) {
 				const float p0 = res.x * s.x, p1 = res.y * s.y, p2 = res.z * s.z, p3 = res.w * s.w;
 				acc += (double)p0;
 				acc += (double)p1;
@@ -298,7 +298,9 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <bool DOT>
 static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, const float* src, const float* A0,
                                const float* Ai, const float* Aj, const float* Ak, double* partials,
-                               const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr) {
+                               const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr,
+                               int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr) {
+	if (ranged) *ranged = false;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
 	static const int am_rows = [] {
@@ -313,13 +315,14 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
 		nb = (int)((vblocks + tpb - 1) / tpb);
 #define AM5(RR)                                                                                                                                   \
 	if (d.is3d && pack)                                                                                                                           \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1); \
 	else if (d.is3d)                                                                                                                              \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1); \
 	else                                                                                                                                          \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack);
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1);
 		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
 #undef AM5
+		if (ranged) *ranged = true;
 	} else if (vec) {
 		const int64_t nq = d.n >> 2;
 		const int qpt = (int)((nq + (int64_t)BLOCK * MAX_BLOCKS - 1) / ((int64_t)BLOCK * MAX_BLOCKS));
@@ -769,6 +772,25 @@ k_cg_update_search(int64_t n, CgScalars* __restrict__ sc, float* __restrict__ se
 	}
 }
 
+// one-block finishers of the slab entry points
+__global__ void __launch_bounds__(BLOCK) k_fin_sum(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+	double acc = strided_sum(partials, nb);
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) out[0] = acc;
+}
+__global__ void __launch_bounds__(BLOCK) k_fin_maxabs(int nb, const float* __restrict__ fpart, double* __restrict__ out) {
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+		lo = fminf(lo, fpart[2 * i]);
+		hi = fmaxf(hi, fpart[2 * i + 1]);
+	}
+	block_minmax(lo, hi);
+	if (threadIdx.x == 0) {
+		const float alo = fabsf(lo), ahi = fabsf(hi);
+		out[0] = (double)(alo > ahi ? alo : ahi);
+	}
+}
+
 // cgSolveDiffusion matrix set-up, conjugategrad.cpp:364-375
 __global__ void __launch_bounds__(BLOCK)
 k_diffusion_matrix(int64_t n, const int32_t* __restrict__ flags, float* __restrict__ A0, float* __restrict__ Ai, float* __restrict__ Aj,
@@ -896,6 +918,50 @@ int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float*
 	const Dim d = mkdim(sx, sy, sz);
 	if (fixPidx - d.Y < 0 || fixPidx + d.Y >= d.n || fixPidx - d.Z < 0 || fixPidx + d.Z >= d.n) return fail("fixPressure: cell %lld on the domain border", (long long)fixPidx);
 	hipLaunchKernelGGL(k_fix_pressure, dim3(1), dim3(1), 0, (hipStream_t)stream, d, fixPidx, value, rhs, A0, Ai, Aj, Ak);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+// ---- fused pieces of the z-slab PCG (mantaflow_amd/slab.py): scalars live in a CgScalars-layout device block ----
+int mf_apply_matrix_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                            const float* Ai, const float* Aj, const float* Ak, int k0, int k1, const void* scalars, double* dot_dev,
+                            void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	if (k0 < 0 || k1 > sz || k0 > k1) return fail("mf_apply_matrix_dot_dev: invalid plane range");
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	const CgScalars* sc = (const CgScalars*)scalars;
+	int nb = 0;
+	bool ranged = false;
+	MF_TRY(launch_apply_matrix<true>(d, flags, dst, src, A0, Ai, Aj, Ak, ws->partials, sc, st, &nb, mic_pack_user(flags, Ai, Aj, Ak), k0, k1, &ranged));
+	if (!ranged) {
+		// the fallback kernels sum over the whole grid: redo the dot over the requested planes
+		const int64_t XY = (int64_t)sx * sy, n = (int64_t)(k1 - k0) * XY;
+		nb = blocks_for(n >> 2, BLOCK, 2048);
+		hipLaunchKernelGGL(k_cg_dot, dim3(nb), dim3(BLOCK), 0, st, n, sc, dst + k0 * XY, src + k0 * XY, ws->partials);
+	}
+	hipLaunchKernelGGL(k_fin_sum, dim3(1), dim3(BLOCK), 0, st, nb, ws->partials, dot_dev);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_cg_slab_axpy2(int64_t n, const void* scalars, float* x, const float* search, float* residual, const float* tmp,
+                     double* maxabs_dev, void* stream) {
+	if (n <= 0) return 0;
+	hipStream_t st = (hipStream_t)stream;
+	if (!(al16(x) && al16(search) && al16(residual) && al16(tmp))) {
+		// views that do not start on a 16-byte boundary (odd plane sizes): the unfused sequence
+		const float* alpha_dev = &((const CgScalars*)scalars)->alpha;
+		MF_TRY(mf_grid_scaled_add_dev(n, x, search, alpha_dev, 1.f, stream));
+		MF_TRY(mf_grid_scaled_add_dev(n, residual, tmp, alpha_dev, -1.f, stream));
+		return mf_grid_max_abs_dev_f64(n, residual, maxabs_dev, stream);
+	}
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	const int nb = blocks_for(n >> 2, BLOCK, 2048);
+	hipLaunchKernelGGL((k_cg_axpy2<false>), dim3(nb), dim3(BLOCK), 0, st, n, (const CgScalars*)scalars, x, search, residual, (float*)tmp, ws->fpartials, ws->partials + MAX_BLOCKS);
+	hipLaunchKernelGGL(k_fin_maxabs, dim3(1), dim3(BLOCK), 0, st, nb, ws->fpartials, maxabs_dev);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

@@ -235,12 +235,15 @@ __global__ void k_slab_alpha(const double* __restrict__ g, int world, const floa
                              const int32_t* __restrict__ state) {
 	if (state && state[0]) {
 		alpha[0] = 0.f;
+		alpha[1] = -0.f;
 		return;
 	}
 	double acc = 0.0;
 	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
 	const float dp = (float)acc;
-	alpha[0] = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
+	const float a = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
+	alpha[0] = a;
+	alpha[1] = -a;      // nalpha of the CgScalars layout (mf_cg_slab_axpy2)
 }
 __global__ void k_slab_beta(const double* __restrict__ g, int world, float* __restrict__ sigma, float* __restrict__ beta, float* __restrict__ res,
                             float accuracy, int iter, int32_t* __restrict__ state) {

@@ -202,7 +202,6 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     rhs, residual, search, tmp, A0, Ai, Aj, Ak, Akm, Ap = (G(s) for _ in range(10))
     lib.call("mf_make_rhs", sx, sy, sz, flags.ptr, rhs.ptr, vel.ptr, None, None, None, None, None, 0.0, 1e-4, None, None, st)
     lib.call("mf_make_laplace_matrix", sx, sy, sz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, st)
-    lib.call("mf_pack_matrix", sx, sy, sz, flags.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)      # ApplyMatrix reads 13 instead of 28 B per cell
     # slab-local MIC: ghost planes are not part of the block, the coupling across the slab faces is cut
     fmic = core.FlagGrid(s)
     fmic.copyFrom(flags)
@@ -211,6 +210,11 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         fv[:dom.gl] = core.TypeObstacle
     if dom.gu:
         fv[dom.gl + dom.nown:] = core.TypeObstacle
+    # ApplyMatrix runs with these flags too: on the ghost planes it then passes `search` through instead of applying the stencil
+    # (nothing there is needed; the outermost ghost plane has no neighbour plane to read, and the fused dot products below
+    # multiply those values with the zero residual of the ghost planes), the owned planes are unaffected (the stencil never
+    # looks at a neighbour's flags)
+    lib.call("mf_pack_matrix", sx, sy, sz, fmic.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)       # 13 instead of 28 B per cell
     Akm.copyFrom(Ak)
     av = Akm.data.view(sz, XY)
     if dom.gl:
@@ -250,8 +254,11 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     dev = s.device
     world = dom.comm.world
     red = torch.zeros(2, dtype=torch.float64, device=dev)     # {max|residual|, dot} of this rank
-    sc = torch.zeros(4, dtype=torch.float32, device=dev)      # sigma, alpha, beta, resNorm
-    p_sigma, p_alpha, p_beta, p_res = (ctypes.c_void_p(sc.data_ptr() + 4 * i) for i in range(4))
+    # the scalar block of include/manta_hip.h (CgScalars layout): sigma, alpha, nalpha, beta, resNorm, ... (fp32 like the
+    # reference's Real members)
+    sc = torch.zeros(12, dtype=torch.float32, device=dev)
+    p_sc = ctypes.c_void_p(sc.data_ptr())
+    p_sigma, p_alpha, p_beta, p_res = (ctypes.c_void_p(sc.data_ptr() + 4 * i) for i in (0, 1, 3, 4))
     p_red0, p_red1 = ctypes.c_void_p(red.data_ptr()), ctypes.c_void_p(red.data_ptr() + 8)
 
     def dot_own(a, b):
@@ -284,15 +291,15 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     iters, resNorm, stop = 0, 1e20, 0
     for it in range(1, maxIter + 1):
         dom.exchange(search, 1)
-        lib.call("mf_apply_matrix", sx, sy, sz, flags.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)
-        dot_own(tmp, search)
+        # tmp = A search with dot(tmp, search) over the owned planes fused in; x += alpha search, r -= alpha tmp with max|r| fused in
+        lib.call("mf_apply_matrix_dot_dev", sx, sy, sz, fmic.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr,
+                 dom.gl, dom.gl + dom.nown, p_sc, p_red1, st)
         g1 = dom.comm.allgather_dev(red)
         lib.call("mf_cg_slab_alpha", _ptr(g1), world, p_sigma, p_alpha, p_state, st)   # conjugategrad.cpp:252-254
-        lib.call("mf_grid_scaled_add_dev", nown, _off(pressure.data, off), _off(search.data, off), p_alpha, 1.0, st)
-        lib.call("mf_grid_scaled_add_dev", nown, _off(residual.data, off), _off(tmp.data, off), p_alpha, -1.0, st)
-        mic(tmp, residual)
-        lib.call("mf_grid_max_abs_dev_f64", nown, _off(residual.data, off), p_red0, st)
-        dot_own(tmp, residual)
+        lib.call("mf_cg_slab_axpy2", nown, p_sc, _off(pressure.data, off), _off(search.data, off), _off(residual.data, off),
+                 _off(tmp.data, off), p_red0, st)
+        # tmp = M^-1 residual with dot(tmp, residual) fused in (the residual is zero on the ghost planes: the sum is the owned one)
+        lib.call("mf_mic_apply_dot_dev", sx, sy, sz, fmic.ptr, tmp.ptr, residual.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, p_red1, st)
         g2 = dom.comm.allgather_dev(red)
         lib.call("mf_cg_slab_beta", _ptr(g2), world, p_sigma, p_beta, p_res, acc32, it, p_state, st)
         lib.call("mf_update_search_vec_dev", nown, _off(search.data, off), _off(tmp.data, off), p_beta, st)
@@ -304,7 +311,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
                 iters = at
                 break
             iters = it
-    resNorm = float(sc[3])
+    resNorm = float(sc[4])
     if stop == 2:
         raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     lib.call("mf_set_mic_blocking", 0)

@@ -47,6 +47,16 @@ int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai
 	(void)sx; (void)sy; (void)sz; (void)flags; (void)Ai; (void)Aj; (void)Ak; (void)st; /* an accelerator of the HIP library only */
 	return 0;
 }
+int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
+                         const float* Ai, const float* Aj, const float* Ak, double* dot, void* st) {
+	int rc = mf_mic_apply(sx, sy, sz, flags, dst, var1, Aprecond, Ai, Aj, Ak, st);
+	if (rc) return rc;
+	const int64_t n = (int64_t)sx * sy * sz;
+	double acc = 0.0;
+	for (int64_t i = 0; i < n; i++) acc += (double)(dst[i] * var1[i]);
+	dot[0] = acc;
+	return 0;
+}
 int mf_set_mic_blocking_x(int cells_x) {
 	(void)cells_x; /* the serial sweep needs no schedule: it runs over whatever coefficients it is given */
 	return 0;
@@ -2694,12 +2704,44 @@ int mf_cg_slab_alpha(const double* g, int world, const float* sigma, float* alph
 	(void)s;
 	if (state && state[0]) {
 		alpha[0] = 0.f;
+		alpha[1] = -0.f;
 		return 0;
 	}
 	double acc = 0.0;
 	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
 	const float dp = (float)acc;
 	alpha[0] = (fabs((double)dp) > 0.) ? sigma[0] / dp : 0.f;
+	alpha[1] = -alpha[0]; /* nalpha of the scalar block (mf_cg_slab_axpy2) */
+	return 0;
+}
+int mf_apply_matrix_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
+                            const float* Ai, const float* Aj, const float* Ak, int k0, int k1, const void* scalars, double* dot,
+                            void* st) {
+	(void)scalars;
+	if (k0 < 0 || k1 > sz || k0 > k1) return fail("mf_apply_matrix_dot_dev: invalid plane range");
+	int rc = mf_apply_matrix(sx, sy, sz, flags, dst, src, A0, Ai, Aj, Ak, st);
+	if (rc) return rc;
+	const int64_t XY = (int64_t)sx * sy;
+	double acc = 0.0;
+	for (int64_t i = k0 * XY; i < k1 * XY; i++) acc += (double)(dst[i] * src[i]);
+	dot[0] = acc;
+	return 0;
+}
+int mf_cg_slab_axpy2(int64_t n, const void* scalars, float* x, const float* search, float* residual, const float* tmp,
+                     double* maxabs, void* st) {
+	(void)st;
+	const float alpha = ((const float*)scalars)[1], nalpha = ((const float*)scalars)[2];
+	float lo = 3.402823466e38f, hi = -3.402823466e38f;
+	for (int64_t i = 0; i < n; i++) {
+		x[i] = x[i] + alpha * search[i];
+		const float r = residual[i] + nalpha * tmp[i];
+		residual[i] = r;
+		lo = r < lo ? r : lo;
+		hi = r > hi ? r : hi;
+	}
+	lo = fabsf(lo);
+	hi = fabsf(hi);
+	maxabs[0] = n > 0 ? (double)(lo > hi ? lo : hi) : 0.0;
 	return 0;
 }
 int mf_cg_slab_beta(const double* g, int world, float* sigma, float* beta, float* res, float accuracy, int iter, int32_t* state,
