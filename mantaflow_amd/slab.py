@@ -32,7 +32,7 @@ from .core import _ptr
 
 STOP_POLL = 4          # slab PCG: iterations between two host reads of the device-side stop state
 MIC_BLOCK_CELLS_X = int(os.environ.get("MF_SLAB_XBLOCK", "128"))   # x-extent of a preconditioner block for P > 1 (0 = whole rows)
-MIC_BLOCK_ROWS = 64   # y-extent of a preconditioner block when the domain is split over several ranks (0 = do not cut)
+MIC_BLOCK_ROWS = int(os.environ.get("MF_SLAB_YBLOCK", "64"))   # y-extent of a preconditioner block when the domain is split over several ranks (0 = do not cut)
 
 
 def _off(t, nelem):
