@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Focused launcher for rocprofv3: runs one hot kernel family at 256^3 so kernel-trace / PMC output stays small.
-  python3 tools/prof_kernels.py apply_matrix [reps]   |   mic [reps]   |   advect
+  python3 tools/prof_kernels.py apply_matrix [reps] | apply_matrix_packed [reps] | mic [reps] | flip | dam | wavelet | advect
 """
 import ctypes
 import os
@@ -51,6 +51,12 @@ def main():
         us = ctypes.c_double()
         lib.call("mf_time_apply_matrix", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, reps, ctypes.byref(us), s.stream)
         print("apply_matrix avg %.2f us  %.1f GB/s" % (us.value, 28 * n ** 3 / us.value / 1e3))
+    elif what == "apply_matrix_packed":
+        # the variant the PCG loop runs: flags + Ai + Aj + Ak packed into one byte per cell by mf_mic_init
+        lib.call("mf_mic_init", n, n, n, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        us = ctypes.c_double()
+        lib.call("mf_time_apply_matrix_packed", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, reps, ctypes.byref(us), s.stream)
+        print("apply_matrix (packed) avg %.2f us  %.1f GB/s of its 13 B per cell" % (us.value, 13 * n ** 3 / us.value / 1e3))
     elif what == "mic":
         lib.call("mf_mic_init", n, n, n, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
         torch.cuda.synchronize()
