@@ -330,6 +330,12 @@ int mf_update_velocity_from_delta_pos(int64_t np, int64_t pstride, const float* 
 /* eulerStep -> KnStepEuler, ptsplugins.cpp:43-53 */
 int mf_euler_step(int64_t np, int64_t pstride, float* pos, const float* pvel, float dt, const int32_t* ptype,
                   int exclude, void* stream);
+/* Shape::computeLevelset -> generateLevelset (shapes.cpp): signed distance at the cell centres.
+ *   kind 0 Box      (BoxSDF :178-229)       params: p0.xyz, p1.xyz
+ *   kind 1 Sphere   (SphereSDF :303-307)    params: center.xyz, radius, scale.xyz
+ *   kind 2 Cylinder (CylinderSDF :367-385)  params: center.xyz, radius, zaxis.xyz (already normalised), zlen
+ * params_host: 12 floats read on the host at call time. */
+int mf_shape_levelset(int sx, int sy, int sz, int kind, const float* params_host, float* phi, void* stream);
 /* resetOutflow, extforces.cpp:134-161: outflow cells get (flags | Empty) & ~Fluid, phi = 0.5, real = 0 (phi / real
  * nullable); active particles that lie inside the grid in an outflow cell are flagged PDELETE (np 0 / pos NULL: none).
  * The reference then compacts the particle array (doCompress); here deleted particles stay flagged and are skipped. */

@@ -171,6 +171,77 @@ __global__ void __launch_bounds__(BLOCK) k_set_bound(Dim d, float* __restrict__ 
 	if (bnd) g[idx] = value;
 }
 
+// ---- shape level sets, shapes.cpp:178-229 (Box), 303-307 (Sphere), 367-385 (Cylinder); fp32, left to right ----
+#define HD __device__ __forceinline__
+#define FMAX(a, b) ((a) > (b) ? (a) : (b))
+#define FMIN(a, b) ((a) < (b) ? (a) : (b))
+#define SQRT(a) sqrtf(a)
+#define FABS(a) fabsf(a)
+
+static HD float shape_sdf_box(int is3d, const float* q, float x, float y, float z) {
+	const float x1 = q[0], y1 = q[1], z1 = q[2], x2 = q[3], y2 = q[4], z2 = q[5];
+	const int inx = (x <= x2) && (x >= x1), iny = (y <= y2) && (y >= y1), inz = (z <= z2) && (z >= z1);
+	const float mx = FMAX(x - x2, x1 - x), my = FMAX(y - y2, y1 - y), mz = FMAX(z - z2, z1 - z);
+	if (inx && iny && inz) return FMAX(mx, FMAX(my, is3d ? mz : mx));
+	if (iny && inz) return mx;
+	if (inx && inz) return my;
+	if (inx && iny) return mz;
+#define SQ(a) ((a) * (a))
+	if (x > x1 && x < x2) {
+		const float a = SQRT(SQ(y1 - y) + SQ(z1 - z)), b = SQRT(SQ(y2 - y) + SQ(z1 - z)), c = SQRT(SQ(y1 - y) + SQ(z2 - z)), d = SQRT(SQ(y2 - y) + SQ(z2 - z));
+		return FMIN(FMIN(FMIN(a, b), c), d);
+	}
+	if (y > y1 && y < y2) {
+		const float a = SQRT(SQ(x1 - x) + SQ(z1 - z)), b = SQRT(SQ(x2 - x) + SQ(z1 - z)), c = SQRT(SQ(x1 - x) + SQ(z2 - z)), d = SQRT(SQ(x2 - x) + SQ(z2 - z));
+		return FMIN(FMIN(FMIN(a, b), c), d);
+	}
+	if (z > x1 && z < z2) { /* sic: the reference tests z against x1 (shapes.cpp:214) */
+		const float a = SQRT(SQ(y1 - y) + SQ(x1 - x)), b = SQRT(SQ(y2 - y) + SQ(x1 - x)), c = SQRT(SQ(y1 - y) + SQ(x2 - x)), d = SQRT(SQ(y2 - y) + SQ(x2 - x));
+		return FMIN(FMIN(FMIN(a, b), c), d);
+	}
+	float best = 0.f;
+	int first = 1;
+	for (int ix = 0; ix < 2; ix++)
+		for (int iy = 0; iy < 2; iy++)
+			for (int iz = 0; iz < 2; iz++) {
+				const float cx = ix ? x2 : x1, cy = iy ? y2 : y1, cz = iz ? z2 : z1;
+				const float dd = SQRT(SQ(x - cx) + SQ(y - cy) + SQ(z - cz));
+				best = first ? dd : FMIN(best, dd);
+				first = 0;
+			}
+	return best;
+}
+static HD float shape_sdf_sphere(const float* q, float x, float y, float z) {
+	const float a = (x - q[0]) / q[4], b = (y - q[1]) / q[5], c = (z - q[2]) / q[6];
+	return SQRT(a * a + b * b + c * c) - q[3];
+}
+static HD float shape_sdf_cylinder(const float* q, float x, float y, float z) {
+	const float px = x - q[0], py = y - q[1], pz = z - q[2];
+	const float zz = FABS(px * q[4] + py * q[5] + pz * q[6]);
+	const float r = SQRT(px * px + py * py + pz * pz - zz * zz); /* NaN when rounding makes the difference negative */
+	const float R = q[3], Z = q[7];
+	if (zz < Z) {
+		if (r < R) return FMAX(r - R, zz - Z);
+		return r - R;
+	}
+	if (r < R) return FABS(zz - Z);
+	return SQRT(SQ(zz - Z) + SQ(r - R));
+#undef SQ
+}
+#undef HD
+#undef FMAX
+#undef FMIN
+#undef SQRT
+#undef FABS
+struct ShapeParams {
+	float q[12];
+};
+__global__ void __launch_bounds__(BLOCK) k_shape_levelset(Dim d, int kind, ShapeParams P, float* __restrict__ phi) {
+	CELL_IJK(d)
+	const float x = (float)i + 0.5f, y = (float)j + 0.5f, z = (float)k + 0.5f;
+	phi[idx] = kind == 0 ? shape_sdf_box(d.is3d, P.q, x, y, z) : (kind == 1 ? shape_sdf_sphere(P.q, x, y, z) : shape_sdf_cylinder(P.q, x, y, z));
+}
+
 // resetOutflow, extforces.cpp:134-161
 __global__ void __launch_bounds__(BLOCK) k_reset_outflow_parts(Dim d, const int32_t* __restrict__ flags, int64_t np, int64_t ps,
                                                                const float* __restrict__ pos, int32_t* __restrict__ pflag) {
@@ -429,6 +500,16 @@ int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boun
 	return 0;
 }
 
+int mf_shape_levelset(int sx, int sy, int sz, int kind, const float* params_host, float* phi, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (kind < 0 || kind > 2) return fail("mf_shape_levelset: unknown shape kind");
+	const Dim d = mkdim(sx, sy, sz);
+	ShapeParams P;
+	for (int q = 0; q < 12; q++) P.q[q] = params_host[q];
+	hipLaunchKernelGGL(k_shape_levelset, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, kind, P, phi);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
 int mf_reset_outflow(int sx, int sy, int sz, int32_t* flags, float* phi, float* real, int64_t np, int64_t ps, const float* pos,
                      int32_t* pflag, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));

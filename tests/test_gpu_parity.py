@@ -429,6 +429,29 @@ def test_reset_outflow(hip_backend, dims):
         assert_bitexact(a[k], b[k], k)
 
 
+@pytest.mark.parametrize("dims", [(13, 11, 9), (16, 12, 1), (40, 33, 27)])
+def test_shape_levelsets(hip, oracle, dims):
+    """mf_shape_levelset (Box / Sphere / Cylinder signed distance fields): HIP bit-identical to the oracle, which
+    test_oracle_vs_reference.py::test_shape_levelsets pins to the compiled reference"""
+    sx, sy, sz = dims
+    shapes = [(0, [1.5, 2.25, 0.5, sx * 0.6, sy * 0.7, max(sz * 0.8, 1.0), 0, 0, 0, 0, 0, 0]),
+              (0, [-2.0, 1.0, -1.0, sx + 3.0, sy * 0.4, sz + 2.0, 0, 0, 0, 0, 0, 0]),
+              (1, [sx * 0.5, sy * 0.4, sz * 0.5, sx * 0.27, 1.0, 1.0, 1.0, 0, 0, 0, 0, 0]),
+              (1, [sx * 0.3, sy * 0.6, sz * 0.5, sx * 0.2, 1.5, 0.75, 2.0, 0, 0, 0, 0, 0]),
+              (2, [sx * 0.5, sy * 0.1, sz * 0.5, sx * 0.14, 0.0, 1.0, 0.0, sy * 0.02, 0, 0, 0, 0]),
+              (2, [sx * 0.3, sy * 0.2, sz * 0.5, sx * 0.08, 0.6, 0.64, 0.48, sx * 0.15, 0, 0, 0, 0])]
+    for kind, q in shapes:
+        qa = (ctypes.c_float * 12)(*[float(np.float32(v)) for v in q])
+        out = []
+        for impl in (hip, oracle):
+            phi = impl.dev(np.zeros((sz, sy, sx), np.float32))
+            impl.call("mf_shape_levelset", sx, sy, sz, kind, qa, phi, None)
+            impl.sync()
+            out.append(impl.host(phi))
+        assert np.isfinite(out[1]).mean() > 0.99
+        assert_bitexact(out[0], out[1], "shape kind %d" % kind)
+
+
 def test_dam_break_steps_match_oracle(hip_backend):
     """three steps of a ghost-fluid FLIP dam break (benchmark_dam.py's loop) on the GPU = the same steps on the oracle:
     flags and particle types bit-exact, CG iteration counts identical, fields within 1e-5 (deterministic P2G)"""
