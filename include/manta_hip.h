@@ -336,6 +336,11 @@ int mf_euler_step(int64_t np, int64_t pstride, float* pos, const float* pvel, fl
  *   kind 2 Cylinder (CylinderSDF :367-385)  params: center.xyz, radius, zaxis.xyz (already normalised), zlen
  * params_host: 12 floats read on the host at call time. */
 int mf_shape_levelset(int sx, int sy, int sz, int kind, const float* params_host, float* phi, void* stream);
+/* Shape::applyToGrid -> ApplyShapeToGrid<T> / ApplyShapeToMACGrid (shapes.cpp:40-69): cells (or, for a MAC grid, the three face
+ * positions of a cell) inside the shape get `value`; cells flagged obstacle in respectFlags (nullable) are left alone.
+ * gridkind 0 Real, 1 Vec3 (SoA), 2 MAC (SoA), 3 int (value_host[0] converted).  Shape parameters as for mf_shape_levelset. */
+int mf_shape_apply_to_grid(int sx, int sy, int sz, int kind, const float* params_host, int gridkind, void* grid,
+                           const float* value_host, const int32_t* respectFlags, void* stream);
 /* resetOutflow, extforces.cpp:134-161: outflow cells get (flags | Empty) & ~Fluid, phi = 0.5, real = 0 (phi / real
  * nullable); active particles that lie inside the grid in an outflow cell are flagged PDELETE (np 0 / pos NULL: none).
  * The reference then compacts the particle array (doCompress); here deleted particles stay flagged and are skipped. */

@@ -233,6 +233,24 @@ static HD float shape_sdf_cylinder(const float* q, float x, float y, float z) {
 #undef FMIN
 #undef SQRT
 #undef FABS
+#define HD __device__ __forceinline__
+#define FABS(a) fabsf(a)
+
+/* Box::isInside :151-154 (z is tested in 2-D as well), Sphere::isInside :240-242, Cylinder::isInside :324-329 (r^2 < R^2, no root) */
+static HD int shape_inside(int kind, const float* q, float x, float y, float z) {
+	if (kind == 0) return x >= q[0] && y >= q[1] && z >= q[2] && x <= q[3] && y <= q[4] && z <= q[5];
+	if (kind == 1) {
+		const float a = (x - q[0]) / q[4], b = (y - q[1]) / q[5], c = (z - q[2]) / q[6];
+		return (a * a + b * b + c * c) <= q[3] * q[3];
+	}
+	const float px = x - q[0], py = y - q[1], pz = z - q[2];
+	const float zz = px * q[4] + py * q[5] + pz * q[6];
+	if (FABS(zz) > q[7]) return 0;
+	const float r2 = (px * px + py * py + pz * pz) - zz * zz;
+	return r2 < q[3] * q[3];
+}
+#undef HD
+#undef FABS
 struct ShapeParams {
 	float q[12];
 };
@@ -500,6 +518,37 @@ int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boun
 	return 0;
 }
 
+__global__ void __launch_bounds__(BLOCK) k_shape_apply(Dim d, int kind, ShapeParams P, int gridkind, float* __restrict__ gf, float v0, float v1,
+                                                       float v2, const int32_t* __restrict__ respect) {
+	CELL_IJK(d)
+	if (respect && (respect[idx] & MF_OBSTACLE)) return;
+	const float x = (float)i, y = (float)j, z = (float)k;
+	if (gridkind == 2) {
+		if (shape_inside(kind, P.q, x, y + 0.5f, z + 0.5f)) gf[idx] = v0;
+		if (shape_inside(kind, P.q, x + 0.5f, y, z + 0.5f)) gf[d.n + idx] = v1;
+		if (shape_inside(kind, P.q, x + 0.5f, y + 0.5f, z)) gf[2 * d.n + idx] = v2;
+	} else if (shape_inside(kind, P.q, x + 0.5f, y + 0.5f, z + 0.5f)) {
+		if (gridkind == 0) gf[idx] = v0;
+		else if (gridkind == 3) ((int32_t*)gf)[idx] = (int32_t)v0;
+		else {
+			gf[idx] = v0;
+			gf[d.n + idx] = v1;
+			gf[2 * d.n + idx] = v2;
+		}
+	}
+}
+int mf_shape_apply_to_grid(int sx, int sy, int sz, int kind, const float* params_host, int gridkind, void* grid, const float* value_host,
+                           const int32_t* respectFlags, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	if (kind < 0 || kind > 2 || gridkind < 0 || gridkind > 3) return fail("mf_shape_apply_to_grid: unknown shape or grid kind");
+	const Dim d = mkdim(sx, sy, sz);
+	ShapeParams P;
+	for (int q = 0; q < 12; q++) P.q[q] = params_host[q];
+	hipLaunchKernelGGL(k_shape_apply, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, kind, P, gridkind, (float*)grid, value_host[0], value_host[1],
+	                   value_host[2], respectFlags);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
 int mf_shape_levelset(int sx, int sy, int sz, int kind, const float* params_host, float* phi, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	if (kind < 0 || kind > 2) return fail("mf_shape_levelset: unknown shape kind");

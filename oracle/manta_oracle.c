@@ -2081,6 +2081,54 @@ static HD float shape_sdf_cylinder(const float* q, float x, float y, float z) {
 #undef FMIN
 #undef SQRT
 #undef FABS
+#define HD inline
+#define FABS(a) fabsf(a)
+
+/* Box::isInside :151-154 (z is tested in 2-D as well), Sphere::isInside :240-242, Cylinder::isInside :324-329 (r^2 < R^2, no root) */
+static HD int shape_inside(int kind, const float* q, float x, float y, float z) {
+	if (kind == 0) return x >= q[0] && y >= q[1] && z >= q[2] && x <= q[3] && y <= q[4] && z <= q[5];
+	if (kind == 1) {
+		const float a = (x - q[0]) / q[4], b = (y - q[1]) / q[5], c = (z - q[2]) / q[6];
+		return (a * a + b * b + c * c) <= q[3] * q[3];
+	}
+	const float px = x - q[0], py = y - q[1], pz = z - q[2];
+	const float zz = px * q[4] + py * q[5] + pz * q[6];
+	if (FABS(zz) > q[7]) return 0;
+	const float r2 = (px * px + py * py + pz * pz) - zz * zz;
+	return r2 < q[3] * q[3];
+}
+#undef HD
+#undef FABS
+int mf_shape_apply_to_grid(int sx, int sy, int sz, int kind, const float* q, int gridkind, void* grid, const float* value,
+                           const int32_t* respectFlags, void* st) {
+	(void)st;
+	if (kind < 0 || kind > 2 || gridkind < 0 || gridkind > 3) return fail("mf_shape_apply_to_grid: unknown shape or grid kind");
+	Dim d = mkdim(sx, sy, sz);
+	const int64_t n = d.n;
+	float* gf = (float*)grid;
+	int32_t* gi = (int32_t*)grid;
+	for (int k = 0; k < sz; k++)
+		for (int j = 0; j < sy; j++)
+			for (int i = 0; i < sx; i++) {
+				const int64_t idx = IDX(d, i, j, k);
+				if (respectFlags && (respectFlags[idx] & MF_OBSTACLE)) continue;
+				const float x = (float)i, y = (float)j, z = (float)k;
+				if (gridkind == 2) {
+					if (shape_inside(kind, q, x, y + 0.5f, z + 0.5f)) gf[idx] = value[0];
+					if (shape_inside(kind, q, x + 0.5f, y, z + 0.5f)) gf[n + idx] = value[1];
+					if (shape_inside(kind, q, x + 0.5f, y + 0.5f, z)) gf[2 * n + idx] = value[2];
+				} else if (shape_inside(kind, q, x + 0.5f, y + 0.5f, z + 0.5f)) {
+					if (gridkind == 0) gf[idx] = value[0];
+					else if (gridkind == 3) gi[idx] = (int32_t)value[0];
+					else {
+						gf[idx] = value[0];
+						gf[n + idx] = value[1];
+						gf[2 * n + idx] = value[2];
+					}
+				}
+			}
+	return 0;
+}
 int mf_shape_levelset(int sx, int sy, int sz, int kind, const float* q, float* phi, void* st) {
 	(void)st;
 	if (kind < 0 || kind > 2) return fail("mf_shape_levelset: unknown shape kind");

@@ -899,6 +899,39 @@ int ref_shape_levelset(int sx, int sy, int sz, int kind, const float* q, float* 
 	sh->generateLevelset(*ph.g);
 	SHIM_CATCH
 }
+/* Shape::applyToGrid needs the Python argument store (NOPYTHON build: errMsg), so the kernels ApplyShapeToGrid<T> /
+ * ApplyShapeToMACGrid (shapes.cpp:40-69) are applied here with the shape's own isInside / isInsideGrid.
+ * gridkind 0 Real [n], 1 Vec3 SoA [3][n], 2 MAC SoA [3][n], 3 int [n] */
+int ref_shape_apply(int sx, int sy, int sz, int kind, const float* q, int gridkind, void* grid, const float* value,
+                    const int32_t* respectFlags) {
+	SHIM_TRY
+	Ctx c(sx, sy, sz, 1.f);
+	std::unique_ptr<Shape> sh(make_shape(c, kind, q));
+	const int64_t n = c.n;
+	float* gf = (float*)grid;
+	int32_t* gi = (int32_t*)grid;
+	std::unique_ptr<FlagGrid> fl;
+	if (respectFlags) fl.reset(new FlagGrid(&c.solver, const_cast<int*>(respectFlags)));
+	Grid<Real> dummy(&c.solver);
+	FOR_IJK(dummy) {
+		const int64_t idx = dummy.index(i, j, k);
+		if (fl && fl->isObstacle(i, j, k)) continue;
+		if (gridkind == 2) {
+			if (sh->isInside(Vec3(i, j + 0.5, k + 0.5))) gf[idx] = value[0];
+			if (sh->isInside(Vec3(i + 0.5, j, k + 0.5))) gf[n + idx] = value[1];
+			if (sh->isInside(Vec3(i + 0.5, j + 0.5, k))) gf[2 * n + idx] = value[2];
+		} else if (sh->isInsideGrid(i, j, k)) {
+			if (gridkind == 0) gf[idx] = value[0];
+			else if (gridkind == 3) gi[idx] = (int32_t)value[0];
+			else {
+				gf[idx] = value[0];
+				gf[n + idx] = value[1];
+				gf[2 * n + idx] = value[2];
+			}
+		}
+	}
+	SHIM_CATCH
+}
 /* the reference's wavelet noise tile (3 x 128^3, generated once per process) and seed offset */
 int ref_noise_tile(float* out) {
 	SHIM_TRY

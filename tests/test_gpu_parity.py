@@ -450,6 +450,19 @@ def test_shape_levelsets(hip, oracle, dims):
             out.append(impl.host(phi))
         assert np.isfinite(out[1]).mean() > 0.99
         assert_bitexact(out[0], out[1], "shape kind %d" % kind)
+        # Shape.applyToGrid on the four grid kinds, with obstacle cells respected
+        flags = util.make_flags(sx, sy, sz, 88, obstacles=True)
+        val = (ctypes.c_float * 3)(1.5, -2.25, 3.0)
+        for gk in (0, 1, 2, 3):
+            shp = (sz, sy, sx) if gk in (0, 3) else (3, sz, sy, sx)
+            base = np.full(shp, 7, np.int32) if gk == 3 else util.rand_real(shp, 89).astype(np.float32)
+            res = []
+            for impl in (hip, oracle):
+                g = impl.dev(base.copy())
+                impl.call("mf_shape_apply_to_grid", sx, sy, sz, kind, qa, gk, g, val, impl.dev(flags), None)
+                impl.sync()
+                res.append(impl.host(g))
+            assert_bitexact(res[0], res[1], "applyToGrid shape %d grid kind %d" % (kind, gk))
 
 
 def test_dam_break_steps_match_oracle(hip_backend):

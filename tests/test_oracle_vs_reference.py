@@ -307,6 +307,40 @@ def test_shape_levelsets(oracle_backend, case, dims):
     assert_bitexact(ours, ref, "levelset of shape %d" % case)
 
 
+@pytest.mark.parametrize("case", range(len(SHAPES)))
+@pytest.mark.parametrize("dims", [(13, 11, 9), (16, 12, 1)])
+def test_shape_apply_to_grid(oracle_backend, case, dims):
+    """Shape.applyToGrid on Real / Vec3 / MAC / int grids, with and without respectFlags: the reference's isInside tests at the
+    cell centres and, for MAC grids, at the three face positions"""
+    from mantaflow_amd import core, scene
+    kind, q, mk = SHAPES[case]
+    sx, sy, sz = dims
+    s = cases._mk_solver(dims)
+    to3 = lambda t: core.vec3(*t)
+    class SC:
+        Box = staticmethod(lambda parent, p0, p1: scene.Box(parent=parent, p0=to3(p0), p1=to3(p1)))
+        Sphere = staticmethod(lambda parent, center, radius, scale: scene.Sphere(parent=parent, center=to3(center), radius=radius, scale=to3(scale)))
+        Cylinder = staticmethod(lambda parent, center, radius, z: scene.Cylinder(parent=parent, center=to3(center), radius=radius, z=to3(z)))
+    shape = mk(SC, s)
+    flags = util.make_flags(sx, sy, sz, 88, obstacles=True)
+    fl = cases.soa_to_grid(core.FlagGrid(s), flags)
+    qa = np.array(q, np.float32)
+    val = np.array([1.5, -2.25, 0.75], np.float32)
+    hit = 0
+    for gk, G, shp in ((0, core.Grid, (sz, sy, sx)), (1, core.VecGrid, (3, sz, sy, sx)), (2, core.MACGrid, (3, sz, sy, sx)), (3, core.IntGrid, (sz, sy, sx))):
+        for respect in (None, fl):
+            base = util.rand_real(shp, 89).astype(np.float32) if gk != 3 else np.full(shp, 7, np.int32)
+            g = cases.soa_to_grid(G(s), base)
+            value = float(val[0]) if gk == 0 else (3 if gk == 3 else core.vec3(*[float(v) for v in val]))
+            shape.applyToGrid(grid=g, value=value, respectFlags=respect)
+            ref = base.copy()
+            v = np.array([3, 0, 0], np.float32) if gk == 3 else val
+            util.refcall("ref_shape_apply", sx, sy, sz, kind, qa, gk, ref, v, None if respect is None else flags)
+            assert_bitexact(cases.grid_to_soa(g), ref, "shape %d on grid kind %d" % (case, gk))
+            hit += int((ref != base).sum())
+    assert hit > 0 or sz == 1       # (the 3-D test shapes do not all reach the z = 0.5 plane of a 2-D grid)
+
+
 def test_noise_tile_and_density_inflow(oracle_backend, oracle):
     """the wavelet noise tile (3 x 128^3, noisefield.cpp:95-186) and densityInflow (initplugins.cpp:27-43) with the source
     of scenes/simpleplume.py: bit-identical to the reference"""

@@ -38,6 +38,7 @@ REF_PROTOS = {
     "ref_advect_semi_lagrange": [c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i],
     "ref_map_parts_to_mac": [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_i],
     "ref_cg_solve_diffusion": [c_i, c_i, c_i, c_p, c_p, c_i, c_f, c_f, c_f],
+    "ref_shape_apply": [c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
     "ref_reset_outflow": [c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_p],
     "ref_apic_map_parts_to_mac": [c_i, c_i, c_i, c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i],
     "ref_apic_map_mac_to_parts": [c_i, c_i, c_i, c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i],
