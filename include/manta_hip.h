@@ -52,21 +52,15 @@ const char* mf_backend(void);
  * planes [zoff, zoff+sz) of a global grid with gsz planes -- positions handed to the interpolators are global
  * coordinates, so a slab reproduces the undivided domain bit for bit.  (0, 0) restores the default (whole domain). */
 int mf_set_slab_window(int zoff, int gsz);
+/* the window of the SOURCE grid of the calls that read a grid of another size (mf_interpolate_grid, mf_interpolate_mac_grid,
+ * the weight grid of mf_apply_noise_vec3): in a two-resolution scene each solver's slab has its own window */
+int mf_set_slab_window_source(int zoff, int gsz);
 
 /* How the MIC(0) substitution sweeps are parallelised on the GPU (no reference counterpart; every mode gives the same
  * bits as the serial sweep of ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:88-128):
  * "rows" (default for 3D), "tiles", "levels"; NULL or "" = back to the default / MF_MIC_MODE.  Returns 0, or -1 for an
  * unknown name.  The oracle accepts and ignores it. */
 int mf_set_mic_mode(const char* name);
-/* Multi-GPU only (no reference counterpart): tell the MIC sweeps that the caller has cut the preconditioner into
- * independent blocks of `rows_j` grid rows along y (a multiple of 8) by zeroing the Aj coupling across the block faces --
- * the block-Jacobi form the z-slab solver already uses across slabs.  The sweeps then skip the hand-off across those
- * faces (the values exchanged there are multiplied by 0 anyway), which shortens the dependency chain.  The arithmetic
- * is unchanged: results equal the serial sweep with the same (cut) coefficients bit for bit.  0 = off (default). */
-int mf_set_mic_blocking(int rows_j);
-/* the same along x: independent x-blocks of cells_x cells (a non-negative multiple of 8; 0 = whole rows).  The caller has
- * zeroed the Ai coupling across the block faces in the preconditioner's copy of the matrix. */
-int mf_set_mic_blocking_x(int cells_x);
 /* Synchronises the stream and reports whether any MIC sweep since the last check gave up waiting for a neighbouring
  * workgroup (a deadlock guard of the single-launch sweeps; never seen in practice).  mf_cg_solve checks by itself; callers
  * that drive mf_mic_apply directly call this once per solve.  The oracle returns 0. */
@@ -159,6 +153,15 @@ int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float*
  * contents of these grids between mf_mic_init and mf_mic_apply is a caller error (the reference's Aprecond would be stale too). */
 int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0,
                 const float* Ai, const float* Aj, const float* Ak, void* stream);
+/* Multi-GPU only (no reference counterpart): mf_mic_init for a preconditioner the caller has cut into independent blocks of
+ * `rows_j` grid rows along y and `cells_x` cells along x (non-negative multiples of 8; 0 = uncut) by zeroing the Aj / Ai
+ * coupling across the block faces in the copies passed here -- the block-Jacobi form the z-slab solver already uses across
+ * slabs.  The blocking is remembered WITH this system (the flags / Aprecond / Aj / Ak pointers): mf_mic_apply called with the
+ * same pointers skips the hand-offs across the block faces (the values exchanged there are multiplied by 0 anyway), which
+ * shortens the dependency chain; any other system is swept uncut.  The arithmetic is unchanged: results equal the serial
+ * sweep over the same (cut) coefficients bit for bit.  The oracle ignores the two numbers. */
+int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0,
+                        const float* Ai, const float* Aj, const float* Ak, int rows_j, int cells_x, void* stream);
 /* ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159 (3-D only).
  * dst keeps its previous content in non-fluid cells, exactly like the reference. */
 int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1,

@@ -73,6 +73,12 @@ class Library:
         if missing:
             raise RuntimeError("mantaflow_amd: %s lacks ABI symbols: %s" % (path, ", ".join(missing)))
         self.backend = self.cdll.mf_backend().decode()
+        # the z-slab window is thread-local state of the shared object (which stays loaded across Library instances): start
+        # from "the grid is the whole domain"; solvers carry their own window and set it per call (core.SolverLib)
+        self.cdll.mf_set_slab_window(0, 0)
+        self.cdll.mf_set_slab_window_source(0, 0)
+        self._window = (0, 0)
+        self._window_src = (0, 0)
 
     def call(self, name, *args):
         fn = getattr(self.cdll, name)

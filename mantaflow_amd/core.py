@@ -129,6 +129,32 @@ class PbClass(object):
         return type(self)._cname_cpp + ("<%s>" % t if t else "")
 
 
+class SolverLib(object):
+    """The C ABI as seen by ONE solver: every call is made under that solver's z-slab window (zoff, gsz) -- (0, 0) for an
+    ordinary solver whose grids are the whole domain.  The window is thread-local state of the library; binding it to the
+    solver means a slab solver and a plain solver (or two slab solvers of different resolution, as in waveletTurbulence.py) can
+    live in one process without inheriting each other's coordinates."""
+
+    def __init__(self, lib, solver):
+        self._lib, self._solver = lib, solver
+        self.backend, self.device, self.cdll, self.path = lib.backend, lib.device, lib.cdll, lib.path
+
+    def call(self, name, *args):
+        lib, w = self._lib, self._solver._slab_window
+        if lib._window != w:
+            lib.call("mf_set_slab_window", w[0], w[1])
+            lib._window = w
+        return lib.call(name, *args)
+
+    def call2(self, src_solver, name, *args):
+        """a call that reads a grid of another solver (interpolateGrid & co.): that grid's window goes in as the source window"""
+        lib, w = self._lib, src_solver._slab_window
+        if lib._window_src != w:
+            lib.call("mf_set_slab_window_source", w[0], w[1])
+            lib._window_src = w
+        return self.call(name, *args)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # FluidSolver (python name Solver), fluidsolver.{h,cpp}
 # ---------------------------------------------------------------------------------------------------------
@@ -155,7 +181,8 @@ class FluidSolver(PbClass):
         self.frameLength = 1.0
         self.timePerFrame = 0.0
         self.mLockDt = False
-        self.lib = _lib.get()
+        self._slab_window = (0, 0)
+        self.lib = SolverLib(_lib.get(), self)
         self.device = self.lib.device
         self._pool = {}    # dtype/ncomp -> list of free tensors  (GridStorage, fluidsolver.cpp:34-50)
         self._live = 0

@@ -59,6 +59,15 @@ static inline Dim mkdim(int sx, int sy, int sz) {
 	d.n = (int64_t)sx * sy * sz;
 	return d;
 }
+// the same for the SOURCE grid of a call that reads a grid of another resolution (interpolateGrid & co.): its own window,
+// mf_set_slab_window_source
+extern thread_local int g_slab_src_zoff, g_slab_src_gsz;
+static inline Dim mkdim_src(int sx, int sy, int sz) {
+	Dim d = mkdim(sx, sy, sz);
+	d.zoff = g_slab_src_gsz > 0 ? g_slab_src_zoff : 0;
+	d.gsz = g_slab_src_gsz > 0 ? g_slab_src_gsz : sz;
+	return d;
+}
 // global plane index -> index inside the local window, kept addressable for the ghost fringe (whose results are
 // discarded); the identity when the grid is the whole domain
 __device__ __forceinline__ int local_z(const Dim& d, int zi, int hi_off) {

@@ -973,6 +973,9 @@ struct FlowState {
 	int* bempty = nullptr;
 	int bempty_cap = 0;
 	const void *be_flags = nullptr, *be_Ap = nullptr, *be_Aj = nullptr, *be_Ak = nullptr;
+	// preconditioner blocks of the system mf_mic_init_blocked was given (0 = uncut): the apply sweeps use them only when they
+	// are called with the same flags / Aprecond / Aj / Ak (be_*), any other system is swept as the uncut reference algorithm
+	int blk_rows = 0, blk_cells = 0;
 	// packed operands of the apply sweeps (k_mic_pack), valid for the grids mf_mic_init was given
 	unsigned char* pack = nullptr;
 	int* pack_ok = nullptr;
@@ -1068,18 +1071,16 @@ static bool xcd_round_robin_ok() {
 	}
 	return state == 1;
 }
-static thread_local int g_mic_jblock_rows = 0;   // mf_set_mic_blocking
-static thread_local int g_mic_xblock_cells = 0;  // mf_set_mic_blocking_x
-static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st) {
+static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jblock_rows, int xblock_cells) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
 	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8;
 	// x-blocks of g_mic_xblock_cells cells (independent systems, the caller has cut Ai) -- or the whole row
-	const int xcells = (g_mic_xblock_cells > 0 && g_mic_xblock_cells < d.sx) ? g_mic_xblock_cells : ((d.sx + 7) / 8) * 8;
+	const int xcells = (xblock_cells > 0 && xblock_cells < d.sx) ? xblock_cells : ((d.sx + 7) / 8) * 8;
 	const int nchunks = xcells / 8, nxb = (d.sx + xcells - 1) / xcells;
 	if (nbj > 4095 || nbk > 4095 || nxb > 127) return fail("grid too large for the MIC bundle order table");
-	int jb = g_mic_jblock_rows > 0 ? g_mic_jblock_rows / 8 : nbj;
+	int jb = jblock_rows > 0 ? jblock_rows / 8 : nbj;
 	if (jb < 1 || jb > nbj) jb = nbj;
 	static const int use_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : 0;
 	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
@@ -1190,16 +1191,6 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 	f.up_Ak = Ak;
 	return 0;
 }
-extern "C" int mf_set_mic_blocking_x(int cells_x) {
-	if (cells_x < 0 || (cells_x % 8) != 0) return fail("mf_set_mic_blocking_x: cells must be a non-negative multiple of 8");
-	g_mic_xblock_cells = cells_x;
-	return 0;
-}
-extern "C" int mf_set_mic_blocking(int rows_j) {
-	if (rows_j < 0 || (rows_j % 8) != 0) return fail("mf_set_mic_blocking: rows must be a non-negative multiple of 8");
-	g_mic_jblock_rows = rows_j;
-	return 0;
-}
 static int mic_mode_() {
 	if (g_mic_mode < 0) {
 		const char* e = getenv("MF_MIC_MODE");
@@ -1219,8 +1210,12 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
 	if constexpr (MODE != 0) {
 		if (mic_mode_() == 2 && d.is3d) {
+			int dev_ = 0;
+			MF_HIP(hipGetDevice(&dev_));
+			const FlowState& f0 = g_flow[dev_];
+			const bool same_system = f0.be_flags == flags && f0.be_Ap == Ap && f0.be_Aj == Aj && f0.be_Ak == Ak;
 			FlowState* f;
-			MF_TRY(rows_prepare(d, &f, st));
+			MF_TRY(rows_prepare(d, &f, st, same_system ? f0.blk_rows : 0, same_system ? f0.blk_cells : 0));
 			f->sgen++;
 			if (f->sgen == 0) {
 				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
@@ -1406,7 +1401,13 @@ extern "C" {
 
 int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0, const float* Ai,
                 const float* Aj, const float* Ak, void* stream) {
+	return mf_mic_init_blocked(sx, sy, sz, flags, Aprecond, A0, Ai, Aj, Ak, 0, 0, stream);
+}
+int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, const float* A0, const float* Ai,
+                        const float* Aj, const float* Ak, int rows_j, int cells_x, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
+	if (rows_j < 0 || (rows_j % 8) != 0) return fail("mf_mic_init_blocked: rows_j must be a non-negative multiple of 8");
+	if (cells_x < 0 || (cells_x % 8) != 0) return fail("mf_mic_init_blocked: cells_x must be a non-negative multiple of 8");
 	const Dim d = mkdim(sx, sy, sz);
 	if (!d.is3d) return fail("mICP only supports 3D grids so far");
 	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, (hipStream_t)stream));
@@ -1414,7 +1415,9 @@ int mf_mic_init(int sx, int sy, int sz, const int32_t* flags, float* Aprecond, c
 	if (mic_mode_() == 2) {
 		// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
 		FlowState* f;
-		MF_TRY(rows_prepare(d, &f, (hipStream_t)stream));
+		MF_TRY(rows_prepare(d, &f, (hipStream_t)stream, rows_j, cells_x));
+		f->blk_rows = rows_j;
+		f->blk_cells = cells_x;
 		if (f->nblocks + 1 > f->bempty_cap) {
 			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
 			if (f->bempty) MF_HIP(hipFree(f->bempty));

@@ -985,6 +985,14 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	if (pc != MF_PC_NONE && pc != MF_PC_MICP) return fail("GridCg<APPLYMAT>::setICPreconditioner: Invalid method specified.");
 	if (pc == MF_PC_MICP && !d.is3d) pc = MF_PC_NONE;  // conjugategrad.cpp:315-321
 	if (!(al16(dst) && al16(rhs) && al16(residual) && al16(search) && al16(tmp))) return fail("mf_cg_solve: work grids must be 16-byte aligned");
+	if (maxIter <= 0) {
+		// GridCg::solve (conjugategrad.cpp:302-307) never reaches iterate(), and doInit is only called from there: pressure
+		// and the work grids stay untouched; mIterations = 0, mResNorm = 1e20 (constructor, :203)
+		out_host[0] = 0.f;
+		out_host[1] = 1e20f;
+		out_host[2] = 0.f;
+		return 0;
+	}
 	Workspace* ws;
 	MF_TRY(get_workspace(&ws));
 	CgScalars* sc = (CgScalars*)ws->scalars;
@@ -1010,7 +1018,7 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	MF_LAUNCH_CHECK();
 	// ApplyMatrix reads the same packed coefficient bytes as the MIC sweeps when mf_mic_init found the matrix packable
 	const unsigned char* am_pack = nullptr;
-	if (pc == MF_PC_MICP && maxIter > 0) MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &am_pack, st));
+	if (pc == MF_PC_MICP) MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &am_pack, st));
 
 	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done`, one batch behind the batch it has just queued
 	// (every kernel of an iteration returns at once when `done` is already set, so running ahead costs a few empty
@@ -1019,7 +1027,11 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	CgScalars h;
 	memset(&h, 0, sizeof h);
 	h.resNorm = 1e20f;
-	static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+	// one event pair per device (an event belongs to the device that was current when it was created)
+	static thread_local hipEvent_t ev_dev[16][2] = {};
+	int dev_ = 0;
+	MF_HIP(hipGetDevice(&dev_));
+	hipEvent_t* ev = ev_dev[dev_ & 15];
 	if (!ev[0]) {
 		MF_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
 		MF_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
@@ -1063,11 +1075,6 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	MF_HIP(hipMemcpyAsync(&hslot[0], sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
 	MF_HIP(hipStreamSynchronize(st));
 	memcpy(&h, &hslot[0], sizeof h);
-	if (maxIter <= 0) {
-		MF_HIP(hipMemcpyAsync(ws->host, sc, sizeof(CgScalars), hipMemcpyDeviceToHost, st));
-		MF_HIP(hipStreamSynchronize(st));
-		memcpy(&h, ws->host, sizeof h);
-	}
 	out_host[0] = (float)h.iterations;
 	out_host[1] = h.resNorm;
 	out_host[2] = h.sigma;

@@ -6,6 +6,7 @@
 namespace mf {
 thread_local char g_err[512];
 thread_local int g_slab_zoff = 0, g_slab_gsz = 0;
+thread_local int g_slab_src_zoff = 0, g_slab_src_gsz = 0;
 int fail(const char* fmt, ...) {
 	va_list ap;
 	va_start(ap, fmt);
@@ -297,6 +298,12 @@ int mf_set_slab_window(int zoff, int gsz) {
 	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid slab window %d / %d", zoff, gsz);
 	mf::g_slab_zoff = zoff;
 	mf::g_slab_gsz = gsz;
+	return 0;
+}
+int mf_set_slab_window_source(int zoff, int gsz) {
+	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid source slab window %d / %d", zoff, gsz);
+	mf::g_slab_src_zoff = zoff;
+	mf::g_slab_src_gsz = gsz;
 	return 0;
 }
 

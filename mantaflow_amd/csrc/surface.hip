@@ -12,6 +12,18 @@ __device__ __forceinline__ bool in_bounds(const Dim& d, int i, int j, int k) {
 	return i >= 0 && j >= 0 && k >= 0 && i < d.sx && j < d.sy && k < d.sz;
 }
 __device__ __forceinline__ int64_t cidx(const Dim& d, int i, int j, int k) { return (int64_t)i + d.Y * j + d.Z * k; }
+// Particle positions are GLOBAL grid coordinates; a z-slab window (mf_set_slab_window) holds planes [zoff, zoff + sz) of gsz.
+// cell_of: cell of a position, k as the plane inside the window; false when the cell is outside the domain or the window
+// (a particle of another slab).  Without a window this is the reference's isInBounds(toVec3i(pos)).
+__device__ __forceinline__ bool cell_of(const Dim& d, float x, float y, float z, int& i, int& j, int& k) {
+	i = (int)x;
+	j = (int)y;
+	const int kg = (int)z;
+	k = kg - d.zoff;
+	return i >= 0 && j >= 0 && kg >= 0 && i < d.sx && j < d.sy && kg < d.gsz && k >= 0 && k < d.sz;
+}
+// domain-boundary test in global planes (a slab's outer ghost plane is not a domain wall)
+__device__ __forceinline__ bool z_wall(const Dim& d, int k, int w) { return d.is3d && (k + d.zoff <= w || k + d.zoff >= d.gsz - 1 - w); }
 #define CELL_IJK(d)                                                               \
 	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;                \
 	if (idx >= (d).n) return;                                                     \
@@ -35,7 +47,7 @@ k_project_out_of_bnd(Dim d, int64_t np, int64_t ps, float* __restrict__ pos, con
 	if (axis & 8) { const float hi = (float)d.sy - bnd; y = hi < y ? hi : y; }
 	if (d.is3d) {
 		if (axis & 16) z = z > bnd ? z : bnd;
-		if (axis & 32) { const float hi = (float)d.sz - bnd; z = hi < z ? hi : z; }
+		if (axis & 32) { const float hi = (float)d.gsz - bnd; z = hi < z ? hi : z; }
 	}
 	pos[p] = x;
 	pos[ps + p] = y;
@@ -50,8 +62,8 @@ k_push_out_of_obs(Dim d, int64_t np, int64_t ps, float* __restrict__ pos, const 
 	if (p >= np) return;
 	if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) return;
 	const float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
-	int i = (int)x, j = (int)y, k = (int)z;
-	if (!in_bounds(d, i, j, k)) return;
+	int i, j, k;
+	if (!cell_of(d, x, y, z, i, j, k)) return;
 	const float v = interpol1(d, phi, x, y, z);
 	if (!(v < thresh)) return;
 	if (i > d.sx - 2) i = d.sx - 2;
@@ -62,6 +74,11 @@ k_push_out_of_obs(Dim d, int64_t np, int64_t ps, float* __restrict__ pos, const 
 	float gy = phi[cidx(d, i, j + 1, k)] - phi[cidx(d, i, j - 1, k)];
 	float gz = 0.f;
 	if (d.is3d) {
+		// getGradient clamps to [1, size - 2] of the whole domain; inside a slab window additionally stay addressable
+		int kg = k + d.zoff;
+		if (kg > d.gsz - 2) kg = d.gsz - 2;
+		if (kg < 1) kg = 1;
+		k = kg - d.zoff;
 		if (k > d.sz - 2) k = d.sz - 2;
 		if (k < 1) k = 1;
 		gz = phi[cidx(d, i, j, k + 1)] - phi[cidx(d, i, j, k - 1)];
@@ -100,8 +117,8 @@ k_gpi_keys(Dim d, int64_t np, int64_t ps, const float* __restrict__ pos, const i
 	if (p >= np) return;
 	int key = (int)d.n;
 	if (!(pflag[p] & MF_PDELETE)) {
-		const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
-		if (in_bounds(d, i, j, k)) {
+		int i, j, k;
+		if (cell_of(d, pos[p], pos[ps + p], pos[2 * ps + p], i, j, k)) {
 			key = (int)cidx(d, i, j, k);
 			atomicAdd(&counter[key], 1);
 		}
@@ -133,12 +150,12 @@ __global__ void __launch_bounds__(BLOCK)
 k_union_levelset(Dim d, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ isys, int64_t n_indexed,
                  const int32_t* __restrict__ index, float* __restrict__ phi, float radius, const int32_t* __restrict__ ptype, int exclude) {
 	CELL_IJK(d)
-	const bool bnd = (i <= 0 || i >= d.sx - 1 || j <= 0 || j >= d.sy - 1 || (d.is3d && (k <= 0 || k >= d.sz - 1)));
+	const bool bnd = (i <= 0 || i >= d.sx - 1 || j <= 0 || j >= d.sy - 1 || z_wall(d, k, 0));
 	if (bnd) {
 		phi[idx] = 0.5f;
 		return;
 	}
-	const float gx = (float)i + 0.5f, gy = (float)j + 0.5f, gz = (float)k + 0.5f;
+	const float gx = (float)i + 0.5f, gy = (float)j + 0.5f, gz = (float)(k + d.zoff) + 0.5f;
 	float phiv = (float)((double)radius * 1.0);
 	const int r = (int)radius + 1, rZ = d.is3d ? r : 0;
 	const float eps2 = 1e-6f * 1e-6f;
@@ -167,7 +184,7 @@ k_union_levelset(Dim d, int64_t ps, const float* __restrict__ pos, const int32_t
 // knSetBoundary, grid.cpp:629-633
 __global__ void __launch_bounds__(BLOCK) k_set_bound(Dim d, float* __restrict__ g, float value, int w) {
 	CELL_IJK(d)
-	const bool bnd = (i <= w || i >= d.sx - 1 - w || j <= w || j >= d.sy - 1 - w || (d.is3d && (k <= w || k >= d.sz - 1 - w)));
+	const bool bnd = (i <= w || i >= d.sx - 1 - w || j <= w || j >= d.sy - 1 - w || z_wall(d, k, w));
 	if (bnd) g[idx] = value;
 }
 
@@ -256,7 +273,7 @@ struct ShapeParams {
 };
 __global__ void __launch_bounds__(BLOCK) k_shape_levelset(Dim d, int kind, ShapeParams P, float* __restrict__ phi) {
 	CELL_IJK(d)
-	const float x = (float)i + 0.5f, y = (float)j + 0.5f, z = (float)k + 0.5f;
+	const float x = (float)i + 0.5f, y = (float)j + 0.5f, z = (float)(k + d.zoff) + 0.5f;
 	phi[idx] = kind == 0 ? shape_sdf_box(d.is3d, P.q, x, y, z) : (kind == 1 ? shape_sdf_sphere(P.q, x, y, z) : shape_sdf_cylinder(P.q, x, y, z));
 }
 
@@ -285,7 +302,8 @@ __global__ void __launch_bounds__(BLOCK) k_reset_outflow(int64_t n, int32_t* __r
 __global__ void __launch_bounds__(BLOCK) k_els_mark(Dim d, const float* __restrict__ phi, int32_t* __restrict__ tmp, int inside, int b) {
 	CELL_IJK(d)
 	int t = 0;
-	if (INTERIOR_B(d, b)) {
+	// the b-cell border of the DOMAIN stays unmarked; the outer ghost plane of a slab window is an ordinary cell
+	if (i >= b && i < d.sx - b && j >= b && j < d.sy - b && (!d.is3d || (k + d.zoff >= b && k + d.zoff < d.gsz - b))) {
 		if (!inside) t = (phi[idx] < 0.) ? 1 : 0;
 		else t = (phi[idx] > 0.) ? 1 : 0;
 	}
@@ -331,9 +349,9 @@ k_set_part_type(Dim d, const int32_t* __restrict__ flags, int64_t np, int64_t ps
                 int mark, int stype, int cflag) {
 	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
 	if (p >= np) return;
-	const int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
+	const int i = (int)pos[p], j = (int)pos[ps + p], kg = (int)pos[2 * ps + p], k = kg - d.zoff;
 	bool in = i >= 0 && j >= 0 && i < d.sx && j < d.sy;
-	in = in && (d.is3d ? (k >= 0 && k < d.sz) : (k == 0));
+	in = in && (d.is3d ? (kg >= 0 && kg < d.gsz && k >= 0 && k < d.sz) : (kg == 0));
 	if (!in) return;
 	if ((flags[cidx(d, i, j, k)] & cflag) && (ptype[p] & stype)) ptype[p] = mark;
 }
@@ -522,7 +540,7 @@ __global__ void __launch_bounds__(BLOCK) k_shape_apply(Dim d, int kind, ShapePar
                                                        float v2, const int32_t* __restrict__ respect) {
 	CELL_IJK(d)
 	if (respect && (respect[idx] & MF_OBSTACLE)) return;
-	const float x = (float)i, y = (float)j, z = (float)k;
+	const float x = (float)i, y = (float)j, z = (float)(k + d.zoff);
 	if (gridkind == 2) {
 		if (shape_inside(kind, P.q, x, y + 0.5f, z + 0.5f)) gf[idx] = v0;
 		if (shape_inside(kind, P.q, x + 0.5f, y, z + 0.5f)) gf[d.n + idx] = v1;

@@ -123,8 +123,9 @@ class SlabDomain(object):
         self.XY = self.NX * self.NY
         self.solver = core.Solver(gridSize=core.vec3(self.NX, self.NY, self.LZ), dim=3)
         self.solver._global_max = max(self.NX, self.NY, self.NZ)       # getDx() of the undivided domain (gravity / buoyancy scaling)
-        # positions handed to the interpolators are global coordinates -> bit-identical to the undivided domain
-        self.solver.lib.call("mf_set_slab_window", self.lo, self.NZ)
+        # positions handed to the interpolators are global coordinates -> bit-identical to the undivided domain.  The window
+        # belongs to THIS solver (core.SolverLib sets it per call): other solvers of the process keep their own
+        self.solver._slab_window = (self.lo, self.NZ)
         self.below = r - 1 if r > 0 else None
         self.above = r + 1 if r < P - 1 else None
 
@@ -192,8 +193,9 @@ def advectSemiLagrange(dom, flags, vel, grid, order=1, strength=1.0, clampMode=2
     plugins.advectSemiLagrange(flags, vel, grid, order=order, strength=strength, clampMode=clampMode)
 
 
-def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, stats=None):
-    """computePressureRhs + PCG (slab-local MIC) + correctVelocity on a slab.  vel ghosts (1 plane) must be current."""
+def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, stats=None, phi=None, gfClamp=1e-04):
+    """computePressureRhs + PCG (slab-local MIC) + correctVelocity on a slab.  vel ghosts (1 plane) must be current; with `phi`
+    (ghost-fluid free surface, pressure.cpp:136-214) its one-plane ghosts as well."""
     s = dom.solver
     lib, st = s.lib, s.stream
     sx, sy, sz = dom.NX, dom.NY, dom.LZ
@@ -202,6 +204,9 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     rhs, residual, search, tmp, A0, Ai, Aj, Ak, Akm, Ap = (G(s) for _ in range(10))
     lib.call("mf_make_rhs", sx, sy, sz, flags.ptr, rhs.ptr, vel.ptr, None, None, None, None, None, 0.0, 1e-4, None, None, st)
     lib.call("mf_make_laplace_matrix", sx, sy, sz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, st)
+    if phi is not None:
+        # ApplyGhostFluidDiagonal (pressure.cpp:136-151): the diagonal of a fluid cell next to an empty one, from phi of the two
+        lib.call("mf_apply_ghost_fluid_diagonal", sx, sy, sz, A0.ptr, flags.ptr, phi.ptr, float(gfClamp), st)
     # slab-local MIC: ghost planes are not part of the block, the coupling across the slab faces is cut
     fmic = core.FlagGrid(s)
     fmic.copyFrom(flags)
@@ -267,14 +272,13 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     def mic(dst, src):
         lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, st)
 
-    lib.call("mf_set_mic_blocking", jblock)
-    lib.call("mf_set_mic_blocking_x", xblock)
     # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather whose
     # rows are combined in rank order by a one-thread kernel; the host reads one number per iteration (the stopping test).
     # doInit, conjugategrad.cpp:210-235
     pressure.clear()
     residual.copyFrom(rhs)
-    lib.call("mf_mic_init", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, st)
+    # the y / x blocking travels with this system (flags / Aprecond / Aj / Ak pointers), not with the process
+    lib.call("mf_mic_init_blocked", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, jblock, xblock, st)
     mic(tmp, residual)
     search.copyFrom(tmp)
     dot_own(tmp, residual)
@@ -312,15 +316,19 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
                 break
             iters = it
     resNorm = float(sc[4])
+    lib.call("mf_mic_check", st)
     if stop == 2:
         raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
-    lib.call("mf_set_mic_blocking", 0)
-    lib.call("mf_set_mic_blocking_x", 0)
-    lib.call("mf_mic_check", st)
     if stats is not None:
         stats["iterations"], stats["residual"] = iters, float(resNorm)
-    dom.exchange(pressure, 1)
+    # knReplaceClampedGhostFluidVels reads the CORRECTED z-velocity of the planes below and above: the first ghost plane must come
+    # out right as well, and its correction reads the pressure of the second one
+    dom.exchange(pressure, 1 if phi is None else 2)
     lib.call("mf_correct_velocity", sx, sy, sz, flags.ptr, vel.ptr, pressure.ptr, st)
+    if phi is not None:
+        # knCorrectVelocityGhostFluid + knReplaceClampedGhostFluidVels, pressure.cpp:154-214 (read pressure / phi / flags at +-1)
+        lib.call("mf_correct_velocity_ghost_fluid", sx, sy, sz, vel.ptr, flags.ptr, pressure.ptr, phi.ptr, float(gfClamp), None, 0.0, st)
+        lib.call("mf_replace_clamped_ghost_fluid_vels", sx, sy, sz, vel.ptr, flags.ptr, pressure.ptr, phi.ptr, float(gfClamp), st)
     return iters
 
 
@@ -427,29 +435,36 @@ class SlabParticles(object):
         if bool(up.any()) and int(k[up].max()) >= ranges[dom.comm.rank + 1][1] and dom.comm.rank + 1 < dom.comm.world - 1:
             raise RuntimeError("slab FLIP: a particle crossed more than one slab in a step")
         send_dn, send_up, stay = packed[:, down].contiguous(), packed[:, up].contiguous(), packed[:, ~(down | up)]
-        # 1. counts
-        cnt = torch.tensor([send_dn.shape[1], send_up.shape[1]], dtype=torch.int64, device=s.device)
-        got = torch.zeros(2, dtype=torch.int64, device=s.device)
-        pairs = []
-        if dom.below is not None:
-            pairs.append((cnt[0:1], got[0:1], dom.below))
-        if dom.above is not None:
-            pairs.append((cnt[1:2], got[1:2], dom.above))
-        dom.comm.sendrecv(pairs)
-        # 2. payloads (only the non-empty ones; both sides know the counts)
-        ncol = packed.shape[0]
-        from_dn = torch.zeros((ncol, int(got[0])), dtype=torch.float32, device=s.device)
-        from_up = torch.zeros((ncol, int(got[1])), dtype=torch.float32, device=s.device)
-        pairs = []
-        if dom.below is not None and (send_dn.shape[1] or from_dn.shape[1]):
-            pairs.append((send_dn if send_dn.shape[1] else None, from_dn if from_dn.shape[1] else None, dom.below))
-        if dom.above is not None and (send_up.shape[1] or from_up.shape[1]):
-            pairs.append((send_up if send_up.shape[1] else None, from_up if from_up.shape[1] else None, dom.above))
-        dom.comm.sendrecv(pairs)
+        from_dn, from_up = exchange_columns(dom, send_dn, send_up)
         moved = send_dn.shape[1] + send_up.shape[1] + from_dn.shape[1] + from_up.shape[1]
         if moved:
             self._assign(torch.cat([stay, from_dn, from_up], dim=1))
         return moved
+
+
+def exchange_columns(dom, send_dn, send_up):
+    """variable-size exchange with the two z-neighbours: [ncol][n] float32 blocks (bit patterns) go down / up, the blocks the
+    neighbours sent come back as (from_below, from_above).  One count message + one payload message per side and direction."""
+    s = dom.solver
+    cnt = torch.tensor([send_dn.shape[1], send_up.shape[1]], dtype=torch.int64, device=s.device)
+    got = torch.zeros(2, dtype=torch.int64, device=s.device)
+    pairs = []
+    if dom.below is not None:
+        pairs.append((cnt[0:1], got[0:1], dom.below))
+    if dom.above is not None:
+        pairs.append((cnt[1:2], got[1:2], dom.above))
+    dom.comm.sendrecv(pairs)
+    # payloads (only the non-empty ones; both sides know the counts)
+    ncol = send_dn.shape[0]
+    from_dn = torch.zeros((ncol, int(got[0])), dtype=torch.float32, device=s.device)
+    from_up = torch.zeros((ncol, int(got[1])), dtype=torch.float32, device=s.device)
+    pairs = []
+    if dom.below is not None and (send_dn.shape[1] or from_dn.shape[1]):
+        pairs.append((send_dn if send_dn.shape[1] else None, from_dn if from_dn.shape[1] else None, dom.below))
+    if dom.above is not None and (send_up.shape[1] or from_up.shape[1]):
+        pairs.append((send_up if send_up.shape[1] else None, from_up if from_up.shape[1] else None, dom.above))
+    dom.comm.sendrecv(pairs)
+    return from_dn, from_up
 
 
 def reduce_ghosts(dom, grid, width=1):
@@ -473,8 +488,11 @@ def reduce_ghosts(dom, grid, width=1):
         dst.add_(tmp)
 
 
-def advectInGrid(dom, sp, flags, vel, integrationMode, deleteInObstacle=True, stopInObstacle=True, skipNew=False):
-    """ParticleSystem::advectInGrid on a slab (particle.h:526-550): ghosts of `vel` to the ghost width, local step, migration"""
+def advectInGrid(dom, sp, flags, vel, integrationMode, deleteInObstacle=True, stopInObstacle=True, skipNew=False, ptype=None,
+                 exclude=0, migrate=True):
+    """ParticleSystem::advectInGrid on a slab (particle.h:526-550): ghosts of `vel` to the ghost width, local step, migration
+    (migrate=False: the caller moves the particles further -- eulerStep, projectOutOfBnd, pushOutofObs -- and calls sp.migrate()
+    itself once the positions of the step are final)"""
     s = dom.solver
     if dom.comm.world > 1:
         m = 0.0
@@ -484,27 +502,28 @@ def advectInGrid(dom, sp, flags, vel, integrationMode, deleteInObstacle=True, st
         if reach > dom.G:
             raise RuntimeError("slab advectInGrid: max|v| dt = %.2f needs %d ghost planes, domain has %d" % (m * s.getDt(), reach, dom.G))
     dom.exchange(vel)
-    sp.pp.advectInGrid(flags, vel, integrationMode, deleteInObstacle=deleteInObstacle, stopInObstacle=stopInObstacle, skipNew=skipNew)
-    return sp.migrate()
+    sp.pp.advectInGrid(flags, vel, integrationMode, deleteInObstacle=deleteInObstacle, stopInObstacle=stopInObstacle, skipNew=skipNew,
+                       ptype=ptype, exclude=exclude)
+    return sp.migrate() if migrate else 0
 
 
-def mapPartsToMAC(dom, flags, vel, velOld, sp, partVel, weight=None, deterministic=True):
+def mapPartsToMAC(dom, flags, vel, velOld, sp, partVel, weight=None, deterministic=True, ptype=None, exclude=0):
     """mapPartsToMAC (flip.cpp:637-661) on a slab: local scatter, reverse halo of the pre-division sums, then the division"""
     s = dom.solver
     w = weight if weight is not None else core.VecGrid(s)
     pp = sp.pp
     s.lib.call("mf_map_parts_to_mac_accum", dom.NX, dom.NY, dom.LZ, vel.ptr, w.ptr, pp.np, pp.cap, _ptr(pp.pos), _ptr(pp.flag),
-               partVel.ptr, None, 0, int(deterministic), s.stream)
+               partVel.ptr, None if ptype is None else ptype.ptr, int(exclude), int(deterministic), s.stream)
     reduce_ghosts(dom, vel, 1)
     reduce_ghosts(dom, w, 1)
     s.lib.call("mf_map_parts_to_mac_finish", 3 * vel.n, vel.ptr, velOld.ptr, w.ptr, s.stream)
 
 
-def markFluidCells(dom, sp, flags):
+def markFluidCells(dom, sp, flags, ptype=None, exclude=0):
     """markFluidCells (flip.cpp:166-188) on a slab: every rank marks the cells of its own particles, ghost flags come from
     their owners"""
     from . import plugins
-    plugins.markFluidCells(sp.pp, flags)
+    plugins.markFluidCells(sp.pp, flags, ptype=ptype, exclude=exclude)
     dom.exchange(flags)
 
 
@@ -541,12 +560,98 @@ def mapMACToParts(dom, flags, vel, sp, partVel):
     s.lib.call("mf_map_mac_to_parts", dom.NX, dom.NY, dom.LZ, vel.ptr, pp.np, pp.cap, _ptr(pp.pos), _ptr(pp.flag), partVel.ptr, None, 0, s.stream)
 
 
-def flipVelocityUpdate(dom, flags, vel, velOld, sp, partVel, flipRatio):
+def flipVelocityUpdate(dom, flags, vel, velOld, sp, partVel, flipRatio, ptype=None, exclude=0):
     s, pp = dom.solver, sp.pp
     dom.exchange(vel, 1)
     dom.exchange(velOld, 1)
     s.lib.call("mf_flip_velocity_update", dom.NX, dom.NY, dom.LZ, vel.ptr, velOld.ptr, pp.np, pp.cap, _ptr(pp.pos), _ptr(pp.flag),
-               partVel.ptr, float(flipRatio), None, 0, s.stream)
+               partVel.ptr, float(flipRatio), None if ptype is None else ptype.ptr, int(exclude), s.stream)
+
+
+# =========================================================================================================
+# free-surface pieces of scenes/benchmark_dam.py on slabs (BASELINE config 4): the ghost-fluid pressure solve needs the particle
+# level set, which reaches across the slab faces in two ways -- a particle's sphere covers cells of the neighbour slab
+# (unionParticleLevelset looks one cell around every cell), and extrapolateLsSimple walks `distance` cells away from the surface.
+# =========================================================================================================
+def max_abs_mac(dom, vel):
+    """MACGrid::getMaxAbs over the whole domain (sqrt of the largest |v|^2, grid.cpp:364-366): local maxima over the owned
+    planes, one all-gather, max -- order independent, so bit-identical to the undivided grid"""
+    s = dom.solver
+    own = dom.planes(vel, dom.gl, dom.gl + dom.nown).contiguous()
+    r = ctypes.c_float()
+    s.lib.call("mf_grid_max_abs_vec3", dom.n_own, _ptr(own), ctypes.byref(r), s.stream)
+    g = dom.comm.gather_scalars([r.value], s.device)
+    return float(np.max(g[:, 0]))
+
+
+def adaptTimestep(dom, vel):
+    """s.adaptTimestep(vel.getMaxAbs()) (fluidsolver.cpp:184-204) with the domain-wide maximum: every rank takes the same dt"""
+    dom.solver.adaptTimestep(max_abs_mac(dom, vel))
+
+
+def halo_particles(dom, sp, width, ptype=None):
+    """A particle system holding this rank's particles followed by the neighbours' particles whose cell lies within `width`
+    planes of the slab faces (positions, flags and -- if given -- the ptype column travel; arrivals from below first).  Used
+    where a cell's value depends on the particles of the cells around it."""
+    s, pp = dom.solver, sp.pp
+    halo = core.BasicParticleSystem(s)
+    hpt = halo.create(core.PdataInt) if ptype is not None else None
+    n = pp.np
+    cols = [pp.pos[c * pp.cap:c * pp.cap + n] for c in range(3)] + [pp.flag[:n].view(torch.float32)]
+    if ptype is not None:
+        cols.append(ptype.data[:n].view(torch.float32))
+    packed = torch.stack(cols) if n > 0 else torch.zeros((len(cols), 0), dtype=torch.float32, device=s.device)
+    if dom.comm.world > 1:
+        s.sync()
+        k = torch.floor(packed[2]).to(torch.int64)
+        dn = (k < dom.z0 + width) if dom.below is not None else torch.zeros_like(k, dtype=torch.bool)
+        up = (k >= dom.z1 - width) if dom.above is not None else torch.zeros_like(k, dtype=torch.bool)
+        from_dn, from_up = exchange_columns(dom, packed[:, dn].contiguous(), packed[:, up].contiguous())
+        packed = torch.cat([packed, from_dn, from_up], dim=1)
+    m = packed.shape[1]
+    halo.resizeAll(m)
+    if m:
+        for c in range(3):
+            halo.pos[c * halo.cap:c * halo.cap + m] = packed[c]
+        halo.flag[:m] = packed[3].view(torch.int32)
+        if hpt is not None:
+            hpt.data[:m] = packed[4].view(torch.int32)
+    return halo, hpt
+
+
+def unionParticleLevelset(dom, sp, flags, phi, indexSys=None, index=None, radiusFactor=1.0, ptype=None, exclude=0):
+    """gridParticleIndex + unionParticleLevelset (flip.cpp:273-363) on a slab.  phi of a cell is the minimum over the particles of
+    the cells within r = int(radius) + 1 planes (1 for radiusFactor 1), so the index is built over this rank's particles plus
+    the neighbours' particles of the r planes beyond each slab face: the owned planes come out bit-identical to the undivided
+    domain (a minimum does not depend on the order); the ghost planes are then fetched from their owners."""
+    from . import plugins
+    s = dom.solver
+    radius = 0.5 * math.sqrt(3.0) * (float(radiusFactor) + 0.01)            # calculateRadiusFactor, flip.cpp:198-200
+    r = int(radius) + 1
+    if dom.comm.world > 1 and r > dom.G:
+        raise RuntimeError("slab unionParticleLevelset: particle radius reaches %d planes, domain has %d ghost planes" % (r, dom.G))
+    halo, hpt = halo_particles(dom, sp, r, ptype)
+    indexSys = indexSys if indexSys is not None else core.ParticleIndexSystem(s)
+    index = index if index is not None else core.IntGrid(s)
+    plugins.gridParticleIndex(halo, indexSys, flags, index)
+    plugins.unionParticleLevelset(halo, indexSys, flags, index, phi, radiusFactor, ptype=hpt, exclude=exclude)
+    dom.exchange(phi)
+
+
+def extrapolateLsSimple(dom, phi, distance=4, inside=False, include_walls=False):
+    """fastmarch.cpp:472-522: a mark pass, a first layer and `distance` - 1 one-cell passes.  Run on ghosts `distance` + 2 deep
+    (phi ghosts must be current): every pass spoils one more plane from the outside, the owned planes come out exact."""
+    from . import plugins
+    _need_ghost(dom, distance + 1, "extrapolateLsSimple")
+    plugins.extrapolateLsSimple(phi, distance, inside, include_walls)
+
+
+def markIsolatedFluidCell(dom, flags, mark):
+    """grid.cpp:987-1011 (reads the six neighbours' flags): flag ghosts must be current; the outermost ghost plane has no outer
+    neighbour here, so the ghosts are fetched again afterwards"""
+    from . import plugins
+    plugins.markIsolatedFluidCell(flags, mark)
+    dom.exchange(flags)
 
 
 # =========================================================================================================

@@ -39,6 +39,7 @@ typedef struct {
 	int64_t X, Y, Z, n; /* strides (Z == 0 in 2-D, grid.cpp:56) */
 } Dim;
 static _Thread_local int g_slab_zoff = 0, g_slab_gsz = 0;
+static _Thread_local int g_slab_src_zoff = 0, g_slab_src_gsz = 0;
 int mf_mic_check(void* stream) {
 	(void)stream;
 	return 0;
@@ -57,13 +58,11 @@ int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* ds
 	dot[0] = acc;
 	return 0;
 }
-int mf_set_mic_blocking_x(int cells_x) {
-	(void)cells_x; /* the serial sweep needs no schedule: it runs over whatever coefficients it is given */
-	return 0;
-}
-int mf_set_mic_blocking(int rows_j) {
-	(void)rows_j;
-	return 0;
+int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Ap, const float* A0, const float* Ai,
+                        const float* Aj, const float* Ak, int rows_j, int cells_x, void* st) {
+	(void)rows_j; /* the serial sweep needs no schedule: it runs over whatever (cut) coefficients it is given */
+	(void)cells_x;
+	return mf_mic_init(sx, sy, sz, flags, Ap, A0, Ai, Aj, Ak, st);
 }
 int mf_set_mic_mode(const char* name) {
 	(void)name;
@@ -73,6 +72,12 @@ int mf_set_slab_window(int zoff, int gsz) {
 	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid slab window");
 	g_slab_zoff = zoff;
 	g_slab_gsz = gsz;
+	return 0;
+}
+int mf_set_slab_window_source(int zoff, int gsz) {
+	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid source slab window");
+	g_slab_src_zoff = zoff;
+	g_slab_src_gsz = gsz;
 	return 0;
 }
 static Dim mkdim(int sx, int sy, int sz) {
@@ -87,6 +92,12 @@ static Dim mkdim(int sx, int sy, int sz) {
 	d.Y = sx;
 	d.Z = d.is3d ? (int64_t)sx * sy : 0;
 	d.n = (int64_t)sx * sy * sz;
+	return d;
+}
+static Dim mkdim_src(int sx, int sy, int sz) { /* the source grid of a two-grid call: its own window */
+	Dim d = mkdim(sx, sy, sz);
+	d.zoff = g_slab_src_gsz > 0 ? g_slab_src_zoff : 0;
+	d.gsz = g_slab_src_gsz > 0 ? g_slab_src_gsz : sz;
 	return d;
 }
 #define IDX(d, i, j, k) ((int64_t)(i) + (d).Y * (j) + (d).Z * (k))
@@ -663,6 +674,12 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	if (pc == MF_PC_MICP && !d.is3d) pc = MF_PC_NONE; /* conjugategrad.cpp:315-321 */
 	int iterations = 0;
 	float resNorm = 1e20f, sigma = 0.f;
+	if (maxIter <= 0) { /* GridCg::solve, conjugategrad.cpp:302-307: iterate() (and with it doInit) is never reached */
+		out[0] = 0.f;
+		out[1] = resNorm;
+		out[2] = 0.f;
+		return 0;
+	}
 	/* doInit */
 	memset(dst, 0, sizeof(float) * n);
 	memcpy(residual, rhs, sizeof(float) * n);
@@ -1140,6 +1157,18 @@ int mf_maccormack_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const 
 
 /* applyOutflowBC, advection.cpp:327-392 */
 static int in_bounds(const Dim* d, int i, int j, int k) { return i >= 0 && j >= 0 && k >= 0 && i < d->sx && j < d->sy && k < d->sz; }
+/* Particle positions are GLOBAL grid coordinates; with a z-slab window (mf_set_slab_window: multi-GPU tests) the grid holds
+ * planes [zoff, zoff + sz) of gsz.  cell_of: cell of a position, k as the plane inside the window; 0 when the cell is outside
+ * the domain or the window.  Without a window this is isInBounds(toVec3i(pos)). */
+static int cell_of(const Dim* d, float x, float y, float z, int* i, int* j, int* k) {
+	*i = (int)x;
+	*j = (int)y;
+	const int kg = (int)z;
+	*k = kg - d->zoff;
+	return *i >= 0 && *j >= 0 && kg >= 0 && *i < d->sx && *j < d->sy && kg < d->gsz && *k >= 0 && *k < d->sz;
+}
+/* domain-boundary test in global planes (a slab's outer ghost plane is not a domain wall) */
+static int z_wall(const Dim* d, int k, int w) { return d->is3d && (k + d->zoff <= w || k + d->zoff >= d->gsz - 1 - w); }
 int mf_apply_outflow_bc(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* velPrev, float* velDst,
                         float dtIn, void* st) {
 	(void)st;
@@ -1878,7 +1907,7 @@ int mf_project_out_of_bnd(int sx, int sy, int sz, int64_t np, int64_t ps, float*
 		if (axis & 8) { float hi = (float)sy - bnd; *y = hi < *y ? hi : *y; }
 		if (d.is3d) {
 			if (axis & 16) *z = *z > bnd ? *z : bnd;
-			if (axis & 32) { float hi = (float)sz - bnd; *z = hi < *z ? hi : *z; }
+			if (axis & 32) { float hi = (float)d.gsz - bnd; *z = hi < *z ? hi : *z; }
 		}
 	}
 	return 0;
@@ -1894,6 +1923,10 @@ static void get_gradient(const Dim* d, const float* data, int i, int j, int k, f
 	g[1] = data[IDX(*d, i, j + 1, k)] - data[IDX(*d, i, j - 1, k)];
 	g[2] = 0.f;
 	if (d->is3d) {
+		int kg = k + d->zoff; /* clamp to [1, size - 2] of the whole domain; inside a slab window stay addressable */
+		if (kg > d->gsz - 2) kg = d->gsz - 2;
+		if (kg < 1) kg = 1;
+		k = kg - d->zoff;
 		if (k > d->sz - 2) k = d->sz - 2;
 		if (k < 1) k = 1;
 		g[2] = data[IDX(*d, i, j, k + 1)] - data[IDX(*d, i, j, k - 1)];
@@ -1926,8 +1959,8 @@ int mf_push_out_of_obs(int sx, int sy, int sz, int64_t np, int64_t ps, float* po
 	for (int64_t p = 0; p < np; p++) {
 		if ((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude))) continue;
 		float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
-		int i = (int)x, j = (int)y, k = (int)z;
-		if (!in_bounds(&d, i, j, k)) continue;
+		int i, j, k;
+		if (!cell_of(&d, x, y, z, &i, &j, &k)) continue;
 		float v = interpol1(&d, phiObs, x, y, z);
 		if (v < thresh) {
 			float g[3];
@@ -1955,8 +1988,8 @@ int mf_grid_particle_index(int sx, int sy, int sz, int64_t np, int64_t ps, const
 	int64_t inactive = 0;
 	for (int64_t p = 0; p < np; p++) {
 		if (pflag[p] & MF_PDELETE) { inactive++; continue; }
-		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
-		if (!in_bounds(&d, i, j, k)) { inactive++; continue; }
+		int i, j, k;
+		if (!cell_of(&d, pos[p], pos[ps + p], pos[2 * ps + p], &i, &j, &k)) { inactive++; continue; }
 		index[IDX(d, i, j, k)]++;
 	}
 	int64_t run = 0;
@@ -1967,8 +2000,8 @@ int mf_grid_particle_index(int sx, int sy, int sz, int64_t np, int64_t ps, const
 	}
 	for (int64_t p = 0; p < np; p++) {
 		if (pflag[p] & MF_PDELETE) continue;
-		int i = (int)pos[p], j = (int)pos[ps + p], k = (int)pos[2 * ps + p];
-		if (!in_bounds(&d, i, j, k)) continue;
+		int i, j, k;
+		if (!cell_of(&d, pos[p], pos[ps + p], pos[2 * ps + p], &i, &j, &k)) continue;
 		int64_t c = IDX(d, i, j, k);
 		indexSys[index[c] + counter[c]] = (int32_t)p;
 		counter[c]++;
@@ -1991,7 +2024,7 @@ int mf_union_particle_levelset(int sx, int sy, int sz, int64_t np, int64_t ps, c
 	for (int k = 0; k < sz; k++)
 		for (int j = 0; j < sy; j++)
 			for (int i = 0; i < sx; i++) {
-				const float gx = (float)i + 0.5f, gy = (float)j + 0.5f, gz = (float)k + 0.5f;
+				const float gx = (float)i + 0.5f, gy = (float)j + 0.5f, gz = (float)(k + d.zoff) + 0.5f;
 				float phiv = (float)((double)radius * 1.0);
 				for (int zj = k - rZ; zj <= k + rZ; zj++)
 					for (int yj = j - r; yj <= j + r; yj++)
@@ -2112,7 +2145,7 @@ int mf_shape_apply_to_grid(int sx, int sy, int sz, int kind, const float* q, int
 			for (int i = 0; i < sx; i++) {
 				const int64_t idx = IDX(d, i, j, k);
 				if (respectFlags && (respectFlags[idx] & MF_OBSTACLE)) continue;
-				const float x = (float)i, y = (float)j, z = (float)k;
+				const float x = (float)i, y = (float)j, z = (float)(k + d.zoff);
 				if (gridkind == 2) {
 					if (shape_inside(kind, q, x, y + 0.5f, z + 0.5f)) gf[idx] = value[0];
 					if (shape_inside(kind, q, x + 0.5f, y, z + 0.5f)) gf[n + idx] = value[1];
@@ -2137,7 +2170,7 @@ int mf_shape_levelset(int sx, int sy, int sz, int kind, const float* q, float* p
 	for (int k = 0; k < sz; k++)
 		for (int j = 0; j < sy; j++)
 			for (int i = 0; i < sx; i++) {
-				const float x = (float)i + 0.5f, y = (float)j + 0.5f, z = (float)k + 0.5f;
+				const float x = (float)i + 0.5f, y = (float)j + 0.5f, z = (float)(k + d.zoff) + 0.5f;
 				phi[IDX(d, i, j, k)] = kind == 0 ? shape_sdf_box(d.is3d, q, x, y, z) : (kind == 1 ? shape_sdf_sphere(q, x, y, z) : shape_sdf_cylinder(q, x, y, z));
 			}
 	return 0;
@@ -2171,7 +2204,7 @@ int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int w, v
 	for (int k = 0; k < sz; k++)
 		for (int j = 0; j < sy; j++)
 			for (int i = 0; i < sx; i++) {
-				int bnd = (i <= w || i >= sx - 1 - w || j <= w || j >= sy - 1 - w || (d.is3d && (k <= w || k >= sz - 1 - w)));
+				int bnd = (i <= w || i >= sx - 1 - w || j <= w || j >= sy - 1 - w || z_wall(&d, k, w));
 				if (bnd) grid[IDX(d, i, j, k)] = value;
 			}
 	return 0;
@@ -2187,17 +2220,21 @@ int mf_extrapolate_ls_simple(int sx, int sy, int sz, float* phi, int distance, i
 	memset(tmp, 0, sizeof(int32_t) * d.n);
 	float direction = 1.f;
 	if (!inside) {
-		for (int k = K0(d, 1); k < K1(d, 1); k++)
+		for (int k = 0; k < sz; k++) {
+			if (d.is3d && (k + d.zoff < 1 || k + d.zoff >= d.gsz - 1)) continue;
 			for (int j = 1; j < sy - 1; j++)
 				for (int i = 1; i < sx - 1; i++)
 					if (phi[IDX(d, i, j, k)] < 0.) tmp[IDX(d, i, j, k)] = 1;
+		}
 	} else {
 		direction = -1.f;
 		const int b = include_walls ? 0 : 1;
-		for (int k = K0(d, b); k < K1(d, b); k++)
+		for (int k = 0; k < sz; k++) {
+			if (d.is3d && (k + d.zoff < b || k + d.zoff >= d.gsz - b)) continue; /* the b-cell border of the DOMAIN (global planes) */
 			for (int j = b; j < sy - b; j++)
 				for (int i = b; i < sx - b; i++)
 					if (phi[IDX(d, i, j, k)] > 0.) tmp[IDX(d, i, j, k)] = 1;
+		}
 	}
 	for (int k = K0(d, 1); k < K1(d, 1); k++)
 		for (int j = 1; j < sy - 1; j++)

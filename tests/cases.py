@@ -80,15 +80,23 @@ def run_apply_matrix_ref(dims, flags, A, src):
     return dst
 
 
-def run_mic_impl(impl, dims, flags, A, var1):
+def run_mic_impl(impl, dims, flags, A, var1, blocking=None, then_plain=None):
+    """blocking = (rows_j, cells_x): mf_mic_init_blocked (the caller has cut A accordingly).  then_plain = another (uncut) system:
+    after the blocked one, an ordinary mf_mic_init / mf_mic_apply on it in the same process must be the uncut reference sweep
+    (the blocking belongs to the system it was given with)"""
     sx, sy, sz = dims
     ap = impl.dev(np.full((sz, sy, sx), 3.0, np.float32))
     dA = [impl.dev(a) for a in A]
     f = impl.dev(flags)
-    impl.call("mf_mic_init", sx, sy, sz, f, ap, dA[0], dA[1], dA[2], dA[3], None)
+    if blocking is None:
+        impl.call("mf_mic_init", sx, sy, sz, f, ap, dA[0], dA[1], dA[2], dA[3], None)
+    else:
+        impl.call("mf_mic_init_blocked", sx, sy, sz, f, ap, dA[0], dA[1], dA[2], dA[3], int(blocking[0]), int(blocking[1]), None)
     dst = impl.dev(np.zeros((sz, sy, sx), np.float32))
     impl.call("mf_mic_apply", sx, sy, sz, f, dst, impl.dev(var1), ap, dA[1], dA[2], dA[3], None)
     impl.sync()
+    if then_plain is not None:
+        return impl.host(ap), impl.host(dst), run_mic_impl(impl, dims, flags, then_plain, var1)
     return impl.host(ap), impl.host(dst)
 
 
@@ -676,12 +684,45 @@ def run_surface_ref(dims, I, dt=0.35):
     return out
 
 
-def run_dam_pkg(res, steps, deterministic=True):
+def dam_geometry(res, zflow=False):
+    """grid size and the boxes of the dam-break case: the long axis is x (as in scenes/benchmark_dam.py) or, for the z-slab
+    tests, z -- the liquid then crosses the slab faces"""
+    bnd = 3
+    ext = (int(res * 1.6) + 2 * bnd, res + 2 * bnd, res // 2 + 2 * bnd)
+    obs_c, obs_s = (0.45 * ext[0], bnd + 0.1 * res, 0.5 * ext[2]), (0.06 * res, 0.1 * res, 0.2 * res)
+    dam_c, dam_s = (ext[0] - bnd - 0.25 * res, bnd + 0.3 * res, 0.5 * ext[2]), (0.25 * res, 0.3 * res, 0.25 * res)
+    if zflow:
+        # a longer dam (it straddles the slab faces of a 2- and a 3-rank split) and the obstacle further down-stream
+        obs_c = (0.25 * ext[0], bnd + 0.1 * res, 0.5 * ext[2])
+        dam_c, dam_s = (ext[0] - bnd - 0.45 * res, bnd + 0.3 * res, 0.5 * ext[2]), (0.45 * res, 0.3 * res, 0.25 * res)
+        sw = lambda t: (t[2], t[1], t[0])
+        ext, obs_c, obs_s, dam_c, dam_s = sw(ext), sw(obs_c), sw(obs_s), sw(dam_c), sw(dam_s)
+    return bnd, ext, obs_c, obs_s, dam_c, dam_s
+
+
+def dam_setup(s, fl, phiS, pp, pT, res, zflow=False):
+    """set-up of the dam break on a whole-domain solver (own code; the call sequence of scenes/benchmark_dam.py:66-92)"""
+    from mantaflow_amd import core, scene
+    bnd, gs, obs_c, obs_s, dam_c, dam_s = dam_geometry(res, zflow)
+    fl.initDomain(bnd - 1)
+    outer = s.create(scene.Box, p0=core.vec3(0), p1=core.vec3(*gs))
+    inner = s.create(scene.Box, p0=core.vec3(bnd), p1=core.vec3(gs[0] - bnd, gs[1] - bnd, gs[2] - bnd))
+    phiS.join(outer.computeLevelset())
+    phiS.subtract(inner.computeLevelset())
+    obs = s.create(scene.Box, center=core.vec3(*obs_c), size=core.vec3(*obs_s))
+    obs.applyToGrid(grid=fl, value=2, respectFlags=fl)
+    phiS.join(obs.computeLevelset())
+    dam = s.create(scene.Box, center=core.vec3(*dam_c), size=core.vec3(*dam_s))
+    dam.applyToGrid(grid=fl, value=1, respectFlags=fl)
+    scene.sampleShapeWithParticles(shape=dam, flags=fl, parts=pp, discretization=2, randomness=0)
+    pT.setConstRange(1, 0, pp.pySize())
+
+
+def run_dam_pkg(res, steps, deterministic=True, zflow=False, cgacc=1e-3):
     """a ghost-fluid FLIP dam break with the call sequence of scenes/benchmark_dam.py's main loop (own set-up code)"""
     from mantaflow_amd import core, plugins, scene
     FF, FE = 1, 4
-    bnd, sres = 3, 2
-    gs = (int(res * 1.6) + 2 * bnd, res + 2 * bnd, res // 2 + 2 * bnd)
+    bnd, gs = dam_geometry(res, zflow)[:2]
     s = core.Solver(name="dam", gridSize=core.vec3(*gs), dim=3)
     s.cfl, s.frameLength, s.timestepMin = 1, 1.0 / 30, 0
     s.timestepMax = s.timestep = s.frameLength
@@ -691,29 +732,20 @@ def run_dam_pkg(res, steps, deterministic=True):
     isys, idx = s.create(core.ParticleIndexSystem), s.create(core.IntGrid)
     pp = s.create(core.BasicParticleSystem)
     pT, pV, pX = pp.create(core.PdataInt), pp.create(core.PdataVec3), pp.create(core.PdataVec3)
-    fl.initDomain(bnd - 1)
-    outer = s.create(scene.Box, p0=core.vec3(0), p1=core.vec3(*gs))
-    inner = s.create(scene.Box, p0=core.vec3(bnd), p1=core.vec3(gs[0] - bnd, gs[1] - bnd, gs[2] - bnd))
-    phiS.join(outer.computeLevelset())
-    phiS.subtract(inner.computeLevelset())
-    obs = s.create(scene.Box, center=core.vec3(0.45 * gs[0], bnd + 0.1 * res, 0.5 * gs[2]), size=core.vec3(0.06 * res, 0.1 * res, 0.2 * res))
-    obs.applyToGrid(grid=fl, value=2, respectFlags=fl)
-    phiS.join(obs.computeLevelset())
-    dam = s.create(scene.Box, center=core.vec3(gs[0] - bnd - 0.25 * res, bnd + 0.3 * res, 0.5 * gs[2]), size=core.vec3(0.25 * res, 0.3 * res, 0.25 * res))
-    dam.applyToGrid(grid=fl, value=FF, respectFlags=fl)
-    scene.sampleShapeWithParticles(shape=dam, flags=fl, parts=pp, discretization=sres, randomness=0)
-    pT.setConstRange(FF, 0, pp.pySize())
+    dam_setup(s, fl, phiS, pp, pT, res, zflow)
     grav = core.vec3(0, -9.8 * res, 0)
-    iters = []
-    for _ in range(steps):
+    iters, rec = [], {}
+    for step in range(steps):
         plugins.mapPartsToMAC(vel=V, flags=fl, velOld=Vold, parts=pp, partVel=pV, ptype=pT, exclude=FE)
         s.adaptTimestep(V.getMaxAbs())
         plugins.addGravityNoScale(flags=fl, vel=V, gravity=grav)
         plugins.gridParticleIndex(parts=pp, flags=fl, indexSys=isys, index=idx)
         plugins.unionParticleLevelset(parts=pp, indexSys=isys, flags=fl, index=idx, phi=phi, radiusFactor=1.0)
         plugins.extrapolateLsSimple(phi=phi, distance=4, inside=True)
+        if step == steps - 1:      # the last step's level set, before the solve feeds back
+            rec["phi_ls"], rec["dt_ls"] = grid_to_soa(phi), float(s.timestep)
         plugins.setWallBcs(flags=fl, vel=V)
-        plugins.solvePressure(flags=fl, vel=V, pressure=P, cgAccuracy=1e-3, phi=phi)
+        plugins.solvePressure(flags=fl, vel=V, pressure=P, cgAccuracy=cgacc, phi=phi)
         iters.append(plugins.lastCgStats()["iterations"])
         plugins.setWallBcs(flags=fl, vel=V)
         plugins.extrapolateMACSimple(flags=fl, vel=V)
@@ -734,7 +766,7 @@ def run_dam_pkg(res, steps, deterministic=True):
     plugins.setDeterministicP2G(True)
     return dict(pos=_ppos(pp), pvel=np.ascontiguousarray(pV.to_numpy().T), ptype=pT.data[:pp.np].cpu().numpy().copy(),
                 flags=grid_to_soa(fl), phi=grid_to_soa(phi), vel=grid_to_soa(V), pres=grid_to_soa(P), iters=iters, gs=gs,
-                dt=float(s.timestep))
+                dt=float(s.timestep), rec=rec)
 
 
 # ---- resampling between grids of different size ----

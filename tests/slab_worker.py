@@ -91,6 +91,76 @@ def liquid_case(out, dims):
              vel=dom.gather_owned(vel), iters=np.array(iters), **rec)
 
 
+def dam_case(out, res, steps=3):
+    """the main loop of scenes/benchmark_dam.py (ghost-fluid FLIP dam break, BASELINE config 4) on z-slabs, flowing along z: P2G with
+    ptype exclusion, domain-wide adaptTimestep, particle level set with a one-cell particle halo, extrapolateLsSimple on the
+    ghosts, ghost-fluid solvePressure, FLIP update, RK4 advection + eulerStep / projectOutOfBnd / pushOutofObs, migration,
+    markFluidCells / setPartType / markIsolatedFluidCell.  The set-up runs on a plain whole-domain solver IN THE SAME PROCESS
+    (its slab window stays (0, 0) while the slab solver's is (lo, NZ))."""
+    import cases
+    from mantaflow_amd import core, plugins, slab
+    FF, FE = 1, 4
+    bnd, gs = cases.dam_geometry(res, zflow=True)[:2]
+    dom = slab.SlabDomain(gs, slab.required_ghost(2.0))
+    s = dom.solver
+    s.cfl, s.frameLength, s.timestepMin = 1, 1.0 / 30, 0
+    s.timestepMax = s.timestep = s.frameLength
+    # ---- set-up on the whole domain, then scattered ----
+    sg = core.Solver(name="setup", gridSize=core.vec3(*gs), dim=3)
+    flg, phiSg, ppg = sg.create(core.FlagGrid), sg.create(core.LevelsetGrid), sg.create(core.BasicParticleSystem)
+    pTg = ppg.create(core.PdataInt)
+    cases.dam_setup(sg, flg, phiSg, ppg, pTg, res, zflow=True)
+    flags_g, phiS_g = cases.grid_to_soa(flg), cases.grid_to_soa(phiSg)
+    pos, pflag, ptype = cases._ppos(ppg), ppg.get_flags(), pTg.data[:ppg.np].cpu().numpy().copy()
+    del flg, phiSg, ppg, pTg, sg
+    pid = np.arange(pos.shape[1], dtype=np.int32)
+    fl, V, Vold, P = core.FlagGrid(s), core.MACGrid(s), core.MACGrid(s), core.Grid(s)
+    phiS, phi = core.LevelsetGrid(s), core.LevelsetGrid(s)
+    isys, idx = core.ParticleIndexSystem(s), core.IntGrid(s)
+    dom.scatter_global(fl, flags_g); dom.scatter_global(phiS, phiS_g)
+    sp = slab.SlabParticles(dom)
+    pT, pV, pX, pI = sp.create(core.PdataInt), sp.create(core.PdataVec3), sp.create(core.PdataVec3), sp.create(core.PdataInt)
+    sp.scatter_global(pos, pflag, [(pT, ptype), (pI, pid)])
+    n0 = sp.np
+    grav = core.vec3(0, -9.8 * res, 0)
+    rec, iters, dts, moved = {}, [], [], 0
+    for step in range(steps):
+        slab.mapPartsToMAC(dom, fl, V, Vold, sp, pV, ptype=pT, exclude=FE)
+        slab.adaptTimestep(dom, V)
+        dts.append(s.timestep)
+        plugins.addGravityNoScale(flags=fl, vel=V, gravity=grav)
+        slab.unionParticleLevelset(dom, sp, fl, phi, indexSys=isys, index=idx, radiusFactor=1.0)
+        slab.extrapolateLsSimple(dom, phi, distance=4, inside=True)
+        if step in (0, steps - 1):
+            rec["phi_ls%d" % (0 if step == 0 else 1)] = dom.gather_owned(phi).copy()
+        dom.exchange(V, 1)
+        slab.setWallBcs(dom, fl, V)
+        st = {}
+        slab.solvePressure(dom, V, P, fl, cgAccuracy=1e-6, phi=phi, stats=st)
+        iters.append(st["iterations"])
+        dom.exchange(V, 1)
+        slab.setWallBcs(dom, fl, V)
+        slab.extrapolateMACSimple(dom, fl, V)
+        slab.flipVelocityUpdate(dom, fl, V, Vold, sp, pV, 0.97, ptype=pT, exclude=FE)
+        plugins.addForcePvel(vel=pV, a=grav, dt=s.timestep, ptype=pT, exclude=FF)
+        sp.pp.getPosPdata(target=pX)
+        slab.advectInGrid(dom, sp, fl, V, 2, deleteInObstacle=False, ptype=pT, exclude=FE, migrate=False)
+        plugins.eulerStep(parts=sp.pp, vel=pV, ptype=pT, exclude=FF)
+        sp.pp.projectOutOfBnd(flags=fl, bnd=bnd + 0.25, plane="xXyYzZ", ptype=pT)
+        plugins.pushOutofObs(parts=sp.pp, flags=fl, phiObs=phiS, thresh=0.25, ptype=pT)
+        plugins.updateVelocityFromDeltaPos(parts=sp.pp, vel=pV, x_prev=pX, dt=s.timestep, ptype=pT, exclude=FF)
+        moved += sp.migrate()
+        slab.markFluidCells(dom, sp, fl, ptype=pT)
+        plugins.setPartType(parts=sp.pp, ptype=pT, mark=FF, stype=FE, flags=fl, cflag=FF)
+        slab.markIsolatedFluidCell(dom, fl, FE)
+        plugins.setPartType(parts=sp.pp, ptype=pT, mark=FE, stype=FF, flags=fl, cflag=FE)
+        s.step()
+    fin = sp.gather()
+    np.savez(out + ".%d.npz" % dom.comm.rank, n0=n0, moved=moved, pid=fin["pdata3"][0], pos=fin["pos"], ptype=fin["pdata0"][0],
+             pvel=fin["pdata1"], flags=dom.gather_owned(fl), vel=dom.gather_owned(V), pres=dom.gather_owned(P),
+             phi=dom.gather_owned(phi), iters=np.array(iters), dts=np.array(dts), **rec)
+
+
 def main():
     out, backend = sys.argv[1], sys.argv[2]
     dims = tuple(int(v) for v in sys.argv[3].split("x"))
@@ -102,8 +172,11 @@ def main():
     else:
         torch.cuda.set_device(0)
         _lib.get()
-    if len(sys.argv) > 4 and sys.argv[4] in ("flip", "liquid"):
-        (flip_case if sys.argv[4] == "flip" else liquid_case)(out, dims)
+    if len(sys.argv) > 4 and sys.argv[4] in ("flip", "liquid", "dam"):
+        if sys.argv[4] == "dam":
+            dam_case(out, dims[0])        # "dims" carries the resolution of the dam case: RESx0x0
+        else:
+            (flip_case if sys.argv[4] == "flip" else liquid_case)(out, dims)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -130,8 +203,20 @@ def main():
     dom.exchange(vel, 1)
     rhs = core.Grid(s)
     s.lib.call("mf_make_rhs", NX, NY, dom.LZ, flags.ptr, rhs.ptr, vel.ptr, None, None, None, None, None, 0.0, 1e-4, None, None, s.stream)
+    # a plain whole-domain solver created AFTER the slab domain, in the same process and thread: its grids are the whole domain
+    # (window (0, 0)) whatever the slab solver's window is -- its advection must be the single-device result on every rank
+    import cases
+    from mantaflow_amd import plugins
+    sg = core.Solver(gridSize=core.vec3(NX, NY, NZ), dim=3)
+    sg.timestep = 0.9
+    fg, vg, dg = core.FlagGrid(sg), core.MACGrid(sg), core.Grid(sg)
+    cases.soa_to_grid(fg, flags_g); cases.soa_to_grid(vg, vel_g); cases.soa_to_grid(dg, dens_g)
+    plugins.advectSemiLagrange(fg, vg, dg, order=2)
+    slab.setWallBcs(dom, flags, vel)                     # a slab call in between (idempotent here) ...
+    plugins.advectSemiLagrange(fg, vg, dg, order=1)      # ... and the plain solver again
     np.savez(out + ".%d.npz" % dom.comm.rank, z0=dom.z0, z1=dom.z1, dens=dom.gather_owned(dens), vel_adv=vel_adv,
-             vel=dom.gather_owned(vel), pres=dom.gather_owned(pres), div=dom.gather_owned(rhs), iters=st["iterations"], res=st["residual"])
+             vel=dom.gather_owned(vel), pres=dom.gather_owned(pres), div=dom.gather_owned(rhs), iters=st["iterations"], res=st["residual"],
+             plain_dens=cases.grid_to_soa(dg))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -171,49 +171,49 @@ def test_mic_and_cg_with_a_matrix_that_cannot_be_packed(hip, oracle, dims, varia
 
 @pytest.mark.parametrize("dims,rows", [((32, 64, 24), 16), ((24, 100, 40), 32), ((40, 72, 17), 24)])
 def test_mic_blocked_sweeps_equal_serial_sweep_of_cut_system(hip, oracle, dims, rows):
-    """mf_set_mic_blocking (multi-GPU block-Jacobi in y): with the Aj coupling zeroed at the block faces the row-streaming
-    sweeps skip those hand-offs and still give the bits of the serial sweep over the same cut coefficients"""
+    """mf_mic_init_blocked (multi-GPU block-Jacobi in y): with the Aj coupling zeroed at the block faces the row-streaming
+    sweeps skip those hand-offs and still give the bits of the serial sweep over the same cut coefficients.  The blocking
+    belongs to the system it was given with: an uncut system solved afterwards in the same process is the plain reference sweep."""
     sx, sy, sz = dims
-    flags, A, src = cases.system_inputs(dims, 7)
-    A = [a.copy() for a in A]
+    flags, A0, src = cases.system_inputs(dims, 7)
+    A = [a.copy() for a in A0]
     for jc in range(rows, sy, rows):
         A[2][:, jc - 1, :] = 0          # Aj couples rows j and j+1
     ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
-    assert hip.lib.cdll.mf_set_mic_blocking(rows) == 0
-    try:
-        ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
-        ap2, dst2 = cases.run_mic_impl(hip, dims, flags, A, src)
-    finally:
-        assert hip.lib.cdll.mf_set_mic_blocking(0) == 0
+    apu_o, dstu_o = cases.run_mic_impl(oracle, dims, flags, A0, src)
+    ap, dst, (apu, dstu) = cases.run_mic_impl(hip, dims, flags, A, src, blocking=(rows, 0), then_plain=A0)
+    ap2, dst2 = cases.run_mic_impl(hip, dims, flags, A, src, blocking=(rows, 0))
     assert_bitexact(ap, ap_o, "Aprecond (cut)")
     assert_bitexact(dst, dst_o, "blocked mic apply")
     assert_bitexact(dst, dst2, "blocked mic apply re-run")
-    assert hip.lib.cdll.mf_set_mic_blocking(12) != 0
+    assert_bitexact(apu, apu_o, "Aprecond (uncut system after a blocked one)")
+    assert_bitexact(dstu, dstu_o, "uncut mic apply after a blocked one")
+    with pytest.raises(RuntimeError):
+        cases.run_mic_impl(hip, dims, flags, A, src, blocking=(12, 0))
 
 
 @pytest.mark.parametrize("dims,rows,cells", [((64, 64, 24), 16, 32), ((72, 40, 17), 0, 24), ((100, 48, 16), 24, 48), ((256, 64, 16), 32, 64)])
 def test_mic_x_blocked_sweeps_equal_serial_sweep_of_cut_system(hip, oracle, dims, rows, cells):
-    """mf_set_mic_blocking_x: independent x-blocks (Ai zeroed at the block faces), alone and together with the y-blocking; the
-    last x-block may be shorter than the others"""
+    """mf_mic_init_blocked, x-blocks (Ai zeroed at the block faces), alone and together with the y-blocking; the last x-block may
+    be shorter than the others"""
     sx, sy, sz = dims
-    flags, A, src = cases.system_inputs(dims, 9)
-    A = [a.copy() for a in A]
+    flags, A0, src = cases.system_inputs(dims, 9)
+    A = [a.copy() for a in A0]
     for ic in range(cells, sx, cells):
         A[1][:, :, ic - 1] = 0          # Ai couples cells i and i+1
     if rows:
         for jc in range(rows, sy, rows):
             A[2][:, jc - 1, :] = 0
     ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
-    assert hip.lib.cdll.mf_set_mic_blocking_x(cells) == 0 and hip.lib.cdll.mf_set_mic_blocking(rows) == 0
-    try:
-        ap, dst = cases.run_mic_impl(hip, dims, flags, A, src)
-        ap2, dst2 = cases.run_mic_impl(hip, dims, flags, A, src)
-    finally:
-        assert hip.lib.cdll.mf_set_mic_blocking_x(0) == 0 and hip.lib.cdll.mf_set_mic_blocking(0) == 0
+    apu_o, dstu_o = cases.run_mic_impl(oracle, dims, flags, A0, src)
+    ap, dst, (apu, dstu) = cases.run_mic_impl(hip, dims, flags, A, src, blocking=(rows, cells), then_plain=A0)
+    ap2, dst2 = cases.run_mic_impl(hip, dims, flags, A, src, blocking=(rows, cells))
     assert_bitexact(ap, ap_o, "Aprecond (cut)")
     assert_bitexact(dst, dst_o, "x-blocked mic apply")
     assert_bitexact(dst, dst2, "x-blocked mic apply re-run")
-    assert hip.lib.cdll.mf_set_mic_blocking_x(12) != 0
+    assert_bitexact(dstu, dstu_o, "uncut mic apply after an x-blocked one")
+    with pytest.raises(RuntimeError):
+        cases.run_mic_impl(hip, dims, flags, A, src, blocking=(0, 12))
 
 
 def test_mic_mode_rejects_unknown_name(hip):

@@ -4,8 +4,8 @@ import numpy as np
 import pytest
 
 import util
-from test_slab_gloo import (check_against_single, check_flip_against_single, check_liquid_against_single, run_flip_world,
-                            run_liquid_world, run_world)
+from test_slab_gloo import (check_against_single, check_dam_against_single, check_flip_against_single, check_liquid_against_single,
+                            run_dam_world, run_flip_world, run_liquid_world, run_world)
 
 pytestmark = pytest.mark.gpu
 
@@ -47,3 +47,18 @@ def test_liquid_loop_two_ranks_on_hip(tmp_path):
     util.assert_bitexact(single["vel_ext0"], ora["vel_ext0"], "P2G + extrapolation hip vs oracle")
     assert single["iters"] == ora["iters"]
     assert util.rel_err(single["pvel"], ora["pvel"]) <= 1e-5 and np.abs(single["pos"] - ora["pos"]).max() <= 1e-4
+
+
+def test_dam_break_loop_two_ranks_on_hip(tmp_path):
+    """BASELINE config 4 on slabs: three steps of the benchmark_dam.py loop (ghost-fluid solve, particle level set with the particle
+    halo, extrapolateLsSimple on the ghosts, setPartType / markIsolatedFluidCell) through the HIP library, 2 ranks on the one GPU
+    vs 1 rank; and the single-rank HIP run against the oracle's: index work bit-exact, fields within 1e-5"""
+    single = run_dam_world(tmp_path, 1, "hip", res=20)
+    multi = run_dam_world(tmp_path, 2, "hip", res=20)
+    check_dam_against_single(single, multi)
+    ora = run_dam_world(tmp_path, 1, "oracle", res=20)
+    assert (single["flags"] == ora["flags"]).all() and (single["ptype"] == ora["ptype"]).all()
+    util.assert_bitexact(single["phi_ls0"], ora["phi_ls0"], "level set, step 1, hip vs oracle")
+    assert single["iters"] == ora["iters"] and single["dts"] == ora["dts"]
+    for k in ("pos", "pvel", "vel", "pres"):
+        assert util.rel_err(single[k], ora[k]) <= 1e-5, k

@@ -34,12 +34,15 @@ def run_world(tmp_path, world, backend, dims="20x16x36"):
     parts = [dict(np.load(out + ".%d.npz" % r)) for r in range(world)]
     cat = lambda k, ax: np.concatenate([p[k] for p in parts], axis=ax)
     return dict(dens=cat("dens", 0), vel_adv=cat("vel_adv", 1), vel=cat("vel", 1), pres=cat("pres", 0), div=cat("div", 0),
-                iters=[int(p["iters"]) for p in parts], res=[float(p["res"]) for p in parts])
+                iters=[int(p["iters"]) for p in parts], res=[float(p["res"]) for p in parts], plain_dens=[p["plain_dens"] for p in parts])
 
 
 def check_against_single(single, multi):
     util.assert_bitexact(multi["dens"], single["dens"], "advected density")
     util.assert_bitexact(multi["vel_adv"], single["vel_adv"], "advected velocity")
+    # a plain solver living next to the slab solver (window lo > 0 on the upper ranks) computes the single-device result
+    for r, pd in enumerate(multi["plain_dens"]):
+        util.assert_bitexact(pd, single["plain_dens"][0], "plain solver beside the slab solver of rank %d" % r)
     assert len(set(multi["iters"])) == 1, "every rank must take identical CG branches"
     assert max(multi["res"]) < 1e-4
     assert np.abs(multi["div"]).max() < 2e-3
@@ -220,3 +223,56 @@ def test_liquid_single_rank_slab_equals_plugin_path(liquid_single, oracle_backen
 @pytest.mark.parametrize("world", [2, 3])
 def test_liquid_slab_world(tmp_path, liquid_single, world):
     check_liquid_against_single(liquid_single, run_liquid_world(tmp_path, world))
+
+
+# ---- the whole benchmark_dam.py loop on slabs (BASELINE config 4: ghost-fluid FLIP dam break) ---------------------------
+DAM_RES = 16
+
+
+def run_dam_world(tmp_path, world, backend="oracle", res=DAM_RES):
+    parts = _run_case(tmp_path, world, backend, "%dx0x0" % res, "dam")
+    o = np.argsort(np.concatenate([p["pid"] for p in parts]), kind="stable")
+    cat = lambda k, ax: np.concatenate([p[k] for p in parts], axis=ax)
+    return dict(pid=cat("pid", 0)[o], pos=cat("pos", 1)[:, o], pvel=cat("pvel", 1)[:, o], ptype=cat("ptype", 0)[o], flags=cat("flags", 0),
+                vel=cat("vel", 1), pres=cat("pres", 0), phi=cat("phi", 0), phi_ls0=cat("phi_ls0", 0), phi_ls1=cat("phi_ls1", 0),
+                moved=sum(int(p["moved"]) for p in parts), n0=[int(p["n0"]) for p in parts], iters=[list(p["iters"]) for p in parts],
+                dts=[list(p["dts"]) for p in parts])
+
+
+def check_dam_against_single(one, m):
+    assert (m["pid"] == one["pid"]).all() and m["moved"] > 0 and sum(n > 0 for n in m["n0"]) >= 2, "the case must cross a slab face"
+    # every rank takes the same branches: identical CG iteration counts and time steps (domain-wide max |v|)
+    assert all(it == m["iters"][0] for it in m["iters"]) and all(dt == m["dts"][0] for dt in m["dts"])
+    assert m["dts"][0] == one["dts"][0]
+    # step 1, before the first solve feeds back: the particle level set (one-cell particle halo, a minimum: order independent)
+    # and its extrapolation on the ghosts are bit-identical to the undivided domain
+    util.assert_bitexact(m["phi_ls0"], one["phi_ls0"], "union level set + extrapolateLsSimple, step 1")
+    # after the steps (block-Jacobi-preconditioned ghost-fluid solves to 1e-6): converged-solution level; index work exact
+    assert (m["flags"] != one["flags"]).mean() < 2e-3 and (m["ptype"] != one["ptype"]).mean() < 2e-3
+    assert np.abs(m["phi_ls1"] - one["phi_ls1"]).max() < 1e-3
+    assert np.abs(m["pos"] - one["pos"]).max() < 5e-3
+    for k in ("pvel", "vel", "pres"):
+        assert np.abs(m[k] - one[k]).max() < 5e-3 * max(np.abs(one[k]).max(), 1.0), k
+
+
+@pytest.fixture(scope="module")
+def dam_single(tmp_path_factory):
+    return run_dam_world(tmp_path_factory.mktemp("dam1"), 1)
+
+
+def test_dam_single_rank_slab_equals_plugin_path(dam_single, oracle_backend):
+    """world 1: the benchmark_dam loop through the slab operators (a slab solver next to a plain set-up solver in one process) =
+    the same loop through the plugins: index work bit for bit, fields within the fp32 tolerance (the slab PCG combines its fp64
+    partial sums per rank)"""
+    import cases
+    ref = cases.run_dam_pkg(DAM_RES, 3, zflow=True, cgacc=1e-6)
+    assert dam_single["iters"][0] == ref["iters"]
+    assert (dam_single["flags"] == ref["flags"]).all() and (dam_single["ptype"] == ref["ptype"]).all()
+    util.assert_bitexact(dam_single["phi_ls1"], ref["rec"]["phi_ls"], "level set of the last step")
+    for k in ("pos", "pvel", "vel", "pres"):
+        assert util.rel_err(dam_single[k], ref[k]) <= 1e-5, k
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dam_slab_world(tmp_path, dam_single, world):
+    check_dam_against_single(dam_single, run_dam_world(tmp_path, world))
