@@ -193,7 +193,10 @@ class FluidSolver(PbClass):
     def is2D(self): return self.mDim == 2
     def is3D(self): return self.mDim == 3
     def getDt(self): return float(np.float32(self.timestep))
-    def getDx(self): return 1.0 / (getattr(self, "_global_max", None) or max(self.mGridSize))   # a z-slab reports the whole domain's dx
+    def globalGridSize(self):
+        """size of the whole domain: mGridSize, or -- for the solver of a z-slab (slab.SlabDomain) -- the undivided grid's"""
+        return getattr(self, "_global_size", None) or self.mGridSize
+    def getDx(self): return 1.0 / max(self.globalGridSize())   # a z-slab reports the whole domain's dx
     @property
     def ncells(self): return self.mGridSize[0] * self.mGridSize[1] * self.mGridSize[2]
     @property
@@ -293,7 +296,7 @@ class GridBase(PbClass):
     def getSize(self): return vec3(self.sx, self.sy, self.sz)
     def is3D(self): return self.parent.is3D()
     def is4D(self): return False
-    def getDx(self): return 1.0 / (getattr(self.parent, "_global_max", None) or max(self.sx, self.sy, self.sz))
+    def getDx(self): return 1.0 / max(self.parent.globalGridSize())
     def getType(self): return self._gtype
     def getGridType(self): return self._gtype
     @property

@@ -186,7 +186,7 @@ k_density_inflow(Dim d, const int32_t* __restrict__ flags, float* __restrict__ d
 	if (f < 0.0) f = 0.0;
 	else if (f > 1.0) f = 1.0;
 	const float factor = (float)f;
-	const float target = noise_evaluate(P, tile, (float)i, (float)j, (float)k) * scale * factor;
+	const float target = noise_evaluate(P, tile, (float)i, (float)j, (float)(k + d.zoff)) * scale * factor;   // global plane
 	if (density[idx] < target) density[idx] = target;
 }
 

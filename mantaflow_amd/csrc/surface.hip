@@ -416,7 +416,7 @@ k_interpolate_grid(Dim t, float* __restrict__ target, Dim s, const float* __rest
 	if (idx >= t.n) return;
 	const int i = (int)(idx % t.sx), j = (int)((idx / t.sx) % t.sy), k = (int)(idx / ((int64_t)t.sx * t.sy));
 	const float px = (float)i * sfx + ox, py = (float)j * sfy + oy;
-	float pz = (float)k * sfz + oz;
+	float pz = (float)(k + t.zoff) * sfz + oz;       // global plane of the target cell; the source samplers take global positions
 	if (MAC) {
 		// MACGrid::getInterpolatedHi -> interpolMAC (grid.h:269-275); one component of each evaluation is kept
 		float vx, vy, vz;
@@ -443,7 +443,7 @@ int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int s
 	MF_TRY(check_dim(tsx, tsy, tsz));
 	MF_TRY(check_dim(ssx, ssy, ssz));
 	if (ncomp != 1 && ncomp != 3) return fail("ncomp must be 1 or 3");
-	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz);   // each grid under its own slab window
 	hipLaunchKernelGGL((k_interpolate_grid<false>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, ncomp, sfx, sfy, sfz, ox, oy, oz);
 	MF_LAUNCH_CHECK();
 	return 0;
@@ -452,7 +452,7 @@ int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, i
                             float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream) {
 	MF_TRY(check_dim(tsx, tsy, tsz));
 	MF_TRY(check_dim(ssx, ssy, ssz));
-	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz);   // each grid under its own slab window
 	hipLaunchKernelGGL((k_interpolate_grid<true>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, 3, sfx, sfy, sfz, ox, oy, oz);
 	MF_LAUNCH_CHECK();
 	return 0;

@@ -269,9 +269,9 @@ k_apply_noise_vec3(Dim d, const int32_t* __restrict__ flags, float* __restrict__
 	float w = 1;
 	if (weight) {
 		if (!interp) w = weight[idx];
-		else w = interpol1(wd, weight, (float)i * sf0, (float)j * sf1, (float)k * sf2);
+		else w = interpol1(wd, weight, (float)i * sf0, (float)j * sf1, (float)(k + d.zoff) * sf2);
 	}
-	float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
+	float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)(k + d.zoff) + 0.5f};   // global cell centre (z-slab window)
 #pragma unroll
 	for (int c = 0; c < 3; c++) pos[c] *= scaleSpatial;
 	float d0[3], d1[3], d2[3];
@@ -338,11 +338,12 @@ int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* tar
 	float sf[3] = {1.f, 1.f, 1.f};
 	if (weight) {
 		MF_TRY(check_dim(wsx, wsy, wsz));
-		wd = mkdim(wsx, wsy, wsz);
-		interp = (wsx != sx || wsy != sy || wsz != sz);
-		sf[0] = (float)wsx / sx;   // calcGridSizeFactor, grid.h:391-393
+		wd = mkdim_src(wsx, wsy, wsz);       // a weight grid of another size lives under its own (source) slab window
+		interp = (wd.gsz != d.gsz || wsx != sx || wsy != sy);
+		if (!interp && (wsz != sz || wd.zoff != d.zoff)) return fail("applyNoiseVec3: weight grid of the same resolution must share the target's slab window");
+		sf[0] = (float)wsx / sx;   // calcGridSizeFactor, grid.h:391-393 (whole-domain sizes)
 		sf[1] = (float)wsy / sy;
-		sf[2] = (float)wsz / sz;
+		sf[2] = (float)wd.gsz / d.gsz;
 	}
 	NoiseParams P;
 	for (int c = 0; c < 3; c++) {

@@ -589,8 +589,8 @@ def _size_factor(source, target, scale, offset, size):
     """calcGridSizeFactorMod, waveletturbulence.cpp:27-34 (fp32 Vec3 arithmetic)"""
     f32 = np.float32
     scale, offset = _to_vec3(scale), _to_vec3(offset)
-    s1 = (source.sx, source.sy, source.sz)
-    s2 = [target.sx, target.sy, target.sz]
+    s1 = tuple(source.parent.globalGridSize())      # whole-domain sizes (a z-slab's grids hold a window of them)
+    s2 = list(target.parent.globalGridSize())
     if size is not None:
         size = tuple(int(v) for v in (size if not isinstance(size, vec3) else (size.x, size.y, size.z)))
         for c in range(3):
@@ -606,7 +606,7 @@ def _interpolate(target, source, scale, offset, size, orderSpace, ncomp):
         raise RuntimeError("interpolateGrid: orderSpace=2 (cubic) is outside the hot path")
     sf, off = _size_factor(source, target, scale, offset, size)
     s = target.parent
-    s.lib.call("mf_interpolate_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz, source.ptr,
+    s.lib.call2(source.parent, "mf_interpolate_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz, source.ptr,
                ncomp, sf[0], sf[1], sf[2], off[0], off[1], off[2], s.stream)
 
 
@@ -629,7 +629,7 @@ def interpolateMACGrid(target, source, scale=vec3(1.), offset=vec3(0.), size=Non
         raise RuntimeError("interpolateMACGrid: orderSpace=2 (cubic) is outside the hot path")
     sf, off = _size_factor(source, target, scale, offset, size)
     s = target.parent
-    s.lib.call("mf_interpolate_mac_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz,
+    s.lib.call2(source.parent, "mf_interpolate_mac_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz,
                source.ptr, sf[0], sf[1], sf[2], off[0], off[1], off[2], s.stream)
 
 
@@ -673,8 +673,8 @@ def applyNoiseVec3(flags, target, noise, scale=1.0, scaleSpatial=1.0, weight=Non
     weight = _opt(weight, Grid, "Grid<Real>")
     s = flags.parent
     w = (None, 0, 0, 0) if weight is None else (weight.ptr, weight.sx, weight.sy, weight.sz)
-    s.lib.call("mf_apply_noise_vec3", flags.sx, flags.sy, flags.sz, flags.ptr, target.ptr, _ptr(noise._tile), noise._params(),
-               float(scale), float(scaleSpatial), w[0], w[1], w[2], w[3], s.stream)
+    s.lib.call2(s if weight is None else weight.parent, "mf_apply_noise_vec3", flags.sx, flags.sy, flags.sz, flags.ptr, target.ptr,
+                _ptr(noise._tile), noise._params(), float(scale), float(scaleSpatial), w[0], w[1], w[2], w[3], s.stream)
 
 
 @plugin

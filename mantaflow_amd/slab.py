@@ -104,13 +104,16 @@ class Comm(object):
 
 
 class SlabDomain(object):
-    def __init__(self, gsize, ghost, comm=None):
+    def __init__(self, gsize, ghost, comm=None, zrange=None):
+        """zrange = (z0, z1): this rank's owned planes, when they are not the even split (the fine solver of a two-resolution
+        scene owns upres x the coarse solver's planes: `refine`)"""
         self.comm = comm or Comm()
-        self.NX, self.NY, self.NZ = gsize
+        self.NX, self.NY, self.NZ = (int(v) for v in gsize)
         P, r = self.comm.world, self.comm.rank
-        base, rem = divmod(self.NZ, P)
-        self.z0 = r * base + min(r, rem)
-        self.z1 = self.z0 + base + (1 if r < rem else 0)
+        if zrange is None:
+            self.z0, self.z1 = slab_ranges(self.NZ, P)[r]
+        else:
+            self.z0, self.z1 = int(zrange[0]), int(zrange[1])
         self.G = int(ghost)
         if P > 1 and (self.z1 - self.z0) < self.G:
             raise RuntimeError("slab of %d planes is thinner than the ghost width %d" % (self.z1 - self.z0, self.G))
@@ -122,7 +125,7 @@ class SlabDomain(object):
         self.LZ = self.hi - self.lo
         self.XY = self.NX * self.NY
         self.solver = core.Solver(gridSize=core.vec3(self.NX, self.NY, self.LZ), dim=3)
-        self.solver._global_max = max(self.NX, self.NY, self.NZ)       # getDx() of the undivided domain (gravity / buoyancy scaling)
+        self.solver._global_size = (self.NX, self.NY, self.NZ)         # getDx() / noise scaling / resampling factors of the undivided domain
         # positions handed to the interpolators are global coordinates -> bit-identical to the undivided domain.  The window
         # belongs to THIS solver (core.SolverLib sets it per call): other solvers of the process keep their own
         self.solver._slab_window = (self.lo, self.NZ)
@@ -175,6 +178,13 @@ class SlabDomain(object):
         return float(np.max(g[:, 0]))
 
 
+def refine(dom, upres, ghost=None):
+    """the slab of an `upres` times finer solver on the same z-range (waveletTurbulence.py's `xl` solver next to `sm`): fine
+    plane K lies in coarse plane K // upres, so every rank owns the fine planes of its coarse planes"""
+    u = int(upres)
+    return SlabDomain((dom.NX * u, dom.NY * u, dom.NZ * u), dom.G if ghost is None else ghost, comm=dom.comm, zrange=(dom.z0 * u, dom.z1 * u))
+
+
 def required_ghost(maxvz_dt):
     """G = 2R, R = ceil(max|v_z| dt) + 1 (reach of one trilinear gather after a trace of that length)"""
     return 2 * (int(math.ceil(maxvz_dt)) + 1)
@@ -183,14 +193,39 @@ def required_ghost(maxvz_dt):
 # =========================================================================================================
 # distributed plugins (names mirror the single-device ones)
 # =========================================================================================================
+def has_outflow(dom, flags):
+    """does the DOMAIN hold an outflow cell (setOpenBound)?  Looked at once per flag grid: outflow cells are scene set-up."""
+    key = (flags.data.data_ptr(),)
+    if getattr(flags, "_slab_outflow_key", None) != key:
+        dom.solver.sync()
+        mine = float(bool((flags.data & core.TypeOutflow).any().item()))
+        flags._slab_outflow = bool(np.max(dom.comm.gather_scalars([mine], dom.solver.device)) > 0)
+        flags._slab_outflow_key = key
+    return flags._slab_outflow
+
+
 def advectSemiLagrange(dom, flags, vel, grid, order=1, strength=1.0, clampMode=2):
-    """advection.cpp:293-322 / 407-437 on a slab; ghosts of `vel` and `grid` must be current (dom.exchange)."""
+    """advection.cpp:293-322 / 407-437 on a slab; ghosts of `vel` and `grid` must be current (dom.exchange).  MAC grids with
+    outflow cells in the domain: applyOutflowBC (advection.cpp:347-392) reads the ADVECTED velocity up to two cells around an
+    outflow cell, so it runs after the advected field's ghosts have been fetched (two planes), not inside the local advection."""
     from . import plugins
     s = dom.solver
     m = dom.max_abs_owned(vel, comp=2) * s.getDt()
     if dom.comm.world > 1 and required_ghost(m) > dom.G:
         raise RuntimeError("slab advection: max|v_z| dt = %.2f needs %d ghost planes, domain has %d" % (m, required_ghost(m), dom.G))
-    plugins.advectSemiLagrange(flags, vel, grid, order=order, strength=strength, clampMode=clampMode)
+    split_bc = dom.comm.world > 1 and bool(grid.getType() & core.GridBase.TypeMAC) and has_outflow(dom, flags)
+    if not split_bc:
+        plugins.advectSemiLagrange(flags, vel, grid, order=order, strength=strength, clampMode=clampMode)
+        return
+    prev = core.MACGrid(s)
+    prev.copyFrom(grid)                         # velPrev of the convective BC: the field before this advection
+    flags._may_have_outflow = False
+    try:
+        plugins.advectSemiLagrange(flags, vel, grid, order=order, strength=strength, clampMode=clampMode)
+    finally:
+        del flags._may_have_outflow
+    dom.exchange(grid, 2)
+    plugins._apply_outflow_bc(flags, grid, prev, s.getDt())
 
 
 def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, stats=None, phi=None, gfClamp=1e-04):
@@ -652,6 +687,95 @@ def markIsolatedFluidCell(dom, flags, mark):
     from . import plugins
     plugins.markIsolatedFluidCell(flags, mark)
     dom.exchange(flags)
+
+
+# =========================================================================================================
+# the up-res loop of scenes/waveletTurbulence.py on slabs (BASELINE config 5): a coarse solver `sm` and an `upres` times finer
+# solver `xl` on the same z-ranges (SlabDomain + refine).  Everything except the pressure solve is bit-identical to the
+# undivided domain: the operators below only fetch the ghosts their stencil reaches.
+# =========================================================================================================
+def vorticityConfinement(dom, vel, flags, strength=0.):
+    """extforces.cpp:409-428: velCenter (reads vel at +1), curl (+-1), |curl|, its gradient (+-1) -> three planes of reach;
+    run on the full ghost width, the owned planes come out exact"""
+    from . import plugins
+    if dom.comm.world > 1 and dom.G < 4:
+        raise RuntimeError("slab vorticityConfinement needs 4 ghost planes, domain has %d" % dom.G)
+    dom.exchange(vel)
+    plugins.vorticityConfinement(vel, flags, strength)
+
+
+def addBuoyancy(dom, flags, density, vel, gravity):
+    """extforces.cpp:73-88 (reads density at -1): density ghosts must be current"""
+    from . import plugins
+    plugins.addBuoyancy(flags, density, vel, gravity)
+
+
+def gather_window(dom, grid, w0, w1):
+    """planes [w0, w1) of a Real grid of the whole domain as one contiguous device tensor [w1 - w0][NY * NX], fetched from
+    their owners (any number of ranks away; every rank calls this with its own window)"""
+    s, comm = dom.solver, dom.comm
+    out = torch.empty((w1 - w0, dom.XY), dtype=torch.float32, device=s.device)
+    mine = dom.planes(grid, dom.gl, dom.gl + dom.nown)[0]
+    a, b = max(w0, dom.z0), min(w1, dom.z1)
+    if a < b:
+        out[a - w0:b - w0] = mine[a - dom.z0:b - dom.z0]
+    if comm.world > 1:
+        # every rank's window, so that owners know what to send
+        wins = comm.gather_scalars([float(w0), float(w1)], s.device).astype(np.int64)
+        ranges = slab_ranges_of(dom)
+        s.sync()
+        pairs = []
+        for q in range(comm.world):
+            if q == comm.rank:
+                continue
+            qa, qb = max(int(wins[q][0]), dom.z0), min(int(wins[q][1]), dom.z1)        # my planes inside q's window
+            ra, rb = max(w0, ranges[q][0]), min(w1, ranges[q][1])                        # q's planes inside my window
+            snd = mine[qa - dom.z0:qb - dom.z0] if qa < qb else None
+            rcv = out[ra - w0:rb - w0] if ra < rb else None
+            if snd is not None or rcv is not None:
+                pairs.append((snd, rcv, q))
+        comm.sendrecv(pairs)
+    return out
+
+
+def slab_ranges_of(dom):
+    """owned z-range of every rank (the even split, or the refined one)"""
+    g = dom.comm.gather_scalars([float(dom.z0), float(dom.z1)], dom.solver.device).astype(np.int64)
+    return [(int(a), int(b)) for a, b in g]
+
+
+WAVELET_REACH = 20     # planes: upsample reads coarse samples i/2-1 .. i/2+2, each the taps 2k-16 .. 2k+15, + 1 for the smoothing
+
+
+def computeWaveletCoeffs(dom, energy):
+    """computeWaveletCoeffs (waveletturbulence.cpp:197-201 -> WaveletNoiseField::computeCoefficients, noisefield.cpp:233-300) on a
+    slab.  The decomposition filters whole lines along x, y and z; a value depends on the 20 planes either side of it.  Every rank
+    therefore runs the filter on a WINDOW of planes [z0 - 20, z1 + 20) (clipped to the domain, even start: the down-sampling pairs
+    planes 2m, 2m+1) gathered from their owners and keeps its own planes: same taps in the same order as the undivided filter,
+    bit-identical.  The window is not a solver grid (its depth differs), so the library is called on raw tensors."""
+    s = dom.solver
+    if dom.comm.world == 1:
+        from . import plugins
+        return plugins.computeWaveletCoeffs(energy)
+    w0 = max(0, (dom.z0 - WAVELET_REACH) & ~1)
+    w1 = min(dom.NZ, dom.z1 + WAVELET_REACH)
+    win = gather_window(dom, energy, w0, w1)
+    t1, t2 = torch.empty_like(win), torch.empty_like(win)
+    s.lib.call("mf_compute_wavelet_coeffs", dom.NX, dom.NY, w1 - w0, _ptr(win), _ptr(t1), _ptr(t2), s.stream)
+    dom.planes(energy, dom.gl, dom.gl + dom.nown)[0].copy_(win[dom.z0 - w0:dom.z1 - w0])
+
+
+def interpolateGrid(cdom, fdom, target, source):
+    """interpolateGrid (waveletturbulence.cpp:37-56) from the coarse slab to the fine slab: a fine cell samples the coarse
+    grid around its own (global) position, i.e. the coarse planes of its own rank plus at most one ghost plane -- run on every
+    fine plane, exact wherever the coarse ghosts reach (source ghosts must be current)"""
+    from . import plugins
+    plugins.interpolateGrid(target=target, source=source)
+
+
+def interpolateMACGrid(cdom, fdom, target, source):
+    from . import plugins
+    plugins.interpolateMACGrid(target=target, source=source)
 
 
 # =========================================================================================================

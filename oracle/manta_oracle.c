@@ -2353,11 +2353,11 @@ int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_
 int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
                         float sfx, float sfy, float sfz, float ox, float oy, float oz, void* st) {
 	(void)st;
-	Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz); /* each grid under its own slab window */
 	for (int k = 0; k < tsz; k++)
 		for (int j = 0; j < tsy; j++)
 			for (int i = 0; i < tsx; i++) {
-				float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)k * sfz + oz;
+				float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)(k + t.zoff) * sfz + oz; /* global plane */
 				if (!s.is3d) pz = 0.f;
 				for (int c = 0; c < ncomp; c++) target[c * t.n + IDX(t, i, j, k)] = interpol1(&s, source + c * s.n, px, py, pz);
 			}
@@ -2367,11 +2367,11 @@ int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int s
 int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
                             float sfx, float sfy, float sfz, float ox, float oy, float oz, void* st) {
 	(void)st;
-	Dim t = mkdim(tsx, tsy, tsz), s = mkdim(ssx, ssy, ssz);
+	Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz); /* each grid under its own slab window */
 	for (int k = 0; k < tsz; k++)
 		for (int j = 0; j < tsy; j++)
 			for (int i = 0; i < tsx; i++) {
-				const float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)k * sfz + oz;
+				const float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)(k + t.zoff) * sfz + oz;
 				const int64_t idx = IDX(t, i, j, k);
 				/* MACGrid::getInterpolatedHi -> interpolMAC (grid.h:269-275), one component of each evaluation is kept */
 				float v[3];
@@ -2573,7 +2573,7 @@ int mf_density_inflow(int sx, int sy, int sz, const int32_t* flags, float* densi
 				if (f < 0.0) f = 0.0;
 				else if (f > 1.0) f = 1.0;
 				const float factor = (float)f;
-				const float target = noise_evaluate(P, tile, (float)i, (float)j, (float)k) * scale * factor;
+				const float target = noise_evaluate(P, tile, (float)i, (float)j, (float)(k + d.zoff)) * scale * factor; /* global plane */
 				if (density[idx] < target) density[idx] = target;
 			}
 	return 0;
@@ -2801,9 +2801,10 @@ int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* tar
                         float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, void* st) {
 	(void)st;
 	Dim d = mkdim(sx, sy, sz);
-	const int interp = weight && (wsx != sx || wsy != sy || wsz != sz);
-	Dim wd = weight ? mkdim(wsx, wsy, wsz) : d;
-	const float sf[3] = {(float)wsx / sx, (float)wsy / sy, (float)wsz / sz};   /* calcGridSizeFactor, grid.h:391-393 */
+	Dim wd = weight ? mkdim_src(wsx, wsy, wsz) : d; /* a weight grid of another size lives under its own (source) slab window */
+	const int interp = weight && (wd.gsz != d.gsz || wsx != sx || wsy != sy);
+	if (weight && !interp && (wsz != sz || wd.zoff != d.zoff)) return fail("applyNoiseVec3: weight grid of the same resolution must share the target's slab window");
+	const float sf[3] = {(float)wsx / sx, (float)wsy / sy, (float)wd.gsz / d.gsz};   /* calcGridSizeFactor, grid.h:391-393 (whole-domain sizes) */
 	for (int k = 0; k < sz; k++)
 		for (int j = 0; j < sy; j++)
 			for (int i = 0; i < sx; i++) {
@@ -2812,9 +2813,9 @@ int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* tar
 				float w = 1;
 				if (weight) {
 					if (!interp) w = weight[idx];
-					else w = interpol1(&wd, weight, (float)i * sf[0], (float)j * sf[1], (float)k * sf[2]);
+					else w = interpol1(&wd, weight, (float)i * sf[0], (float)j * sf[1], (float)(k + d.zoff) * sf[2]);
 				}
-				float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
+				float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)(k + d.zoff) + 0.5f}; /* global cell centre */
 				for (int c = 0; c < 3; c++) pos[c] *= scaleSpatial;
 				float d0[3], d1[3], d2[3];
 				noise_evaluate_vec(P, tile, pos[0], pos[1], pos[2], 0, d0);

@@ -1117,3 +1117,103 @@ def golden_outputs(impl, deterministic_p2g=True):
 def load_golden():
     import os
     return dict(np.load(os.path.join(util.GOLDEN, "reference_vectors.npz")))
+
+
+# ---- scenes/waveletTurbulence.py, 3-D, shared by the plugin path and the z-slab path (tests/slab_worker.py) -----------------
+WLT_UPRES, WLT_STRENGTH, WLT_DT = 2, 0.4, 1.5
+
+
+def wavelet_inputs(gs):
+    """global set-up arrays of the wavelet-turbulence case: coarse / fine flags with the open +y boundary of the scene
+    (initDomain + fillGrid + setOpenBound on plain whole-domain solvers), a smooth synthetic velocity and a random fine density for
+    the bit-exact check of the up-res pipeline"""
+    from mantaflow_amd import core, plugins
+    out = {}
+    for name, f in (("flags", 1), ("xl_flags", WLT_UPRES)):
+        s = _mk_solver(tuple(v * f for v in gs), WLT_DT)
+        fl = core.FlagGrid(s)
+        fl.initDomain(0)
+        fl.fillGrid()
+        if f == 1:
+            plugins.setOpenBound(fl, 0, "Y", 16 | 4)
+        out[name] = grid_to_soa(fl)
+    out["vel_syn"] = util.smooth_vel(*gs, 91, 0.6)
+    out["xl_dens_syn"] = util.rand_real((gs[2] * WLT_UPRES, gs[1] * WLT_UPRES, gs[0] * WLT_UPRES), 92)
+    return out
+
+
+def wavelet_objects(sm, xl, gs):
+    """noise fields and shapes of the scene (waveletTurbulence.py:27-80), parents = the two solvers (plain or slab)"""
+    from mantaflow_amd import core, scene
+    vec3 = core.vec3
+    res = gs[0]
+    g, xg = vec3(*gs), vec3(*[v * WLT_UPRES for v in gs])
+    o = {}
+    n = o["noise"] = scene.NoiseField(parent=sm, fixedSeed=265, loadFromFile=True)
+    n.posScale, n.clamp, n.clampNeg, n.clampPos, n.valScale, n.valOffset, n.timeAnim = vec3(20), True, 0, 2, 1, 0.075, 0.3
+    o["source"] = scene.Cylinder(parent=sm, center=g * vec3(0.3, 0.2, 0.5), radius=res * 0.081, z=g * vec3(0.081, 0, 0))
+    o["sourceVel"] = scene.Cylinder(parent=sm, center=g * vec3(0.3, 0.2, 0.5), radius=res * 0.15, z=g * vec3(0.15, 0, 0))
+    o["xl_source"] = scene.Cylinder(parent=xl, center=xg * vec3(0.3, 0.2, 0.5), radius=xg.x * 0.081, z=xg * vec3(0.081, 0, 0))
+    xn = o["xl_noise"] = scene.NoiseField(parent=xl, fixedSeed=265, loadFromFile=True)
+    xn.posScale, xn.clamp, xn.clampNeg, xn.clampPos, xn.valScale, xn.valOffset = n.posScale, n.clamp, n.clampNeg, n.clampPos, n.valScale, n.valOffset
+    xn.timeAnim = n.timeAnim * WLT_UPRES
+    w1 = o["wlt1"] = scene.NoiseField(parent=xl, loadFromFile=True)
+    w1.posScale, w1.timeAnim = vec3(int(1.0 * gs[0])) * 0.5, 0.1
+    w2 = o["wlt2"] = scene.NoiseField(parent=xl, loadFromFile=True)
+    w2.posScale, w2.timeAnim = w1.posScale * 2.0, 0.1
+    w3 = o["wlt3"] = scene.NoiseField(parent=xl, loadFromFile=True)
+    w3.posScale, w3.timeAnim = w2.posScale * 2.0, 0.1
+    o["velInflow"] = vec3(0.025, 0, 0) * float(res)
+    return o
+
+
+def run_wavelet_pkg(gs, steps, cgacc=1e-6):
+    """the loop of scenes/waveletTurbulence.py:105-146 (3-D) through the plugins on two plain solvers, preceded by one pass of the
+    up-res pipeline on synthetic input (recorded: it involves no pressure solve, so a z-slab run must reproduce it bit for bit)"""
+    from mantaflow_amd import core, plugins, scene
+    inp = wavelet_inputs(gs)
+    sm, xl = _mk_solver(gs, WLT_DT), _mk_solver(tuple(v * WLT_UPRES for v in gs), WLT_DT)
+    o = wavelet_objects(sm, xl, gs)
+    fl, V, D, P, E = core.FlagGrid(sm), core.MACGrid(sm), core.Grid(sm), core.Grid(sm), core.Grid(sm)
+    xfl, xV, xD, xW = core.FlagGrid(xl), core.MACGrid(xl), core.Grid(xl), core.Grid(xl)
+    soa_to_grid(fl, inp["flags"]); soa_to_grid(xfl, inp["xl_flags"])
+
+    def upres_pass():
+        plugins.interpolateGrid(target=xW, source=E)
+        plugins.interpolateMACGrid(source=V, target=xV)
+        plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt1"], scale=WLT_STRENGTH * 1.0, weight=xW)
+        plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt2"], scale=WLT_STRENGTH * 0.6, weight=xW)
+        plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt3"], scale=WLT_STRENGTH * 0.6 * 0.6, weight=xW)
+        for _ in range(WLT_UPRES):
+            plugins.advectSemiLagrange(flags=xfl, vel=xV, grid=xD, order=2)
+
+    rec = {}
+    soa_to_grid(V, inp["vel_syn"]); soa_to_grid(xD, inp["xl_dens_syn"])
+    plugins.setWallBcs(flags=fl, vel=V)
+    plugins.computeEnergy(flags=fl, vel=V, energy=E)
+    plugins.computeWaveletCoeffs(E)
+    upres_pass()
+    rec["energy0"], rec["xl_vel0"], rec["xl_dens0"] = grid_to_soa(E), grid_to_soa(xV), grid_to_soa(xD)
+    V.clear(); xD.clear(); xV.clear(); E.clear()
+    iters = []
+    for t in range(steps):
+        plugins.advectSemiLagrange(flags=fl, vel=V, grid=D, order=2)
+        plugins.advectSemiLagrange(flags=fl, vel=V, grid=V, order=2)
+        scene.densityInflow(flags=fl, density=D, noise=o["noise"], shape=o["source"], scale=1, sigma=0.5)
+        o["sourceVel"].applyToGrid(grid=V, value=o["velInflow"])
+        plugins.setWallBcs(flags=fl, vel=V)
+        plugins.addBuoyancy(density=D, vel=V, gravity=core.vec3(0, -1e-3, 0), flags=fl)
+        plugins.vorticityConfinement(vel=V, flags=fl, strength=0.3)
+        if t == 0:
+            rec["vel_pre0"], rec["dens_pre0"] = grid_to_soa(V), grid_to_soa(D)
+        plugins.solvePressure(flags=fl, vel=V, pressure=P, cgMaxIterFac=2.0, cgAccuracy=cgacc)
+        iters.append(plugins.lastCgStats()["iterations"])
+        plugins.setWallBcs(flags=fl, vel=V)
+        plugins.computeEnergy(flags=fl, vel=V, energy=E)
+        plugins.computeWaveletCoeffs(E)
+        sm.step()
+        upres_pass()
+        scene.densityInflow(flags=xfl, density=xD, noise=o["xl_noise"], shape=o["xl_source"], scale=1, sigma=0.5)
+        xl.step()
+    sm.sync()
+    return dict(dens=grid_to_soa(D), vel=grid_to_soa(V), energy=grid_to_soa(E), xl_dens=grid_to_soa(xD), xl_vel=grid_to_soa(xV), iters=iters, **rec)

@@ -161,6 +161,74 @@ def dam_case(out, res, steps=3):
              phi=dom.gather_owned(phi), iters=np.array(iters), dts=np.array(dts), **rec)
 
 
+def wavelet_case(out, gs, steps=2):
+    """the loop of scenes/waveletTurbulence.py:105-146 (BASELINE config 5) on z-slabs: the coarse solver `sm` and the 2x finer `xl`
+    on the same z-ranges, preceded by one pass of the up-res pipeline on synthetic input (no solve -> bit-exact check)"""
+    import cases
+    from mantaflow_amd import core, plugins, scene, slab
+    U, WS = cases.WLT_UPRES, cases.WLT_STRENGTH
+    inp = cases.wavelet_inputs(gs)                           # plain whole-domain solvers in the same process
+    dom = slab.SlabDomain(gs, slab.required_ghost(2.0))
+    xdom = slab.refine(dom, U)
+    sm, xl = dom.solver, xdom.solver
+    sm.timestep = xl.timestep = cases.WLT_DT
+    o = cases.wavelet_objects(sm, xl, gs)
+    fl, V, D, P, E = core.FlagGrid(sm), core.MACGrid(sm), core.Grid(sm), core.Grid(sm), core.Grid(sm)
+    xfl, xV, xD, xW = core.FlagGrid(xl), core.MACGrid(xl), core.Grid(xl), core.Grid(xl)
+    dom.scatter_global(fl, inp["flags"]); xdom.scatter_global(xfl, inp["xl_flags"])
+
+    def upres_pass():
+        # coarse ghosts (energy, vel) are current: the resampled fields are right on every fine plane, ghosts included
+        slab.interpolateGrid(dom, xdom, target=xW, source=E)
+        slab.interpolateMACGrid(dom, xdom, source=V, target=xV)
+        plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt1"], scale=WS * 1.0, weight=xW)
+        plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt2"], scale=WS * 0.6, weight=xW)
+        plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt3"], scale=WS * 0.6 * 0.6, weight=xW)
+        for _ in range(U):
+            xdom.exchange(xD)
+            slab.advectSemiLagrange(xdom, xfl, xV, xD, order=2)
+
+    def energy_step():
+        dom.exchange(V, 1)
+        plugins.computeEnergy(flags=fl, vel=V, energy=E)
+        slab.computeWaveletCoeffs(dom, E)
+        dom.exchange(E)
+        dom.exchange(V)
+
+    rec = {}
+    dom.scatter_global(V, inp["vel_syn"]); xdom.scatter_global(xD, inp["xl_dens_syn"])
+    slab.setWallBcs(dom, fl, V)
+    energy_step()
+    upres_pass()
+    rec["energy0"], rec["xl_vel0"], rec["xl_dens0"] = dom.gather_owned(E).copy(), xdom.gather_owned(xV).copy(), xdom.gather_owned(xD).copy()
+    V.clear(); xD.clear(); xV.clear(); E.clear()
+    iters = []
+    for t in range(steps):
+        dom.exchange(D); dom.exchange(V)
+        slab.advectSemiLagrange(dom, fl, V, D, order=2)
+        slab.advectSemiLagrange(dom, fl, V, V, order=2)
+        scene.densityInflow(flags=fl, density=D, noise=o["noise"], shape=o["source"], scale=1, sigma=0.5)
+        o["sourceVel"].applyToGrid(grid=V, value=o["velInflow"])
+        slab.setWallBcs(dom, fl, V)
+        dom.exchange(D, 1)
+        slab.addBuoyancy(dom, fl, D, V, core.vec3(0, -1e-3, 0))
+        slab.vorticityConfinement(dom, V, fl, strength=0.3)
+        if t == 0:
+            rec["vel_pre0"], rec["dens_pre0"] = dom.gather_owned(V).copy(), dom.gather_owned(D).copy()
+        dom.exchange(V, 1)
+        st = {}
+        slab.solvePressure(dom, V, P, fl, cgAccuracy=1e-6, cgMaxIterFac=2.0, stats=st)
+        iters.append(st["iterations"])
+        slab.setWallBcs(dom, fl, V)
+        energy_step()
+        sm.step()
+        upres_pass()
+        scene.densityInflow(flags=xfl, density=xD, noise=o["xl_noise"], shape=o["xl_source"], scale=1, sigma=0.5)
+        xl.step()
+    np.savez(out + ".%d.npz" % dom.comm.rank, dens=dom.gather_owned(D), vel=dom.gather_owned(V), energy=dom.gather_owned(E),
+             xl_dens=xdom.gather_owned(xD), xl_vel=xdom.gather_owned(xV), iters=np.array(iters), **rec)
+
+
 def main():
     out, backend = sys.argv[1], sys.argv[2]
     dims = tuple(int(v) for v in sys.argv[3].split("x"))
@@ -172,8 +240,10 @@ def main():
     else:
         torch.cuda.set_device(0)
         _lib.get()
-    if len(sys.argv) > 4 and sys.argv[4] in ("flip", "liquid", "dam"):
-        if sys.argv[4] == "dam":
+    if len(sys.argv) > 4 and sys.argv[4] in ("flip", "liquid", "dam", "wavelet"):
+        if sys.argv[4] == "wavelet":
+            wavelet_case(out, dims)
+        elif sys.argv[4] == "dam":
             dam_case(out, dims[0])        # "dims" carries the resolution of the dam case: RESx0x0
         else:
             (flip_case if sys.argv[4] == "flip" else liquid_case)(out, dims)

@@ -5,7 +5,8 @@ import pytest
 
 import util
 from test_slab_gloo import (check_against_single, check_dam_against_single, check_flip_against_single, check_liquid_against_single,
-                            run_dam_world, run_flip_world, run_liquid_world, run_world)
+                            check_wavelet_against_single, run_dam_world, run_flip_world, run_liquid_world, run_wavelet_world, run_world,
+                            _WLT_AXIS)
 
 pytestmark = pytest.mark.gpu
 
@@ -62,3 +63,21 @@ def test_dam_break_loop_two_ranks_on_hip(tmp_path):
     assert single["iters"] == ora["iters"] and single["dts"] == ora["dts"]
     for k in ("pos", "pvel", "vel", "pres"):
         assert util.rel_err(single[k], ora[k]) <= 1e-5, k
+
+
+def test_wavelet_turbulence_loop_two_ranks_on_hip(tmp_path):
+    """BASELINE config 5 on slabs: the up-res loop of waveletTurbulence.py (coarse + 2x fine solver on the same z-ranges) through
+    the HIP library, 2 ranks on the one GPU vs 1 rank (bit-exact before the first solve), and the single-rank HIP run against the
+    oracle's (every field bit-exact up to the solve; identical CG iteration counts, fields within 1e-5 after)"""
+    gs = (24, 32, 32)
+    single = run_wavelet_world(tmp_path, 1, "hip", gs=gs)
+    multi = run_wavelet_world(tmp_path, 2, "hip", gs=gs)
+    check_wavelet_against_single(single, multi)
+    ora = run_wavelet_world(tmp_path, 1, "oracle", gs=gs)
+    assert single["iters"] == ora["iters"]
+    for k in ("vel_pre0", "dens_pre0", "energy0", "xl_vel0", "xl_dens0"):
+        util.assert_bitexact(single[k], ora[k], k + " hip vs oracle")
+    for k in ("dens", "vel", "energy", "xl_dens", "xl_vel"):
+        d = np.abs(single[k] - ora[k])
+        scale = max(np.abs(ora[k]).max(), 1e-3)
+        assert (d > 1e-5 * scale).mean() < 1e-3, k

@@ -276,3 +276,49 @@ def test_dam_single_rank_slab_equals_plugin_path(dam_single, oracle_backend):
 @pytest.mark.parametrize("world", [2, 3])
 def test_dam_slab_world(tmp_path, dam_single, world):
     check_dam_against_single(dam_single, run_dam_world(tmp_path, world))
+
+
+# ---- the up-res loop of waveletTurbulence.py on slabs (BASELINE config 5: two solvers on the same z-ranges) -----------------
+WLT_GS = (16, 24, 24)
+_WLT_AXIS = dict(dens=0, vel=1, energy=0, xl_dens=0, xl_vel=1, energy0=0, xl_vel0=1, xl_dens0=0, vel_pre0=1, dens_pre0=0)
+
+
+def run_wavelet_world(tmp_path, world, backend="oracle", gs=WLT_GS):
+    parts = _run_case(tmp_path, world, backend, "%dx%dx%d" % gs, "wavelet")
+    out = {k: np.concatenate([p[k] for p in parts], axis=a) for k, a in _WLT_AXIS.items()}
+    out["iters"] = [list(p["iters"]) for p in parts]
+    return out
+
+
+def check_wavelet_against_single(one, m):
+    assert all(it == m["iters"][0] for it in m["iters"])
+    # no cross-rank sum before the first solve: advection with the split outflow BC, inflow noise, buoyancy, vorticity confinement,
+    # and -- on synthetic input -- energy, the wavelet decomposition over a gathered z-window, resampling between the two slabs
+    # (each under its own window), three noise octaves and the fine MacCormack advection are bit-identical to the undivided run
+    for k in ("vel_pre0", "dens_pre0", "energy0", "xl_vel0", "xl_dens0"):
+        util.assert_bitexact(m[k], one[k], k)
+    # after two steps (block-Jacobi-preconditioned solves to 1e-6): converged-solution level; MacCormack's clamp is a selection,
+    # so a few cells may pick the other candidate
+    for k in ("dens", "vel", "energy", "xl_dens", "xl_vel"):
+        d = np.abs(m[k] - one[k])
+        scale = max(np.abs(one[k]).max(), 1e-3)
+        assert (d > 1e-4 * scale).mean() < 1e-3 and d.max() < 5e-2 * scale, (k, d.max(), scale)
+
+
+@pytest.fixture(scope="module")
+def wavelet_single(tmp_path_factory):
+    return run_wavelet_world(tmp_path_factory.mktemp("wlt1"), 1)
+
+
+def test_wavelet_single_rank_slab_equals_plugin_path(wavelet_single, oracle_backend):
+    """world 1: the loop through the slab operators = the loop through the plugins on two plain solvers, bit for bit"""
+    import cases
+    ref = cases.run_wavelet_pkg(WLT_GS, 2)
+    assert wavelet_single["iters"][0] == ref["iters"]
+    for k in _WLT_AXIS:
+        util.assert_bitexact(wavelet_single[k], ref[k], k)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_wavelet_slab_world(tmp_path, wavelet_single, world):
+    check_wavelet_against_single(wavelet_single, run_wavelet_world(tmp_path, world))
