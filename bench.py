@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 GRID = 256
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 APPLY_MATRIX_BYTES_PER_CELL = 28  # flags 4 + src 4 + A0,Ai,Aj,Ak 16 read; dst 4 written
+MIC_BYTES_PER_CELL = 56           # (flags 4, var1 4, Aprecond 4, Ai, Aj, Ak 12 read; dst 4 written) x 2 sweeps
+CG_ITERATION_BYTES_PER_CELL = 144  # 96 (unpreconditioned, as structured by the reference) - 8 (copy) + 56 (MIC apply)
+STEP_FIXED_BYTES_PER_CELL = 92 + 188 + 20 + 24 + 28 + 20 + 20 + 28 + 32   # once per step, SURVEY 8d table (see roofline_step below)
 
 
 def synthetic_velocity(sx, sy, sz, seed=7, vmax=2.0):
@@ -201,16 +204,19 @@ def main():
         us_pk = ctypes.c_double()
         lib.call("mf_time_apply_matrix_packed", n, n, n, flags.ptr, dst.ptr, src.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, 200, ctypes.byref(us_pk), s.stream)
         del apk
-        traffic = None
+        # HBM traffic needs the PMC counters (rocprofv3 --pmc, separate passes): not measurable from inside this process, so
+        # the number is read from the committed counter summary and labelled with its source
+        traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "apply_matrix_traffic.json")
         if os.path.exists(tp) and n == GRID:
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/apply_matrix_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
             except Exception:
                 traffic = None
         result["roofline"] = {"kernel": "k_apply_matrix_v5 (ApplyMatrix, conjugategrad.h:118-133)", "bound": "hbm",
                               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                              "traffic": traffic, "avg_launch_us": round(us.value, 2),
+                              "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(us.value, 2),
                               "algorithmic_bytes_per_launch": APPLY_MATRIX_BYTES_PER_CELL * n ** 3,
                               "pcg_variant": {"kernel": "k_apply_matrix_v5<PACKED> (flags + Ai + Aj + Ak as one byte per cell, exact for a 0 / -1 matrix)",
                                               "avg_launch_us": round(us_pk.value, 2), "bytes_per_cell": 13,
@@ -229,19 +235,30 @@ def main():
         e1.record(torch.cuda.current_stream())
         torch.cuda.synchronize()
         mic_us = e0.elapsed_time(e1) * 1e3 / 50
-        mic_bytes = 60 * n ** 3
-        mic_traffic = None
+        mic_bytes = MIC_BYTES_PER_CELL * n ** 3
+        mic_traffic, mic_traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "mic_traffic.json")
         if os.path.exists(tp) and n == GRID:
             try:
                 mic_traffic = json.load(open(tp)).get("hbm_bytes_per_apply")     # PMC counters, see profiles/README.md
+                mic_traffic_src = "profiles/mic_traffic.json (rocprofv3 --pmc passes, not measured in this run)"
             except Exception:
                 mic_traffic = None
         result["roofline_mic"] = {"kernel": "k_mic_rows<1> + k_mic_rows<2> (ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:135-159)",
                                   "bound": "dependency chain (serial sweep in the reference), hbm if it were free",
                                   "achieved": round(mic_bytes / (mic_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(mic_bytes / (mic_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_apply_us": round(mic_us, 1),
-                                  "algorithmic_bytes_per_apply": mic_bytes, "traffic": mic_traffic}
+                                  "algorithmic_bytes_per_apply": mic_bytes, "traffic": mic_traffic, "traffic_source": mic_traffic_src}
+        # ---- the whole step against the HBM roofline: SURVEY 8d's algorithmic bytes of every operator of the step / ms_per_step
+        its = float(np.mean(result["cg_iterations"])) if result["cg_iterations"] else 0.0
+        step_bytes = (STEP_FIXED_BYTES_PER_CELL + its * CG_ITERATION_BYTES_PER_CELL) * n ** 3
+        step_gbs = step_bytes / (el / max(a.steps, 1)) / 1e9
+        result["roofline_step"] = {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(step_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": int(step_bytes),
+                                   "bytes_per_cell": {"fixed (MacCormack Real 92 + MAC 188 + outflow sweeps 20 + velocity restore 24 + setWallBcs 28 "
+                                                      "+ MakeRhs 20 + MakeLaplaceMatrix 20 + MIC init 28 + correctVelocity 32)": STEP_FIXED_BYTES_PER_CELL,
+                                                      "per CG iteration (ApplyMatrix 28 + 2 dot 16 + 2 axpy 24 + max-norm 8 + search update 12 + MIC apply 56)": CG_ITERATION_BYTES_PER_CELL,
+                                                      "mean CG iterations": round(its, 1)}}
         del A0, Ai, Aj, Ak, src, dst, ap
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline((n, n, max(16, n // 4)), v_np, d_np, None, dt)
@@ -267,6 +284,8 @@ def main():
             line["roofline"] = result["roofline"]
         if "roofline_mic" in result:
             line["roofline_mic"] = result["roofline_mic"]
+        if "roofline_step" in result:
+            line["roofline_step"] = result["roofline_step"]
         if "cpu_baseline" in result:
             line["cpu_baseline"] = result["cpu_baseline"]
         if "notes" in result:

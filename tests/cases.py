@@ -159,28 +159,59 @@ def pressure_inputs(dims, seed, liquid=False):
     return flags, vel, phi
 
 
-def run_solve_pressure_pkg(dims, flags, vel, phi, **kw):
+def pressure_optional_terms(dims, seed, which):
+    """numpy inputs for the optional terms of MakeRhs / MakeLaplaceMatrix (pressure.cpp:32-84, conjugategrad.h:154-187):
+    perCellCorr (Real), fractions (MAC, fill fractions in [0.1, 1] with some faces closed), obvel (MAC), curv (Real)"""
+    sx, sy, sz = dims
+    rng = np.random.default_rng(seed)
+    out = {}
+    if "perCellCorr" in which:
+        out["perCellCorr"] = rng.uniform(-0.2, 0.2, (sz, sy, sx)).astype(np.float32)
+    if "fractions" in which:
+        fr = rng.uniform(0.1, 1.0, (3, sz, sy, sx)).astype(np.float32)
+        fr[rng.uniform(size=fr.shape) < 0.3] = 1.0
+        fr[rng.uniform(size=fr.shape) < 0.05] = 0.0
+        out["fractions"] = fr
+    if "obvel" in which:
+        out["obvel"] = util.rand_vel(sx, sy, sz, seed + 11, 0.3)
+    if "curv" in which:
+        out["curv"] = rng.uniform(-0.5, 0.5, (sz, sy, sx)).astype(np.float32)
+    return out
+
+
+def run_solve_pressure_pkg(dims, flags, vel, phi, extra=None, **kw):
     from mantaflow_amd import core, plugins
     s = _mk_solver(dims)
     fl, v, p = core.FlagGrid(s), core.MACGrid(s), core.Grid(s)
     soa_to_grid(fl, flags); soa_to_grid(v, vel)
     ph = soa_to_grid(core.LevelsetGrid(s), phi) if phi is not None else None
     rr = core.Grid(s)
+    keep = []
+    for name, arr in (extra or {}).items():
+        g = soa_to_grid((core.MACGrid if arr.ndim == 4 else core.Grid)(s), arr)
+        keep.append(g)
+        kw[name] = g
     plugins.solvePressure(v, p, fl, phi=ph, retRhs=rr, **kw)
     s.sync()
     return dict(vel=grid_to_soa(v), pressure=grid_to_soa(p), rhs=grid_to_soa(rr), stats=plugins.lastCgStats())
 
 
 def run_solve_pressure_ref(dims, flags, vel, phi, cgAccuracy=1e-3, cgMaxIterFac=1.5, enforceCompatibility=False,
-                           useL2Norm=False, zeroPressureFixing=False, gfClamp=1e-4):
+                           useL2Norm=False, zeroPressureFixing=False, gfClamp=1e-4, extra=None, surfTens=0.0):
     sx, sy, sz = dims
     v = vel.copy()
     p = np.zeros((sz, sy, sx), np.float32)
     rr = np.zeros((sz, sy, sx), np.float32)
-    refcall("ref_solve_pressure", sx, sy, sz, v, p, flags, ctypes.c_float(cgAccuracy), phi, None, None, None,
-            ctypes.c_float(gfClamp), ctypes.c_float(cgMaxIterFac), 1, 1, int(enforceCompatibility), int(useL2Norm),
-            int(zeroPressureFixing), None, ctypes.c_float(0.0), rr)
+    ex = extra or {}
+    refcall("ref_solve_pressure", sx, sy, sz, v, p, flags, ctypes.c_float(cgAccuracy), phi, ex.get("perCellCorr"), ex.get("fractions"),
+            ex.get("obvel"), ctypes.c_float(gfClamp), ctypes.c_float(cgMaxIterFac), 1, 1, int(enforceCompatibility), int(useL2Norm),
+            int(zeroPressureFixing), ex.get("curv"), ctypes.c_float(surfTens), rr)
     return dict(vel=v, pressure=p, rhs=rr)
+
+
+# (terms given, liquid case?) -- every optional input of solvePressure (pressure.cpp:482-497) at least once, alone and combined
+PRESSURE_OPTIONAL_CASES = [(("perCellCorr",), False), (("fractions",), False), (("fractions", "obvel"), False),
+                           (("curv",), True), (("perCellCorr", "fractions", "obvel", "curv"), True)]
 
 
 def advect_inputs(dims, seed, vmax=2.5, outflow=False):

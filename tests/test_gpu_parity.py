@@ -261,6 +261,27 @@ def test_solve_pressure_vs_reference(hip_backend, dims, liquid):
     _close(a["vel"], b["vel"], "vel")
 
 
+@pytest.mark.parametrize("terms,liquid", cases.PRESSURE_OPTIONAL_CASES)
+@pytest.mark.parametrize("dims", [(24, 20, 16), cases.SIZE_2D])
+def test_solve_pressure_optional_terms(hip_backend, dims, terms, liquid):
+    """solvePressure with perCellCorr, fractions, obvel, curv + surfTens on the GPU against the compiled reference (the oracle
+    where the reference .so did not travel): rhs bit-exact, identical CG path, fields within 1e-5"""
+    flags, vel, phi = cases.pressure_inputs(dims, 12, liquid)
+    extra = cases.pressure_optional_terms(dims, 13, terms)
+    kw = dict(surfTens=0.7) if "curv" in terms else {}
+    a = cases.run_solve_pressure_pkg(dims, flags, vel, phi, extra=extra, **kw)
+    if util.have_ref():
+        b = cases.run_solve_pressure_ref(dims, flags, vel, phi, extra=extra, **kw)
+    else:
+        from mantaflow_amd import _lib
+        _lib.use_library(util.build_oracle(), "cpu")
+        b = cases.run_solve_pressure_pkg(dims, flags, vel, phi, extra=extra, **kw)
+        _lib.reset()
+    assert_bitexact(a["rhs"], b["rhs"], "rhs")
+    _close(a["pressure"], b["pressure"], "pressure")
+    _close(a["vel"], b["vel"], "vel")
+
+
 @pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 17, 9)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 @pytest.mark.parametrize("order,clampMode", [(1, 2), (2, 1), (2, 2)])

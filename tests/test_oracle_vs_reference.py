@@ -83,6 +83,20 @@ def test_solve_pressure_options(oracle_backend):
         assert_bitexact(a[k], b[k], "solvePressure(options) " + k)
 
 
+@pytest.mark.parametrize("terms,liquid", cases.PRESSURE_OPTIONAL_CASES)
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
+def test_solve_pressure_optional_terms(oracle_backend, dims, terms, liquid):
+    """MakeRhs / MakeLaplaceMatrix with perCellCorr, fractions, obvel, curv + surfTens (pressure.cpp:32-84, 277-299): the oracle
+    equals the compiled reference bit for bit"""
+    flags, vel, phi = cases.pressure_inputs(dims, 12, liquid)
+    extra = cases.pressure_optional_terms(dims, 13, terms)
+    kw = dict(surfTens=0.7) if "curv" in terms else {}
+    a = cases.run_solve_pressure_pkg(dims, flags, vel, phi, extra=extra, **kw)
+    b = cases.run_solve_pressure_ref(dims, flags, vel, phi, extra=extra, **kw)
+    for k in ("rhs", "pressure", "vel"):
+        assert_bitexact(a[k], b[k], "solvePressure(%s) %s" % ("+".join(terms), k))
+
+
 def test_solve_pressure_pcnone_raises(oracle_backend):
     """the reference asserts for PcNone / precondition=False (SURVEY intro item 1)"""
     dims = (10, 10, 10)
