@@ -1248,3 +1248,41 @@ def run_wavelet_pkg(gs, steps, cgacc=1e-6):
         xl.step()
     sm.sync()
     return dict(dens=grid_to_soa(D), vel=grid_to_soa(V), energy=grid_to_soa(E), xl_dens=grid_to_soa(xD), xl_vel=grid_to_soa(xV), iters=iters, **rec)
+
+
+# ---- whole steps at BASELINE's stated sizes (tests/test_gpu_fullsize.py) -----------------------------------------------------
+def run_smoke_step_pkg(dims, dt, flags, vel, dens):
+    """bench.py's step: advect density + velocity (MacCormack), setWallBcs, solvePressure (MIC-CG 1e-3)"""
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims, dt)
+    fl, v, d, p = core.FlagGrid(s), core.MACGrid(s), core.Grid(s), core.Grid(s)
+    soa_to_grid(fl, flags); soa_to_grid(v, vel); soa_to_grid(d, dens)
+    plugins.setWallBcs(fl, v)
+    plugins.advectSemiLagrange(fl, v, d, order=2)
+    plugins.advectSemiLagrange(fl, v, v, order=2)
+    plugins.setWallBcs(fl, v)
+    out = dict(dens=grid_to_soa(d), vel_adv=grid_to_soa(v).copy())
+    plugins.solvePressure(v, p, fl)
+    s.sync()
+    out.update(pressure=grid_to_soa(p), vel=grid_to_soa(v), iters=plugins.lastCgStats()["iterations"])
+    return out
+
+
+def run_flip_step_pkg(dims, dt, flags, vel, pos, pflag, pvel):
+    """S-flip: advectInGrid(RK4), mapPartsToMAC, setWallBcs, solvePressure, flipVelocityUpdate"""
+    from mantaflow_amd import core, plugins
+    s = _mk_solver(dims, dt)
+    fl, v, vo, w, p = core.FlagGrid(s), core.MACGrid(s), core.MACGrid(s), core.VecGrid(s), core.Grid(s)
+    soa_to_grid(fl, flags); soa_to_grid(v, vel)
+    pp = _mk_parts(s, pos, pflag)
+    pv = _pd_vec3(s, pp, pvel)
+    pp.advectInGrid(fl, v, 2, deleteInObstacle=False)
+    P, F = _parts_get(pp)
+    plugins.mapPartsToMAC(fl, v, vo, pp, pv, w)
+    out = dict(pos=P, pflag=F, p2g_vel=grid_to_soa(v).copy(), p2g_w=grid_to_soa(w).copy())
+    plugins.setWallBcs(fl, v)
+    plugins.solvePressure(v, p, fl)
+    plugins.flipVelocityUpdate(fl, v, vo, pp, pv, 0.97)
+    s.sync()
+    out.update(vel=grid_to_soa(v), pvel=_pd_get(pv, pp.np), iters=plugins.lastCgStats()["iterations"])
+    return out
