@@ -58,8 +58,10 @@ int mf_set_slab_window_source(int zoff, int gsz);
 
 /* How the MIC(0) substitution sweeps are parallelised on the GPU (no reference counterpart; every mode gives the same
  * bits as the serial sweep of ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:88-128):
- * "rows" (default for 3D), "tiles", "levels"; NULL or "" = back to the default / MF_MIC_MODE.  Returns 0, or -1 for an
- * unknown name.  The oracle accepts and ignores it. */
+ * "rows" (default for 3D: row-streaming sweeps, one 8 x 8 bundle of x-rows per workgroup), "rows-sb" (2 x 2 bundles per workgroup
+ * with the inner faces through LDS, where the system allows it -- measured slower, kept selectable: DESIGN.md), "tiles", "levels";
+ * NULL or "" = back to the default / MF_MIC_MODE.  Set it before mf_mic_init.  Returns 0, or -1 for an unknown name.  The oracle
+ * accepts and ignores it. */
 int mf_set_mic_mode(const char* name);
 /* Synchronises the stream and reports whether any MIC sweep since the last check gave up waiting for a neighbouring
  * workgroup (a deadlock guard of the single-launch sweeps; never seen in practice).  mf_cg_solve checks by itself; callers

@@ -914,6 +914,484 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MIC apply, "super-bundle" form of the row-streaming sweeps (k_mic_sb): ONE workgroup owns 2 x 2 bundles of 8 x 8 x-rows.
+// What bounds k_mic_rows is the chain of face hand-offs between workgroups (62 at 256^3, each = 15 steps of structural lag +
+// a global store -> poll round trip).  Here four compute waves (one per SIMD) sweep the four sub-bundles of a 16 x 16 block of
+// rows and hand their inner faces to each other through LDS; only the outer faces of the block cross workgroups (30 hand-offs
+// at 256^3).  The helper waves are shared: wave 4+w loads for sub-bundle w (software-pipelined three chunks ahead), one wave
+// writes all four back, one wave polls the (up to) four outer input faces, each 8-lane group at its own pace.
+//   sub-bundle w = sj + 2 sk;  j face in : sj == 0 global (polled), sj == 1 from w-1 through LDS;   out: sj == 1 global, else LDS
+//                              k face in : sk == 0 global,          sk == 1 from w-2;                out: sk == 1 global, else LDS
+// Operands reach the compute waves as ONE 16-byte LDS slot per cell: {value, Aprecond (sign bit set = not a fluid cell),
+// (Ai, Aj) and (Ak, -) as fp16 pairs}.  This needs every coefficient to be exactly +0 or -1 (the packed bytes of k_mic_pack)
+// and Aprecond >= +0 (what mf_mic_init writes); the products (val * A) * p are formed exactly as in the reference:
+// v_fma_mix_f32(val, A as fp16, -0) is the fp32 product val * A without rounding (A is 0 or -1, x + (-0) == x for every x), then
+// one fp32 multiply by |p|.  Global faces use the granule arrays of k_mic_rows (per 8 x 8 bundle), so both kernels share them.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SB_THREADS = 640;
+constexpr int SB_FR = 64;          // slots of a face ring
+constexpr int SB_AHEAD = SB_FR / 8 - 1;   // blocks a face producer may run ahead of its consumer
+constexpr int SB_PW = 3;           // windows (blocks) the poller fetches per round trip
+struct SbShared {
+	float4 ring[4][32 * 64];      // operand / result ring of each sub-bundle, index = ((h + 2) & 31) * 64 + lane
+	// input faces of the four sub-bundles, one ring per face: [ring][face lane][slot], slot = (producer row - 7) & (SB_FR - 1), so that a
+	// consumer block m reads the eight slots 8m .. 8m+7.  Rings 0-3 are the OUTER faces, filled by the poller from the granule arrays
+	// (0 j of w0, 1 j of w2, 2 k of w0, 3 k of w1); rings 4-7 the INNER faces, written by the producing compute wave itself
+	// (4 j w0->w1, 5 j w2->w3, 6 k w0->w2, 7 k w1->w3).  SB_FR slots = 8 blocks of slack between producer and consumer: the hand-off
+	// latency jitters by a few blocks, and a ring that is too short turns that jitter into a stall of the whole chain.
+	float FR[8][8][SB_FR];
+	float dump[64 + 8];
+	int ready[4], done[4], flushed[4], faces[4], ticket, pad[3];
+};
+__device__ __forceinline__ float sb_mulh(float v, float packed, bool hi, float negzero) {
+	float r;   // negzero is uniform: it stays in an SGPR (one constant-bus operand)
+	if (hi) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(packed), "s"(negzero));
+	else asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(packed), "s"(negzero));
+	return r;
+}
+typedef float sbf4 __attribute__((ext_vector_type(4)));
+typedef unsigned sbu4 __attribute__((ext_vector_type(4)));
+struct SbChunk {      // one 8-cell chunk of a row in flight (physical order; no arrays, so that it lives in registers)
+	sbu4 C0, C1;     // coefficient words of k_mic_sbcoef
+	sbf4 P0, P1, V0, V1, D0, D1;
+};
+__device__ __forceinline__ unsigned sb_picku(const sbu4& lo, const sbu4& hi, int e) {
+	return e == 0 ? lo.x : e == 1 ? lo.y : e == 2 ? lo.z : e == 3 ? lo.w : e == 4 ? hi.x : e == 5 ? hi.y : e == 6 ? hi.z : hi.w;
+}
+__device__ __forceinline__ float sb_pick(const sbf4& lo, const sbf4& hi, int e) {
+	return e == 0 ? lo.x : e == 1 ? lo.y : e == 2 ? lo.z : e == 3 ? lo.w : e == 4 ? hi.x : e == 5 ? hi.y : e == 6 ? hi.z : hi.w;
+}
+// loader wave of one sub-bundle: three chunks in flight (register sets rotate statically), slot assembly, commit to the ring.
+// A function of its own, NOT inlined: the kernel's other roles would otherwise share one register allocation with it, and the
+// three chunk sets in flight end up spilled to scratch right behind their loads (which serialises the loads).
+template <int MODE>
+__device__ __attribute__((noinline)) int sb_loader(float4* ring_, int* ready_, int* flushed_, int nchunks, bool row_in, int64_t rowbase,
+                                                   const unsigned* __restrict__ coef, const float* __restrict__ Ap, const float* dst,
+                                                   const float* __restrict__ var1, long long* tr) {
+	constexpr bool REV = (MODE == 2);
+	const int lane = threadIdx.x & 63, b = lane & 7, c = lane >> 3, skew = b + c;
+	// LDS address space for the ring and the counters: ds_ instructions, and acquire / release that wait for LDS only (through a
+	// generic pointer every poll of a counter would wait for the global loads in flight as well)
+	typedef __attribute__((address_space(3))) sbf4* lf4;
+	typedef __attribute__((address_space(3))) int* li;
+	lf4 ring = (lf4)ring_;
+	li ready = (li)ready_, flushed = (li)flushed_;
+	int spins = 0;
+	auto issue = [&](SbChunk& r, int m) {
+		const int x0 = (REV ? nchunks - 1 - m : m) * 8;
+		const int64_t i0 = row_in ? rowbase + x0 : 0;      // sx % 8 == 0: a chunk is inside the row, or the row is outside the grid
+		typedef const __attribute__((address_space(1))) sbu4* gu4;      // global address space: global_load, counted by vmcnt alone
+		typedef const __attribute__((address_space(1))) sbf4* gf4;
+		r.C0 = *(gu4)(coef + i0);
+		r.C1 = *(gu4)(coef + i0 + 4);
+		r.P0 = *(gf4)(Ap + i0);
+		r.P1 = *(gf4)(Ap + i0 + 4);
+		r.D0 = *(gf4)(dst + i0);
+		r.D1 = *(gf4)(dst + i0 + 4);
+		if (MODE == 1) {
+			r.V0 = *(gf4)(var1 + i0);
+			r.V1 = *(gf4)(var1 + i0 + 4);
+		}
+	};
+	// The slot is assembled with five VALU instructions per cell (the coefficient word was laid out for it by k_mic_sbcoef):
+	// this wave shares its SIMD with a compute wave, every instruction here is taken from the sweep.
+	auto commit = [&](const SbChunk& r, int m) {
+		const int p0 = 8 * m + skew + 2;
+#pragma unroll
+		for (int a = 0; a < 8; a++) {
+			const int e = REV ? 7 - a : a;              // physical cell of the logical position a
+			const unsigned q = row_in ? sb_picku(r.C0, r.C1, e) : 0x80000000u;
+			// bytes of q: [Ai ? 0xBC : 0, Aj ? 0xBC : 0, Ak ? 0xBC : 0, not fluid ? 0x80 : 0]; fp16 -1.0 = 0xBC00
+			const unsigned zi = __builtin_amdgcn_perm(0u, q, 0x010c000cu);   // bytes {0, q.b0, 0, q.b1}
+			const unsigned zk = __builtin_amdgcn_perm(0u, q, 0x0c0c020cu);   // bytes {0, q.b2, 0, 0}
+			const float p = row_in ? sb_pick(r.P0, r.P1, e) : 0.f;
+			const float pm = __uint_as_float((q & 0x80000000u) | __float_as_uint(p));   // Aprecond >= +0 (mf_mic_init); sign bit = not fluid
+			float v = (MODE == 1 && (int)q >= 0) ? sb_pick(r.V0, r.V1, e) : sb_pick(r.D0, r.D1, e);
+			if (!row_in) v = 0.f;
+			sbf4 slot;
+			slot.x = v;
+			slot.y = pm;
+			slot.z = __uint_as_float(zi);
+			slot.w = __uint_as_float(zk);
+			ring[((p0 + a) & 31) * 64 + lane] = slot;
+		}
+	};
+	SbChunk R0, R1, R2;
+	if (0 < nchunks) issue(R0, 0);
+	if (1 < nchunks) issue(R1, 1);
+	if (2 < nchunks) issue(R2, 2);
+#pragma unroll 1
+	for (int n = 0; n < nchunks; n += 3) {
+#define SB_LOAD_STEP(R, q)                                                                                     \
+	if (n + (q) < nchunks) {                                                                               \
+		if (n + (q) >= 4) {                                                                                \
+			while (__hip_atomic_load(flushed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + (q) - 3) { \
+				if (++spins > FLOW_SPIN_LIMIT) break;                                                      \
+				__builtin_amdgcn_s_sleep(2);                                                               \
+			}                                                                                              \
+		}                                                                                                  \
+		commit(R, n + (q));                                                                                \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                    \
+		__hip_atomic_store(ready, n + (q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);            \
+		if (tr && lane == 0 && n + (q) < 64) tr[n + (q)] = wall_clock64();                                 \
+		if (n + (q) + 3 < nchunks) issue(R, n + (q) + 3);                                                  \
+	}
+		SB_LOAD_STEP(R0, 0)
+		SB_LOAD_STEP(R1, 1)
+		SB_LOAD_STEP(R2, 2)
+#undef SB_LOAD_STEP
+	}
+	return spins > FLOW_SPIN_LIMIT ? FLOW_SPIN_LIMIT + 1 : 0;
+}
+template <int MODE>
+__global__ void __launch_bounds__(SB_THREADS)
+k_mic_sb(Dim d, int nbj, int nbk, int nsj, int nsb, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* tick,
+         unsigned long long* xj, unsigned long long* xk, unsigned gen, float* __restrict__ dst, const float* __restrict__ var1,
+         const float* __restrict__ Ap, const CgScalars* __restrict__ sc, const unsigned* __restrict__ coef, float negzero,
+         long long* trace, int trace_ticket, int dbg) {
+	static_assert(MODE == 1 || MODE == 2, "apply sweeps only");
+	constexpr bool REV = (MODE == 2);
+	if (sc && sc->done) return;
+	extern __shared__ __attribute__((aligned(16))) unsigned char sb_raw[];
+	SbShared& S = *reinterpret_cast<SbShared*>(sb_raw);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
+	const int skew = b + c;
+	// compute waves run above the poller / write-back waves; the loaders sit on the critical ring cycle (a chunk is committed one block
+	// before it is needed) and run at the top
+	if (wave < 4) __builtin_amdgcn_s_setprio(2);
+	else if (wave < 8) { if (dbg & 8) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+	else __builtin_amdgcn_s_setprio(1);
+	const int X8 = nchunks * 8;
+	const int nblocks = nchunks + 2;
+	const int64_t XP = X8 + 2 * ROWS_PAD;
+	int spins = 0;
+	// nap == 1: a compute wave.  It shares its SIMD with the very helper waves it waits for, so it must not spin at high priority:
+	// it steps down while it waits (otherwise the wait starves the loader that would end it)
+	auto wait_ge = [&](int* flag, int need, int nap) {
+		if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return;
+		if (nap == 1) __builtin_amdgcn_s_setprio(0);
+		while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+			if (++spins > FLOW_SPIN_LIMIT) break;
+			if (nap == 1) __builtin_amdgcn_s_sleep(2);
+			else __builtin_amdgcn_s_sleep(4);
+		}
+		if (nap == 1) __builtin_amdgcn_s_setprio(2);
+	};
+
+	for (;;) {
+		if (threadIdx.x == 0) {
+			const int t = atomicAdd(tick, 1);
+			S.ticket = t < nsb ? t : nsb;
+			for (int q = 0; q < 4; q++) S.ready[q] = S.done[q] = S.flushed[q] = S.faces[q] = 0;
+		}
+		__syncthreads();
+		const int t = S.ticket;
+		if (t >= nsb) break;
+		if ((dbg & 128) && t > 0) break;
+		const int pk = order[t];
+		const int SJ = pk & 0xfff, SK = pk >> 12;      // logical (sweep-direction) super-bundle coordinates
+		// ---- geometry of sub-bundle `w` (uniform) ----
+		auto sub_tjl = [&](int w) { return 2 * SJ + (w & 1); };
+		auto sub_tkl = [&](int w) { return 2 * SK + (w >> 1); };
+		auto sub_alive = [&](int w) { return sub_tjl(w) < nbj && sub_tkl(w) < nbk && !((dbg & 16) && w > 0) && !((dbg & 32) && w > 1); };
+
+		if (wave < 4) {
+			// ===================================== compute wave of sub-bundle w =====================================
+			// the role (which faces are inner / outer) is a compile-time property of w: four copies of the step loop
+			auto compute = [&](auto wtag) {
+				constexpr int w = decltype(wtag)::value, sj = w & 1, sk = w >> 1;
+				constexpr bool JIN_INT = (sj == 1), KIN_INT = (sk == 1);      // else: outer face (polled) or none
+				constexpr bool JOUT_GLOB = (sj == 1), KOUT_GLOB = (sk == 1);  // else: inner face through LDS
+				constexpr bool BOTH_GLOB = JOUT_GLOB && KOUT_GLOB;
+				constexpr int gJ = sk ? 1 : 0, gK = sj ? 3 : 2;                     // outer input rings / poller groups
+				constexpr int rJ_in = JIN_INT ? 4 + (sk ? 1 : 0) : gJ, rK_in = KIN_INT ? 6 + sj : gK;
+				constexpr int rJ_out = 4 + (sk ? 1 : 0), rK_out = 6 + sj;
+				const int tjl = sub_tjl(w), tkl = sub_tkl(w);
+				if (!sub_alive(w)) {
+					if (lane == 0) __hip_atomic_store(&S.done[w], 1 << 28, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					return;
+				}
+				const int64_t sid = (int64_t)tkl * nbj + tjl;
+				const bool jin_glob = !JIN_INT && (tjl > 0), kin_glob = !KIN_INT && (tkl > 0);
+				// an outer face without a predecessor bundle reads zeros: the buffers are cleared once, nobody else writes them
+				if (!JIN_INT && !jin_glob)
+					for (int q = lane; q < 8 * SB_FR; q += 64) (&S.FR[gJ][0][0])[q] = 0.f;
+				if (!KIN_INT && !kin_glob)
+					for (int q = lane; q < 8 * SB_FR; q += 64) (&S.FR[gK][0][0])[q] = 0.f;
+				const bool jout_glob = JOUT_GLOB && (tjl + 1 < nbj), kout_glob = KOUT_GLOB && (tkl + 1 < nbk);
+				// outer face lanes: b == 7 publish the j face, c == 7 the k face; when both are outer (w == 3) lane 0 stands in for
+				// lane 63's k value (lane 63 is busy with its j value; lane 0's own x' runs 14 ahead of lane 63's)
+				const bool corner_proxy = BOTH_GLOB && kout_glob && (lane == 0);
+				const bool gl_j = jout_glob && (b == 7), gl_k = kout_glob && (c == 7) && !(BOTH_GLOB && lane == 63);
+				const bool face_lane = gl_j || gl_k || corner_proxy;
+				const int fskew = corner_proxy ? -14 : 0;
+				unsigned long long* out_f = gl_j ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
+				// inner face lanes write LDS every step; all other lanes write to a dump slot (no exec juggling in the step)
+				const bool lj_real = !JOUT_GLOB && (b == 7) && sub_alive(w + 1), lk_real = !KOUT_GLOB && (c == 7) && sub_alive(w + 2);
+				float* lds_j = lj_real ? &S.FR[rJ_out][c][0] : &S.dump[lane];
+				float* lds_k = lk_real ? &S.FR[rK_out][b][0] : &S.dump[lane];
+				float4* ring = S.ring[w];
+				float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
+				float4 nxt = ring[lane];                 // ring row of h = -2 (never valid)
+				const bool tr = trace && (t == trace_ticket) && lane == 0;
+				long long* trb = trace + (int64_t)w * 4 * 64;
+#define SB_TRACE(i) if (tr && m < 64) trb[m * 4 + (i)] = wall_clock64();
+				if (trace && lane == 0 && w == 0 && t < 2048) trace[1024 + 2 * t] = wall_clock64();
+				auto block = [&](int m, auto edge_tag) {
+					constexpr bool EDGE = decltype(edge_tag)::value;
+					const int xq = 8 * m - 2 - skew;
+					SB_TRACE(0)
+					if (m < nchunks) wait_ge(&S.ready[w], m + 1, 1);
+					SB_TRACE(1)
+					const int need_int = (m + 2 < nblocks) ? m + 2 : nblocks;
+					if (JIN_INT) wait_ge(&S.done[JIN_INT ? w - 1 : 0], need_int, 1);
+					else if (jin_glob) wait_ge(&S.faces[gJ], m + 1, 1);
+					if (KIN_INT) wait_ge(&S.done[KIN_INT ? w - 2 : 0], need_int, 1);
+					else if (kin_glob) wait_ge(&S.faces[gK], m + 1, 1);
+					// never run more than SB_AHEAD blocks ahead of the consumer of an inner face (a consumer that does not exist has
+					// done = 2^28)
+					if (!JOUT_GLOB) wait_ge(&S.done[JOUT_GLOB ? 0 : w + 1], m - SB_AHEAD, 1);
+					if (!KOUT_GLOB) wait_ge(&S.done[KOUT_GLOB ? 0 : w + 2], m - SB_AHEAD, 1);
+					SB_TRACE(2)
+					float gj[8], gk[8];
+					{
+						const int r0 = (8 * m) & (SB_FR - 1);
+						const float* pj = &S.FR[rJ_in][c][r0];
+						const float* pk_ = &S.FR[rK_in][b][r0];
+						const float4 j0 = *(const float4*)pj, j1 = *(const float4*)(pj + 4);
+						const float4 k0 = *(const float4*)pk_, k1 = *(const float4*)(pk_ + 4);
+						gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
+						gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
+					}
+					const int base = (8 * m) & 31;
+					unsigned long long* pf = out_f + (int64_t)(8 * m) * 8;
+					// inner face slots of this block: producer row 8m + s -> slot (8m + s - 7) & (SB_FR - 1)
+					float* wjA = lds_j + (lj_real ? ((8 * m - 8) & (SB_FR - 1)) : 0);   // + s + 1 for s < 7
+					float* wjB = lds_j + (lj_real ? ((8 * m) & (SB_FR - 1)) : 0);       // s == 7
+					float* wkA = lds_k + (lk_real ? ((8 * m - 8) & (SB_FR - 1)) : 0);
+					float* wkB = lds_k + (lk_real ? ((8 * m) & (SB_FR - 1)) : 0);
+#pragma unroll
+					for (int s = 0; s < 8; s++) {
+						const float4 cur = nxt;
+						const int row = ((base + s) & 31) * 64 + lane;
+						const int nrow = ((base + s + 1) & 31) * 64 + lane;
+						nxt = ring[nrow];
+						const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+						const float sk_ = (dbg & 4) ? dj : __shfl_up(ok0, 8, 64);
+						const float ij0 = (b == 0) ? gj[s] : dj;
+						const float ik0 = (c == 0) ? gk[s] : sk_;
+						const float ii0 = oi0;
+						const bool valid = !EDGE || ((unsigned)(xq + s) < (unsigned)X8);
+						const float pa = __builtin_fabsf(cur.y);
+						const bool fl = __float_as_int(cur.y) >= 0;
+						float val = cur.x;
+						if (MODE == 1) {
+							const float nv = pa * (val - ii0 - ij0 - ik0);
+							val = fl ? nv : val;
+							const float ti = sb_mulh(val, cur.z, false, negzero), tj_ = sb_mulh(val, cur.z, true, negzero), tk_ = sb_mulh(val, cur.w, false, negzero);
+							oi0 = valid ? ti * pa : 0.f;
+							oj0 = valid ? tj_ * pa : 0.f;
+							ok0 = valid ? tk_ * pa : 0.f;
+						} else {
+							const float ti = sb_mulh(ii0, cur.z, false, negzero), tj_ = sb_mulh(ij0, cur.z, true, negzero), tk_ = sb_mulh(ik0, cur.w, false, negzero);
+							const float nv = pa * (val - ti * pa - tj_ * pa - tk_ * pa);
+							val = fl ? nv : val;
+							oi0 = oj0 = ok0 = valid ? val : 0.f;
+						}
+						if (valid && !(dbg & 1)) ring[row].x = val;
+						if (!JOUT_GLOB && !(dbg & 2)) {
+							if (s < 7) wjA[s + 1] = oj0;
+							else wjB[0] = oj0;
+						}
+						if (!KOUT_GLOB && !(dbg & 2)) {
+							if (s < 7) wkA[s + 1] = ok0;
+							else wkB[0] = ok0;
+						}
+						if (JOUT_GLOB || KOUT_GLOB) {
+							float fv = (JOUT_GLOB && !KOUT_GLOB) ? oj0 : ((KOUT_GLOB && !JOUT_GLOB) ? ok0 : ((b == 7) ? oj0 : ok0));
+							if (BOTH_GLOB) {
+								const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), 63));
+								fv = (lane == 0) ? corner : fv;
+							}
+							if (face_lane) {
+								const bool fvalid = !EDGE || ((unsigned)(xq + s + fskew) < (unsigned)X8);
+								if (fvalid) granule_store(pf + s * 8, fv, gen);
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+					__hip_atomic_store(&S.done[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					SB_TRACE(3)
+				};
+#pragma unroll 1
+				for (int m = 0; m < nblocks; m++) {
+					const bool interior = (m >= 2 && m <= nchunks - 1);
+					if (interior) block(m, std::false_type{});
+					else block(m, std::true_type{});
+				}
+				if (trace && lane == 0 && w == 0 && t < 2048) trace[1024 + 2 * t + 1] = wall_clock64();
+#undef SB_TRACE
+			};
+			if (wave == 0) compute(std::integral_constant<int, 0>{});
+			else if (wave == 1) compute(std::integral_constant<int, 1>{});
+			else if (wave == 2) compute(std::integral_constant<int, 2>{});
+			else compute(std::integral_constant<int, 3>{});
+		} else if (wave < 8) {
+			// ===================================== loader wave of sub-bundle w (own function: own register allocation) =====================================
+			const int w = wave - 4;
+			if (sub_alive(w)) {
+				const int tjl = sub_tjl(w), tkl = sub_tkl(w);
+				const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
+				const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
+				const bool row_in = (j < d.sy) && (k < d.sz);
+				const int sp = sb_loader<MODE>(S.ring[w], &S.ready[w], &S.flushed[w], nchunks, row_in, d.Y * j + d.Z * k, coef, Ap, dst, var1,
+				                               (trace && t == trace_ticket) ? trace + 5120 + w * 64 : nullptr);
+				spins += sp;
+			}
+		} else if (wave == 8) {
+			// ===================================== write-back wave (all four sub-bundles, each at its own pace) =====================================
+			int q[4] = {0, 0, 0, 0};
+			int64_t rowbase[4];
+			bool rin[4], live[4];
+#pragma unroll
+			for (int w = 0; w < 4; w++) {
+				live[w] = sub_alive(w);
+				const int tjl = sub_tjl(w), tkl = sub_tkl(w);
+				const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
+				const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
+				rin[w] = live[w] && (j < d.sy) && (k < d.sz);
+				rowbase[w] = d.Y * j + d.Z * k;
+				if (!live[w]) q[w] = nchunks;
+			}
+			for (;;) {
+				bool all = true, any = false;
+#pragma unroll
+				for (int w = 0; w < 4; w++) {
+					if (q[w] >= nchunks) continue;
+					all = false;
+					if (__hip_atomic_load(&S.done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < q[w] + 3) continue;   // chunk q is complete once block q+2 is finished
+					any = true;
+					const int p0 = 8 * q[w] + skew + 2;
+					float r[8];
+#pragma unroll
+					for (int e = 0; e < 8; e++) r[REV ? 7 - e : e] = S.ring[w][((p0 + e) & 31) * 64 + lane].x;
+					__hip_atomic_store(&S.flushed[w], q[w] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (trace && t == trace_ticket && lane == 0 && q[w] < 64) trace[5376 + w * 64 + q[w]] = wall_clock64();
+					const int x0 = (REV ? nchunks - 1 - q[w] : q[w]) * 8;
+					if (rin[w]) {
+						*(float4*)(dst + rowbase[w] + x0) = make_float4(r[0], r[1], r[2], r[3]);
+						*(float4*)(dst + rowbase[w] + x0 + 4) = make_float4(r[4], r[5], r[6], r[7]);
+					}
+					q[w]++;
+				}
+				if (all) break;
+				if (!any) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(4);
+				}
+			}
+		} else {
+			// ===================================== face poller: four 8-lane groups, each follows its own consumer =====================================
+			// group g = lane >> 3 (lanes 0..31): 0 j face of w0, 1 j face of w2, 2 k face of w0, 3 k face of w1; f = lane & 7 = face lane.
+			// A round trip to the granule arrays costs more than a block of the compute waves, so every round fetches the windows of
+			// SB_PW consecutive blocks and publishes as many leading ones as are complete (the face rings hold SB_FR / 8 blocks).
+			const int g = lane >> 3, f = lane & 7;
+			const int cw = (g == 0 || g == 2) ? 0 : (g == 1 ? 2 : 1);       // consumer sub-bundle
+			const bool isj = g < 2;
+			bool live = (lane < 32) && sub_alive(cw);
+			const int tjl = sub_tjl(cw), tkl = sub_tkl(cw);
+			if (live) live = isj ? (tjl > 0) : (tkl > 0);
+			const int64_t sid = (int64_t)tkl * nbj + tjl;
+			const unsigned long long* in = isj ? xj + (sid - 1) * XP * 8 + f : xk + (sid - nbj) * XP * 8 + f;
+			float* ringf = &S.FR[g & 3][f][0];
+			int m = live ? 0 : nblocks;
+			bool hot = false;      // per group: has a recent round published?  A cold group only probes the last row of its next window
+			int empty = 0;         // consecutive rounds without a publish: a group goes cold after SB_COLD_AFTER of them
+			for (;;) {
+				if (__all(m >= nblocks)) break;
+				unsigned long long gv[SB_PW][8];
+				int nok = 0;
+				if (m < nblocks && !hot) {
+					// probe: one granule per lane = one 64-byte line per group.  A producer stores its rows in order, so a fresh last row
+					// says the window is (nearly) there; the full fetch below verifies every tag.
+					const int xl = 8 * m - 2 - f + 7;
+					const unsigned long long pv = granule_load(in + (int64_t)(8 * m + 14) * 8);
+					const bool fresh = ((unsigned)(pv >> 32) == gen) || !((unsigned)xl < (unsigned)X8);
+					const unsigned long long fm = __ballot(fresh);
+					hot = ((fm >> (8 * g)) & 0xffull) != 0ull;
+				}
+				if (m < nblocks && hot) {
+#pragma unroll
+					for (int q = 0; q < SB_PW; q++) {
+						const int mq = (m + q < nblocks) ? m + q : nblocks - 1;
+#pragma unroll
+						for (int a = 0; a < 8; a++) gv[q][a] = granule_load(in + (int64_t)(8 * mq + 7 + a) * 8);
+					}
+					const int cdone = __hip_atomic_load(&S.done[cw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					bool run = true;
+#pragma unroll
+					for (int q = 0; q < SB_PW; q++) {
+						const int mq = m + q;
+						const int xq = 8 * mq - 2 - f;          // consumer lane (0, f) / (f, 0): skew f
+						unsigned tmin = gen;
+#pragma unroll
+						for (int a = 0; a < 8; a++) {
+							const bool inr = (unsigned)(xq + a) < (unsigned)X8;
+							const unsigned tg = (unsigned)(gv[q][a] >> 32);
+							tmin = min(tmin, inr ? tg : gen);
+						}
+						// complete, inside the sweep, and its ring slots were read (the consumer has finished block mq - SB_FR / 8)
+						run = run && (mq < nblocks) && (tmin == gen) && (cdone >= mq - SB_AHEAD);
+						nok += run ? 1 : 0;
+					}
+				}
+				// a group publishes the leading windows that are complete in all of its eight lanes
+				int gn = 0;
+				bool chain = true;
+#pragma unroll
+				for (int q = 0; q < SB_PW; q++) {
+					const unsigned long long okm = __ballot(nok > q);
+					chain = chain && (((okm >> (8 * g)) & 0xffull) == 0xffull);
+					gn += chain ? 1 : 0;
+				}
+				if (m >= nblocks) gn = 0;
+#pragma unroll
+				for (int q = 0; q < SB_PW; q++) {
+					if (q < gn) {
+						const int r0 = (8 * (m + q)) & (SB_FR - 1);
+						*(float4*)(ringf + r0) = make_float4(__uint_as_float((unsigned)gv[q][0]), __uint_as_float((unsigned)gv[q][1]), __uint_as_float((unsigned)gv[q][2]), __uint_as_float((unsigned)gv[q][3]));
+						*(float4*)(ringf + r0 + 4) = make_float4(__uint_as_float((unsigned)gv[q][4]), __uint_as_float((unsigned)gv[q][5]), __uint_as_float((unsigned)gv[q][6]), __uint_as_float((unsigned)gv[q][7]));
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+				if (m < nblocks) {
+					empty = gn > 0 ? 0 : empty + 1;
+					hot = empty < 8;
+				}
+				if (gn > 0) {
+					if (trace && t == trace_ticket && f == 0 && lane < 32)
+						for (int q = 0; q < gn; q++) if (m + q < 64) trace[5632 + (g & 3) * 64 + m + q] = wall_clock64();
+					if (f == 0) __hip_atomic_store(&S.faces[g & 3], m + gn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					m += gn;
+				} else {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(4);
+				}
+			}
+		}
+		__syncthreads();
+	}
+	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+	if (threadIdx.x == 0) {
+		const int fin = atomicAdd(&ctl->finished, 1);
+		if (fin == (int)gridDim.x - 1) {
+			tick[0] = 0;
+			ctl->finished = 0;
+		}
+	}
+}
+
 // one byte per cell: bit 0 fluid, bits 1..3 "Ai / Aj / Ak is -1"; ok[0] is cleared when a coefficient is neither +0 nor -1
 // (second-order boundaries, a caller's own matrix): the sweeps then read the four arrays themselves
 __global__ void __launch_bounds__(BLOCK)
@@ -926,6 +1404,19 @@ k_mic_pack(int64_t n, const int32_t* __restrict__ flags, const float* __restrict
 	const bool good = (ui == 0u || ui == M1) && (uj == 0u || uj == M1) && (uk == 0u || uk == M1);
 	if (!good) ok[0] = 0;
 	pack[idx] = (unsigned char)(((flags[idx] & MF_FLUID) ? 1u : 0u) | (ui == M1 ? 2u : 0u) | (uj == M1 ? 4u : 0u) | (uk == M1 ? 8u : 0u));
+}
+
+// the coefficient word of k_mic_sb, one per cell: bytes {Ai == -1 ? 0xBC : 0, Aj ..., Ak ..., fluid ? 0 : 0x80} -- 0xBC00 is fp16 -1.0, so
+// a byte permute turns the word into the two fp16 pairs of the LDS slot, and bit 31 is the "not a fluid cell" mark that goes onto
+// the sign of Aprecond.  Valid under the same condition as the packed bytes (every coefficient exactly +0 or -1: ok[0] of k_mic_pack).
+__global__ void __launch_bounds__(BLOCK)
+k_mic_sbcoef(int64_t n, const int32_t* __restrict__ flags, const float* __restrict__ Ai, const float* __restrict__ Aj,
+             const float* __restrict__ Ak, unsigned* __restrict__ coef) {
+	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (idx >= n) return;
+	const unsigned M1 = 0xBF800000u;   // -1.0f
+	const unsigned ui = __float_as_uint(Ai[idx]), uj = __float_as_uint(Aj[idx]), uk = __float_as_uint(Ak[idx]);
+	coef[idx] = (ui == M1 ? 0xBCu : 0u) | (uj == M1 ? 0xBC00u : 0u) | (uk == M1 ? 0xBC0000u : 0u) | ((flags[idx] & MF_FLUID) ? 0u : 0x80000000u);
 }
 
 // bempty[tk * nbj + tj] = 1 when the 8x8 bundle of x-rows (tj, tk) needs no sweep: it has no fluid cell, and nothing couples
@@ -976,6 +1467,17 @@ struct FlowState {
 	// preconditioner blocks of the system mf_mic_init_blocked was given (0 = uncut): the apply sweeps use them only when they
 	// are called with the same flags / Aprecond / Aj / Ak (be_*), any other system is swept as the uncut reference algorithm
 	int blk_rows = 0, blk_cells = 0;
+	// what the host knows about the system mf_mic_init registered (read back once per system, one stream synchronisation):
+	// are the packed bytes exact, and does any row bundle sit out the sweeps?  The super-bundle sweeps need yes / no.
+	bool sys_known = false;
+	int pack_ok_host = 0, nempty_host = 0;
+	// super-bundle sweeps (k_mic_sb): ticket order of the 16 x 16-row blocks, ticket counter
+	int sb_nsj = 0, sb_nsk = 0;
+	int* sb_order = nullptr;
+	int* sb_tick = nullptr;
+	unsigned* sb_coef = nullptr;      // k_mic_sbcoef words of the registered system (nullptr: not built, e.g. sx % 8 != 0)
+	size_t sb_coef_cap = 0;
+	bool sb_coef_valid = false;
 	// packed operands of the apply sweeps (k_mic_pack), valid for the grids mf_mic_init was given
 	unsigned char* pack = nullptr;
 	int* pack_ok = nullptr;
@@ -1152,13 +1654,14 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 // 1 "tiles" : one launch per sweep, ticketed 8^3 tiles + tagged sc1 granules, operands of the next tile prefetched
 //              (256^3 apply 1.32 ms)
 // 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback, 2.2 ms)
-static int g_mic_mode = -1;
+static int g_mic_mode = -1;     // 0 levels, 1 tiles, 2 rows, 3 rows-sb (super-bundles where they apply, else rows)
 extern "C" int mf_set_mic_mode(const char* name) {
 	if (!name || !*name) g_mic_mode = -1;
 	else if (!strcmp(name, "levels")) g_mic_mode = 0;
 	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
 	else if (!strcmp(name, "rows")) g_mic_mode = 2;
-	else return fail("mf_set_mic_mode: unknown mode (rows | tiles | levels)");
+	else if (!strcmp(name, "rows-sb")) g_mic_mode = 3;      // "rows" with the super-bundle form (2 x 2 bundles per workgroup) where it applies
+	else return fail("mf_set_mic_mode: unknown mode (rows | rows-sb | tiles | levels)");
 	return 0;
 }
 extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, void* stream) {
@@ -1194,11 +1697,103 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 static int mic_mode_() {
 	if (g_mic_mode < 0) {
 		const char* e = getenv("MF_MIC_MODE");
-		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : 2);
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : ((e && !strcmp(e, "rows-sb")) ? 3 : 2));
 	}
-	return g_mic_mode;
+	return g_mic_mode >= 2 ? 2 : g_mic_mode;
 }
+static bool mic_sb_() { (void)mic_mode_(); return g_mic_mode == 3; }
 
+// host side of k_mic_sb: ticket order (anti-diagonals of the super-bundle grid, logical coordinates: the same table serves both
+// sweeps), ticket counter, dynamic LDS size
+template <int MODE>
+static int sb_launch(const Dim& d, FlowState* f, float* dst, const float* var1, const float* Ap, const CgScalars* sc, hipStream_t st) {
+	const int nsj = (f->nbj + 1) / 2, nsk = (f->nbk + 1) / 2, nsb = nsj * nsk;
+	if (f->sb_nsj != nsj || f->sb_nsk != nsk) {
+		MF_HIP(hipStreamSynchronize(st));
+		int* h = (int*)malloc(sizeof(int) * nsb);
+		int q = 0;
+		for (int L = 0; L <= nsj + nsk - 2; L++)
+			for (int SK = 0; SK < nsk; SK++) {
+				const int SJ = L - SK;
+				if (SJ >= 0 && SJ < nsj) h[q++] = SJ | (SK << 12);
+			}
+		if (f->sb_order) MF_HIP(hipFree(f->sb_order));
+		MF_HIP(hipMalloc((void**)&f->sb_order, sizeof(int) * nsb));
+		MF_HIP(hipMemcpy(f->sb_order, h, sizeof(int) * nsb, hipMemcpyHostToDevice));
+		free(h);
+		if (!f->sb_tick) MF_HIP(hipMalloc((void**)&f->sb_tick, sizeof(int)));
+		MF_HIP(hipMemset(f->sb_tick, 0, sizeof(int)));
+		f->sb_nsj = nsj;
+		f->sb_nsk = nsk;
+	}
+	static bool attr_set = false;
+	if (!attr_set) {
+		MF_HIP(hipFuncSetAttribute((const void*)k_mic_sb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbShared)));
+		MF_HIP(hipFuncSetAttribute((const void*)k_mic_sb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbShared)));
+		attr_set = true;
+	}
+	static int ncu = -1;
+	if (ncu < 0) {
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		ncu = 256;
+		(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+		const char* e = getenv("MF_SB_WGS");
+		if (e) ncu = atoi(e);
+		if (ncu < 1) ncu = 1;
+	}
+	const int grid = nsb < ncu ? nsb : ncu;
+	union { unsigned u; float fl; } nz;
+	nz.u = 0x80000000u;
+	// MF_SB_TRACE=<ticket>: wall-clock stamps (100 MHz) of that super-bundle's four compute waves per block, and start / end of every
+	// super-bundle's wave 0, printed for the first launches
+	static const int dbg = getenv("MF_SB_DBG") ? atoi(getenv("MF_SB_DBG")) : 0;     // timing experiments only (wrong results)
+	static long long* trace = nullptr;
+	static int trace_ticket = -2;
+	if (trace_ticket == -2) {
+		const char* e = getenv("MF_SB_TRACE");
+		trace_ticket = e ? atoi(e) : -1;
+		if (trace_ticket >= 0) {
+			MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 8192));
+			MF_HIP(hipMemset(trace, 0, sizeof(long long) * 8192));
+		}
+	}
+	hipLaunchKernelGGL((k_mic_sb<MODE>), dim3(grid), dim3(SB_THREADS), sizeof(SbShared), st, d, f->nbj, f->nbk, nsj, nsb, f->nchunks, f->sb_order, f->ctl,
+	                   f->sb_tick, f->sxj, f->sxk, f->sgen, dst, var1, Ap, sc, f->sb_coef, nz.fl, trace, trace_ticket, dbg);
+	MF_LAUNCH_CHECK();
+	if (trace) {
+		static int printed = 0;
+		MF_HIP(hipStreamSynchronize(st));
+		if (printed++ < 2) {
+			long long* h = (long long*)malloc(sizeof(long long) * 8192);
+			MF_HIP(hipMemcpy(h, trace, sizeof(long long) * 8192, hipMemcpyDeviceToHost));
+			const int nb = f->nchunks + 2 < 64 ? f->nchunks + 2 : 64;
+			long long t0 = h[0];
+			fprintf(stderr, "[sb trace] mode %d ticket %d: per wave and block: gap | wait ready | wait faces | steps (us), end time\n", MODE, trace_ticket);
+			for (int w = 0; w < 4; w++) {
+				const long long* b = h + w * 256;
+				for (int m = 0; m < nb; m++)
+					fprintf(stderr, "  w%d m=%2d  %6.2f %6.2f %6.2f %6.2f   t=%8.2f\n", w, m, m ? (b[m * 4] - b[m * 4 - 1]) * 0.01 : (b[0] - t0) * 0.01, (b[m * 4 + 1] - b[m * 4]) * 0.01,
+					        (b[m * 4 + 2] - b[m * 4 + 1]) * 0.01, (b[m * 4 + 3] - b[m * 4 + 2]) * 0.01, (b[m * 4 + 3] - t0) * 0.01);
+			}
+			fprintf(stderr, "[sb trace] helper stamps (us since the super-bundle's start): block | commit w0..w3 | flush w0..w3 | publish g0..g3\n");
+			for (int m = 0; m < nb; m++) {
+				fprintf(stderr, "  m=%2d |", m);
+				for (int q = 0; q < 12; q++) {
+					const long long v = h[5120 + q * 64 + m];
+					fprintf(stderr, " %7.2f%s", v ? (v - t0) * 0.01 : -1.0, (q % 4 == 3) ? " |" : "");
+				}
+				fprintf(stderr, "\n");
+			}
+			long long g0 = h[1024];
+			for (int i = 0; i < nsb && i < 2048; i++) if (h[1024 + 2 * i] && h[1024 + 2 * i] < g0) g0 = h[1024 + 2 * i];
+			fprintf(stderr, "[sb trace] super-bundles (ticket: start end, us since the first start)\n");
+			for (int i = 0; i < nsb && i < 2048; i += (nsb > 64 ? 7 : 1)) fprintf(stderr, "  t=%4d  %8.2f %8.2f\n", i, (h[1024 + 2 * i] - g0) * 0.01, (h[1024 + 2 * i + 1] - g0) * 0.01);
+			free(h);
+		}
+	}
+	return 0;
+}
 // set by mic_launch_dot for the duration of one backward-sweep launch
 static thread_local double* g_dot_request = nullptr;
 static thread_local int g_dot_count = 0;
@@ -1221,6 +1816,26 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
 				MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
 				f->sgen = 1;
+			}
+			// ---- super-bundle sweeps: the uncut system mf_mic_init registered, packed coefficients exact, every bundle swept ----
+			static const bool nosb = getenv("MF_MIC_NOSB") != nullptr;
+			static const bool nopack_sb = getenv("MF_MIC_NOPACK") != nullptr;
+			if (!nosb && mic_sb_() && !nopack_sb && vec && (d.sx % 8) == 0 && same_system && f->blk_rows == 0 && f->blk_cells == 0 && f->pack &&
+			    f->pk_flags == flags && f->pk_Ai == Ai && f->pk_Aj == Aj && f->pk_Ak == Ak && d.sx >= 32 && f->sb_coef_valid) {
+				if (!f->sys_known) {
+					int h[2] = {0, 0};
+					MF_HIP(hipMemcpyAsync(&h[0], f->pack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+					MF_HIP(hipMemcpyAsync(&h[1], f->bempty + f->nbj * f->nbk, sizeof(int), hipMemcpyDeviceToHost, st));
+					MF_HIP(hipStreamSynchronize(st));
+					f->pack_ok_host = h[0] != 0;
+					f->nempty_host = h[1];
+					f->sys_known = true;
+				}
+				if (f->pack_ok_host && f->nempty_host == 0) {
+					MF_TRY(sb_launch<MODE>(d, f, dst, var1, Ap, sc, st));
+					g_dot_count = 0;      // no fused dot in this form: the caller runs its own dot kernel
+					return 0;
+				}
 			}
 			static int rwgs = -1;
 			if (rwgs < 0) {
@@ -1418,6 +2033,7 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 		MF_TRY(rows_prepare(d, &f, (hipStream_t)stream, rows_j, cells_x));
 		f->blk_rows = rows_j;
 		f->blk_cells = cells_x;
+		f->sys_known = false;
 		if (f->nblocks + 1 > f->bempty_cap) {
 			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
 			if (f->bempty) MF_HIP(hipFree(f->bempty));
@@ -1446,6 +2062,20 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 		f->pk_Ai = Ai;
 		f->pk_Aj = Aj;
 		f->pk_Ak = Ak;
+		// coefficient words of the super-bundle sweeps (uncut systems with sx % 8 == 0)
+		f->sb_coef_valid = false;
+		static const bool nosb_init = getenv("MF_MIC_NOSB") != nullptr;
+		if (!nosb_init && mic_sb_() && rows_j == 0 && cells_x == 0 && (d.sx % 8) == 0 && d.sx >= 32) {
+			if ((size_t)d.n > f->sb_coef_cap) {
+				MF_HIP(hipStreamSynchronize((hipStream_t)stream));
+				if (f->sb_coef) MF_HIP(hipFree(f->sb_coef));
+				MF_HIP(hipMalloc((void**)&f->sb_coef, sizeof(unsigned) * ((size_t)d.n + 64)));
+				f->sb_coef_cap = (size_t)d.n;
+			}
+			hipLaunchKernelGGL(k_mic_sbcoef, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d.n, flags, Ai, Aj, Ak, f->sb_coef);
+			MF_LAUNCH_CHECK();
+			f->sb_coef_valid = true;
+		}
 	}
 	return 0;
 }

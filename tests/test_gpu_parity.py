@@ -93,11 +93,13 @@ def test_mic(hip, oracle, dims):
         assert_bitexact(dst, dst_o, "mic apply")
 
 
-@pytest.mark.parametrize("mode", ["rows", "tiles", "levels"])
-@pytest.mark.parametrize("dims", [(32, 24, 40), (37, 21, 19), (64, 64, 64), (24, 40, 9), (16, 8, 136)])
+@pytest.mark.parametrize("mode", ["rows", "rows-sb", "tiles", "levels"])
+@pytest.mark.parametrize("dims", [(32, 24, 40), (37, 21, 19), (64, 64, 64), (24, 40, 9), (16, 8, 136), (40, 33, 27), (128, 40, 24), (32, 8, 8),
+                                  (96, 72, 17)])
 def test_mic_every_sweep_mode(hip, oracle, dims, mode):
-    """the three ways the MIC sweeps are parallelised (mf_set_mic_mode) give the serial sweep's bits, and a CG solve
-    takes the same number of iterations in each"""
+    """the ways the MIC sweeps are parallelised (mf_set_mic_mode) give the serial sweep's bits, and a CG solve takes the same
+    number of iterations in each.  "rows-sb" runs the super-bundle form (2 x 2 bundles of rows per workgroup, inner faces through
+    LDS) where sx % 8 == 0 and sx >= 32: odd bundle counts, rows outside the grid and a single bundle are among the sizes."""
     flags, A, src = cases.system_inputs(dims, 3)
     rhs = cases.cg_rhs(dims, flags, 3)
     ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
