@@ -209,6 +209,15 @@ int mf_maccormack_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags,
 /* MacCormackClampMAC, advection.cpp:271-288 + doClampComponentMAC :192-236 */
 int mf_maccormack_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* dst,
                             const float* orig, const float* fwd, float dt, int clampMode, void* stream);
+/* MacCormackCorrect + MacCormackClamp in ONE pass (advection.cpp:82-92 + 242-268, MAC: 95-116 + 271-288): the clamp only looks at
+ * the corrected value of its own cell, so the intermediate grid of the two-kernel sequence never has to exist.  Same result, bit
+ * for bit, as mf_maccormack_correct followed by mf_maccormack_clamp (dst receives the corrected value in the border cells the
+ * clamp does not visit).  dst must not alias orig / fwd / bwd. */
+int mf_maccormack_correct_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags, const float* vel, float* dst,
+                                const float* orig, const float* fwd, const float* bwd, float strength, float dt, int clampMode,
+                                void* stream);
+int mf_maccormack_correct_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* dst, const float* orig,
+                                    const float* fwd, const float* bwd, float strength, float dt, int clampMode, void* stream);
 /* applyOutflowBC = extrapolateVelConvectiveBC + copyChangedVels, advection.cpp:347-392.
  * velDst is a zeroed MAC scratch grid supplied by the caller. timeStep is the solver dt. */
 int mf_apply_outflow_bc(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* velPrev,

@@ -4,11 +4,14 @@
 // field are SoA planes so that a wave's 64 consecutive cells read 256 contiguous bytes per plane.
 #include "common.h"
 #include <float.h>
+#include <stdlib.h>
 
 using namespace mf;
 
+// blocks are dealt round-robin over the 8 XCDs: give every XCD one contiguous range of cells (a z-slab), so that the planes a
+// gather reaches stay in that XCD's L2 instead of being fetched from HBM by all eight (xcd_swizzle: speed only)
 #define CELL_IJK(d)                                                               \
-	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;                \
+	const int64_t idx = xcd_swizzle((int)blockIdx.x, (int)gridDim.x) * (int64_t)BLOCK + threadIdx.x; \
 	if (idx >= (d).n) return;                                                     \
 	const int i = (int)(idx % (d).sx);                                            \
 	const int j = (int)((idx / (d).sx) % (d).sy);                                 \
@@ -16,6 +19,11 @@ using namespace mf;
 	(void)i; (void)j; (void)k;
 #define INTERIOR(d) (i >= 1 && i < (d).sx - 1 && j >= 1 && j < (d).sy - 1 && (!(d).is3d || (k >= 1 && k < (d).sz - 1)))
 static inline unsigned nblk(const Dim& d) { return (unsigned)((d.n + BLOCK - 1) / BLOCK); }
+
+struct __attribute__((packed, aligned(4))) F2u {
+	float a, b;
+};
+__device__ __forceinline__ F2u ld2(const float* __restrict__ p) { return *(const F2u*)p; }   // 8-byte load from a 4-byte aligned address
 
 // SemiLagrange<T>, advection.cpp:25-42.  NCOMP scalar planes (1 = Real, 3 = cell-centred Vec3).
 template <int NCOMP>
@@ -223,12 +231,16 @@ __device__ __forceinline__ float clamp_component_mac(const Dim& d, int c, const 
 		const int k0 = local_z(d, clampi(czp, 0, d.is3d ? (gz - 1) : 0), 1);
 		const int nz = d.is3d ? 2 : 1;
 		for (int dz = 0; dz < nz; dz++)
-			for (int dy = 0; dy < 2; dy++)
-				for (int dx = 0; dx < 2; dx++) {
-					const float v = oc[(int64_t)(i0 + dx) + d.Y * (j0 + dy) + d.Z * (k0 + dz)];
-					if (v < minv) minv = v;
-					if (v > maxv) maxv = v;
-				}
+			for (int dy = 0; dy < 2; dy++) {
+				const float* rp = oc + (int64_t)i0 + d.Y * (j0 + dy) + d.Z * (k0 + dz);
+				F2u v2;
+				v2.a = rp[0];
+				v2.b = rp[1];
+				if (v2.a < minv) minv = v2.a;
+				if (v2.a > maxv) maxv = v2.a;
+				if (v2.b < minv) minv = v2.b;
+				if (v2.b > maxv) maxv = v2.b;
+			}
 	}
 	if (clampMode == 1)
 		dstv = dstv < minv ? minv : (dstv > maxv ? maxv : dstv);
@@ -255,6 +267,152 @@ k_maccormack_clamp_mac(Dim d, const int32_t* __restrict__ flags, const float* __
 	dst[idx] = rx;
 	dst[d.n + idx] = ry;
 	dst[2 * d.n + idx] = rz;
+}
+
+
+// =========================================================================================================
+// MacCormack's correction fused into its clamp: the clamp only looks at the corrected value of its own cell, so the intermediate
+// grid of the reference's two kernels (and one launch) disappears -- 52 + 64 -> 88 B per cell for MAC grids, 20 + 32 -> 36 for Real.
+// One cell per thread like the kernels above: a four-cells-per-thread variant of these gather kernels (16-byte velocity loads, 2-D
+// index instead of the 64-bit divisions) was measured SLOWER on the MI355X (semi-Lagrange MAC 470 vs 276 us at 256^3): the gathers
+// are latency-bound, and a quarter of the threads at 132 VGPRs leaves too few loads in flight.
+// =========================================================================================================
+// doClampComponent + the clampMode 1 trace test of MacCormackClamp<T> for one cell (advection.cpp:145-187, 250-264): dval in / out
+template <int NCOMP>
+__device__ __forceinline__ void clamp_cell(const Dim& d, const int32_t* __restrict__ flags, const float* __restrict__ orig, int i, int j, int k,
+                                           float vx, float vy, float vz, float dval[NCOMP], const float fw[NCOMP], int clampMode) {
+	float minv[NCOMP], maxv[NCOMP];
+#pragma unroll
+	for (int c = 0; c < NCOMP; c++) {
+		minv[c] = FLT_MAX;
+		maxv[c] = -FLT_MAX;
+	}
+	bool haveFl = false;
+	const int gx = d.sx - 1, gy = d.sy - 1, gz = d.gsz - 1;  // gridUpper = size - 1 (global z extent)
+	const int kg = k + d.zoff;
+	const int numPos = (clampMode == 1) ? 2 : 1;
+	for (int l = 0; l < numPos; l++) {
+		const float sg = l == 0 ? -1.f : 1.f;
+		const int cxp = (int)((float)i + sg * vx), cyp = (int)((float)j + sg * vy), czp = (int)((float)kg + sg * vz);
+		const int a0 = clampi(cxp, 0, gx - 1), b0 = clampi(cyp, 0, gy - 1);
+		const int c0 = local_z(d, clampi(czp, 0, d.is3d ? (gz - 1) : 1), 1);
+		const int nz = d.is3d ? 2 : 1;
+		for (int dz = 0; dz < nz; dz++)
+			for (int dy = 0; dy < 2; dy++) {
+				const int64_t q = (int64_t)a0 + d.Y * (b0 + dy) + d.Z * (c0 + dz);
+				const bool ok0 = checkflag(flags[q]), ok1 = checkflag(flags[q + 1]);
+#pragma unroll
+				for (int c = 0; c < NCOMP; c++) {
+					F2u o2;
+					o2.a = orig[c * d.n + q];
+					o2.b = orig[c * d.n + q + 1];
+					if (ok0) {
+						if (o2.a < minv[c]) minv[c] = o2.a;
+						if (o2.a > maxv[c]) maxv[c] = o2.a;
+					}
+					if (ok1) {
+						if (o2.b < minv[c]) minv[c] = o2.b;
+						if (o2.b > maxv[c]) maxv[c] = o2.b;
+					}
+				}
+				haveFl = haveFl || ok0 || ok1;
+			}
+	}
+	if (!haveFl) {
+#pragma unroll
+		for (int c = 0; c < NCOMP; c++) dval[c] = fw[c];
+	} else if (clampMode == 1) {
+#pragma unroll
+		for (int c = 0; c < NCOMP; c++) dval[c] = dval[c] < minv[c] ? minv[c] : (dval[c] > maxv[c] ? maxv[c] : dval[c]);
+	} else {
+		bool outside = false;
+#pragma unroll
+		for (int c = 0; c < NCOMP; c++) outside |= (dval[c] < minv[c]) | (dval[c] > maxv[c]);
+		if (outside) {
+#pragma unroll
+			for (int c = 0; c < NCOMP; c++) dval[c] = fw[c];
+		}
+	}
+	if (clampMode == 1) {
+		const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)kg + 0.5f;
+		const int fx = (int)(cx - vx), fy = (int)(cy - vy), fz = (int)(cz - vz);
+		const int bx = (int)(cx + vx), by = (int)(cy + vy), bz = (int)(cz + vz);
+		bool bad = fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > gx || fy > gy || ((fz > gz) && d.is3d) ||
+		           bx > gx || by > gy || ((bz > gz) && d.is3d);
+		if (!bad)
+			bad = (flags[(int64_t)fx + d.Y * fy + d.Z * local_z(d, fz, 0)] & MF_OBSTACLE) ||
+			      (flags[(int64_t)bx + d.Y * by + d.Z * local_z(d, bz, 0)] & MF_OBSTACLE);
+		if (bad) {
+#pragma unroll
+			for (int c = 0; c < NCOMP; c++) dval[c] = fw[c];
+		}
+	}
+}
+
+// MacCormackCorrect<T> + MacCormackClamp<T> (advection.cpp:82-92, 145-187, 242-268) in one pass over the grid
+template <int NCOMP>
+__global__ void __launch_bounds__(BLOCK)
+k_mc_correct_clamp(Dim d, const int32_t* __restrict__ flags, const float* __restrict__ vel, float* __restrict__ dst,
+                   const float* __restrict__ orig, const float* __restrict__ fwd, const float* __restrict__ bwd, float strength, float dt,
+                   int clampMode) {
+	CELL_IJK(d)
+	const bool fl = flags[idx] & MF_FLUID;
+	const double sh = (double)strength * 0.5;
+	float fw[NCOMP], dv[NCOMP];
+#pragma unroll
+	for (int c = 0; c < NCOMP; c++) {
+		const int64_t q = c * d.n + idx;
+		fw[c] = fwd[q];
+		float v = fw[c];
+		if (fl) {
+			const float df = orig[q] - bwd[q];
+			if (NCOMP == 1) v = (float)((double)v + sh * (double)df);
+			else v = v + (float)(sh * (double)df);
+		}
+		dv[c] = v;
+	}
+	if (INTERIOR(d)) {
+		float vx, vy, vz;
+		get_centered(d, vel, idx, vx, vy, vz);
+		clamp_cell<NCOMP>(d, flags, orig, i, j, k, vx * dt, vy * dt, vz * dt, dv, fw, clampMode);
+	}
+#pragma unroll
+	for (int c = 0; c < NCOMP; c++) dst[c * d.n + idx] = dv[c];
+}
+
+// MacCormackCorrectMAC + MacCormackClampMAC (advection.cpp:95-116, 192-236, 271-288) in one pass
+__global__ void __launch_bounds__(BLOCK)
+k_mc_correct_clamp_mac(Dim d, const int32_t* __restrict__ flags, const float* __restrict__ vel, float* __restrict__ dst,
+                       const float* __restrict__ orig, const float* __restrict__ fwd, const float* __restrict__ bwd, float strength, float dt,
+                       int clampMode) {
+	CELL_IJK(d)
+	bool s0 = false, s1 = false, s2 = false;
+	if (!(flags[idx] & MF_FLUID)) s0 = s1 = s2 = true;
+	if ((i > 0) && !(flags[idx - 1] & MF_FLUID)) s0 = true;
+	if ((j > 0) && !(flags[idx - d.Y] & MF_FLUID)) s1 = true;
+	if ((k > 0) && !(flags[idx - d.Z] & MF_FLUID)) s2 = true;
+	const double sh = (double)strength * 0.5;
+	const bool skip[3] = {s0, s1, s2};
+	float fw[3], dv[3];
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		const int64_t q = c * d.n + idx;
+		fw[c] = fwd[q];
+		dv[c] = skip[c] ? fw[c] : (float)((double)fw[c] + sh * (double)(orig[q] - bwd[q]));
+	}
+	if (INTERIOR(d)) {
+		float vx, vy, vz;
+		get_at_mac_x(d, vel, idx, vx, vy, vz);
+		dv[0] = clamp_component_mac(d, 0, flags, dv[0], orig, fw[0], i, j, k, vx * dt, vy * dt, vz * dt, clampMode);
+		get_at_mac_y(d, vel, idx, vx, vy, vz);
+		dv[1] = clamp_component_mac(d, 1, flags, dv[1], orig, fw[1], i, j, k, vx * dt, vy * dt, vz * dt, clampMode);
+		if (d.is3d) {
+			get_at_mac_z(d, vel, idx, vx, vy, vz);
+			dv[2] = clamp_component_mac(d, 2, flags, dv[2], orig, fw[2], i, j, k, vx * dt, vy * dt, vz * dt, clampMode);
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < 3; c++) dst[c * d.n + idx] = dv[c];
 }
 
 // extrapolateVelConvectiveBC + getBulkVel, advection.cpp:327-382 (KERNEL(): every cell; work only in outflow cells)
@@ -403,6 +561,29 @@ int mf_maccormack_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const 
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	hipLaunchKernelGGL(k_maccormack_clamp_mac, dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, vel, dst, orig, fwd, dt, clampMode);
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_maccormack_correct_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags, const float* vel, float* dst, const float* orig,
+                                const float* fwd, const float* bwd, float strength, float dt, int clampMode, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (dst == orig || dst == fwd || dst == bwd) return fail("mf_maccormack_correct_clamp: dst must not alias orig / fwd / bwd");
+	if (ncomp == 1)
+		hipLaunchKernelGGL((k_mc_correct_clamp<1>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, vel, dst, orig, fwd, bwd, strength, dt, clampMode);
+	else if (ncomp == 3)
+		hipLaunchKernelGGL((k_mc_correct_clamp<3>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, vel, dst, orig, fwd, bwd, strength, dt, clampMode);
+	else
+		return fail("ncomp must be 1 or 3");
+	MF_LAUNCH_CHECK();
+	return 0;
+}
+int mf_maccormack_correct_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* dst, const float* orig,
+                                    const float* fwd, const float* bwd, float strength, float dt, int clampMode, void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	if (dst == orig || dst == fwd || dst == bwd) return fail("mf_maccormack_correct_clamp_mac: dst must not alias orig / fwd / bwd");
+	hipLaunchKernelGGL(k_mc_correct_clamp_mac, dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, vel, dst, orig, fwd, bwd, strength, dt, clampMode);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

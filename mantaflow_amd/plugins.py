@@ -136,8 +136,9 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
         else:
             bwd, newg = MACGrid(s), MACGrid(s)
             lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), st)
-            lib.call("mf_maccormack_correct_mac", sx, sy, sz, flags.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength), st)
-            lib.call("mf_maccormack_clamp_mac", sx, sy, sz, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, dt, int(clampMode), st)
+            # MacCormackCorrectMAC + MacCormackClampMAC, fused (the clamp reads the corrected value of its own cell only)
+            lib.call("mf_maccormack_correct_clamp_mac", sx, sy, sz, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength),
+                     dt, int(clampMode), st)
             _apply_outflow_bc(flags, newg, grid, dt)
             grid.swap(newg)
     elif t & (GridBase.TypeReal | GridBase.TypeVec3):
@@ -152,8 +153,8 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
         else:
             bwd, newg = G(s), G(s)
             lib.call(sl, sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), st)
-            lib.call("mf_maccormack_correct", sx, sy, sz, ncomp, flags.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength), st)
-            lib.call("mf_maccormack_clamp", sx, sy, sz, ncomp, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, dt, int(clampMode), st)
+            lib.call("mf_maccormack_correct_clamp", sx, sy, sz, ncomp, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr,
+                     float(strength), dt, int(clampMode), st)
             grid.swap(newg)
     else:
         raise RuntimeError("AdvectSemiLagrange: Grid Type is not supported (only Real, Vec3, MAC, Levelset)")

@@ -1169,6 +1169,19 @@ static int cell_of(const Dim* d, float x, float y, float z, int* i, int* j, int*
 }
 /* domain-boundary test in global planes (a slab's outer ghost plane is not a domain wall) */
 static int z_wall(const Dim* d, int k, int w) { return d->is3d && (k + d->zoff <= w || k + d->zoff >= d->gsz - 1 - w); }
+/* the fused entry points of the HIP library: here simply the two reference kernels in sequence */
+int mf_maccormack_correct_clamp(int sx, int sy, int sz, int ncomp, const int32_t* flags, const float* vel, float* dst, const float* orig,
+                                const float* fwd, const float* bwd, float strength, float dt, int clampMode, void* st) {
+	int rc = mf_maccormack_correct(sx, sy, sz, ncomp, flags, dst, orig, fwd, bwd, strength, st);
+	if (rc) return rc;
+	return mf_maccormack_clamp(sx, sy, sz, ncomp, flags, vel, dst, orig, fwd, dt, clampMode, st);
+}
+int mf_maccormack_correct_clamp_mac(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* dst, const float* orig,
+                                    const float* fwd, const float* bwd, float strength, float dt, int clampMode, void* st) {
+	int rc = mf_maccormack_correct_mac(sx, sy, sz, flags, dst, orig, fwd, bwd, strength, st);
+	if (rc) return rc;
+	return mf_maccormack_clamp_mac(sx, sy, sz, flags, vel, dst, orig, fwd, dt, clampMode, st);
+}
 int mf_apply_outflow_bc(int sx, int sy, int sz, const int32_t* flags, float* vel, const float* velPrev, float* velDst,
                         float dtIn, void* st) {
 	(void)st;

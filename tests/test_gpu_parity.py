@@ -284,7 +284,7 @@ def test_solve_pressure_optional_terms(hip_backend, dims, terms, liquid):
     _close(a["vel"], b["vel"], "vel")
 
 
-@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 17, 9)])
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (33, 17, 9), (16, 12, 10), (40, 17, 12)])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 @pytest.mark.parametrize("order,clampMode", [(1, 2), (2, 1), (2, 2)])
 @pytest.mark.parametrize("orderTrace", [1, 2])

@@ -29,9 +29,9 @@ def main():
         nx, ny, nz = dims
         lib.call("mf_make_laplace_matrix", nx, ny, nz, flags.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, None, s.stream)
         src.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (nz, ny, nx)).astype(np.float32))
-        lib.call("mf_set_mic_blocking", int(os.environ.get("MF_MIC_BLOCK", "0")))   # timing only unless Aj is cut as well
-        lib.call("mf_set_mic_blocking_x", int(os.environ.get("MF_MIC_BLOCK_X", "0")))
-        lib.call("mf_mic_init", nx, ny, nz, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr, s.stream)
+        # MF_MIC_BLOCK / MF_MIC_BLOCK_X: y / x blocking of the sweeps (timing only unless Aj / Ai are cut as well)
+        lib.call("mf_mic_init_blocked", nx, ny, nz, flags.ptr, ap.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr,
+                 int(os.environ.get("MF_MIC_BLOCK", "0")), int(os.environ.get("MF_MIC_BLOCK_X", "0")), s.stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
@@ -140,10 +140,26 @@ def main():
         vel, dens = core.MACGrid(s), core.Grid(s)
         vel.from_numpy(np.ascontiguousarray(bench.synthetic_velocity(n, n, n).transpose(1, 2, 3, 0)))
         dens.from_numpy(bench.synthetic_density(n, n, n))
-        for _ in range(reps):
-            plugins.advectSemiLagrange(flags, vel, dens, order=2)
-            plugins.advectSemiLagrange(flags, vel, vel, order=2)
+        vel0 = core.MACGrid(s)
+        vel0.copyFrom(vel)
+        plugins.advectSemiLagrange(flags, vel, dens, order=2)
         torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        for _ in range(reps):
+            plugins.advectSemiLagrange(flags, vel0, dens, order=2)
+        ev[1].record()
+        for _ in range(reps):
+            vel.copyFrom(vel0)
+            plugins.advectSemiLagrange(flags, vel, vel, order=2)
+        ev[2].record()
+        torch.cuda.synchronize()
+        cells = dims[0] * dims[1] * dims[2]
+        t_real, t_mac = ev[0].elapsed_time(ev[1]) * 1e3 / reps, ev[1].elapsed_time(ev[2]) * 1e3 / reps
+        # algorithmic bytes per cell, SURVEY 8d: MacCormack Real 92, MAC 188 (+ 20 for the outflow-BC sweeps, + 24 for the copy here)
+        print("MacCormack Real %s: %.1f us per call = %.2f TB/s of 92 B/cell (%.3f of 8 TB/s)" % (dims, t_real, 92 * cells / t_real / 1e6, 92 * cells / t_real / 8e6))
+        print("MacCormack MAC  %s: %.1f us per call (incl. a 24 B/cell restore copy and the outflow-BC sweeps) = %.2f TB/s of 232 B/cell (%.3f of 8 TB/s)"
+              % (dims, t_mac, 232 * cells / t_mac / 1e6, 232 * cells / t_mac / 8e6))
 
 
 if __name__ == "__main__":
