@@ -449,6 +449,18 @@ int mf_cg_slab_axpy2(int64_t n, const void* scalars, float* x, const float* sear
 int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float* factor_dev, float sign, void* stream);
 /* dst = src + factor_dev[0] * dst */
 int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const float* factor_dev, void* stream);
+/* The z-slab PCG iteration has three stretches of device work between its communication points (halo exchange of `search`, gather of
+ * dot(A search, search), gather of {max|r|, dot(z, r)}).  These two entry points queue the second and the third stretch with ONE
+ * call each instead of three and two -- same kernels, same order; the host loop of a rank is per-iteration latency at N > 1:
+ *   mf_cg_slab_after_dp  : mf_cg_slab_alpha ; mf_cg_slab_axpy2 over the owned cells ; mf_mic_apply_dot_dev  (tmp = M^-1 residual)
+ *   mf_cg_slab_after_zr  : mf_cg_slab_beta ; mf_update_search_vec_dev over the owned cells
+ * `own_off` / `n_own`: first owned cell and number of owned cells of the slab's grids (ghost planes excluded). */
+int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
+                        float* x, const float* search, float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
+                        const int32_t* flags, const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
+                        void* stream);
+int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float accuracy, int iter, int32_t* state_dev, int64_t own_off,
+                        int64_t n_own, float* search, const float* tmp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HIP-only helpers (return an error in the CPU libraries)

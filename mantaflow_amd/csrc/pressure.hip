@@ -1083,4 +1083,23 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	return 0;
 }
 
+
+// the stretches of a z-slab PCG iteration between two communication points, queued with one call each (CgScalars layout: sigma,
+// alpha, nalpha, beta, resNorm at floats 0, 1, 2, 3, 4)
+int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
+                        float* x, const float* search, float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
+                        const int32_t* flags, const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
+                        void* stream) {
+	float* sc = (float*)scalars;
+	MF_TRY(mf_cg_slab_alpha(gathered, world, sc + 0, sc + 1, state_dev, stream));
+	MF_TRY(mf_cg_slab_axpy2(n_own, scalars, x + own_off, search + own_off, residual + own_off, tmp + own_off, maxabs_dev, stream));
+	return mf_mic_apply_dot_dev(sx, sy, sz, flags, tmp, residual, Aprecond, Ai, Aj, Ak, dot_dev, stream);
+}
+int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float accuracy, int iter, int32_t* state_dev, int64_t own_off,
+                        int64_t n_own, float* search, const float* tmp, void* stream) {
+	float* sc = (float*)scalars;
+	MF_TRY(mf_cg_slab_beta(gathered, world, sc + 0, sc + 3, sc + 4, accuracy, iter, state_dev, stream));
+	return mf_update_search_vec_dev(n_own, search + own_off, tmp + own_off, sc + 3, stream);
+}
+
 }  // extern "C"

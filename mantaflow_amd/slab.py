@@ -89,18 +89,19 @@ class Comm(object):
 
     def allgather_dev(self, t):
         """[k] tensor on the compute device -> [world][k] on the same device, without touching the host when the backend
-        moves device memory itself (nccl = RCCL); rows are in rank order on every rank, so reductions over them are
-        bit-identical everywhere"""
-        if not self.on:
+        moves device memory itself (nccl = RCCL: ONE collective into one tensor, no per-rank list and no stacking copy); rows are
+        in rank order on every rank, so reductions over them are bit-identical everywhere.  A world of one gathers nothing."""
+        if not self.on or self.world == 1:
             return t.unsqueeze(0)
-        if self.stage and t.is_cuda:
-            h = t.cpu()
+        if dist.get_backend() != "nccl":
+            # gloo rehearsals (CPU tensors, or device tensors staged through the host)
+            h = t.cpu() if t.is_cuda else t
             out = [torch.empty_like(h) for _ in range(self.world)]
             dist.all_gather(out, h)
             return torch.stack(out).to(t.device)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t)
-        return torch.stack(out)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out
 
 
 class SlabDomain(object):
@@ -334,14 +335,13 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         lib.call("mf_apply_matrix_dot_dev", sx, sy, sz, fmic.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr,
                  dom.gl, dom.gl + dom.nown, p_sc, p_red1, st)
         g1 = dom.comm.allgather_dev(red)
-        lib.call("mf_cg_slab_alpha", _ptr(g1), world, p_sigma, p_alpha, p_state, st)   # conjugategrad.cpp:252-254
-        lib.call("mf_cg_slab_axpy2", nown, p_sc, _off(pressure.data, off), _off(search.data, off), _off(residual.data, off),
-                 _off(tmp.data, off), p_red0, st)
-        # tmp = M^-1 residual with dot(tmp, residual) fused in (the residual is zero on the ghost planes: the sum is the owned one)
-        lib.call("mf_mic_apply_dot_dev", sx, sy, sz, fmic.ptr, tmp.ptr, residual.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, p_red1, st)
+        # alpha (conjugategrad.cpp:252-254); x += alpha search, r -= alpha tmp with max|r| fused in; tmp = M^-1 r with dot(tmp, r) fused
+        # in (the residual is zero on the ghost planes: the sum is the owned one) -- one call for the stretch up to the next gather
+        lib.call("mf_cg_slab_after_dp", _ptr(g1), world, p_sc, p_state, off, nown, pressure.ptr, search.ptr, residual.ptr, tmp.ptr, p_red0,
+                 sx, sy, sz, fmic.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, p_red1, st)
         g2 = dom.comm.allgather_dev(red)
-        lib.call("mf_cg_slab_beta", _ptr(g2), world, p_sigma, p_beta, p_res, acc32, it, p_state, st)
-        lib.call("mf_update_search_vec_dev", nown, _off(search.data, off), _off(tmp.data, off), p_beta, st)
+        # beta + stopping test on the device, search = tmp + beta search
+        lib.call("mf_cg_slab_after_zr", _ptr(g2), world, p_sc, acc32, it, p_state, off, nown, search.ptr, tmp.ptr, st)
         keep.append((g1, g2))                                     # gathered rows stay alive until the stream has consumed them
         if it % STOP_POLL == 0 or it == maxIter:
             stop, at = (int(v) for v in state.tolist())           # the one host read per STOP_POLL iterations

@@ -2962,3 +2962,23 @@ int mf_time_apply_matrix_packed(int sx, int sy, int sz, const int32_t* flags, fl
 	(void)avg_us; (void)st;
 	return fail("mf_time_apply_matrix_packed: HIP only");
 }
+
+/* the two composite stretches of the z-slab PCG iteration (same calls in the same order as the HIP library) */
+int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
+                        float* x, const float* search, float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
+                        const int32_t* flags, const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
+                        void* st) {
+	float* sc = (float*)scalars;
+	int rc = mf_cg_slab_alpha(gathered, world, sc + 0, sc + 1, state_dev, st);
+	if (rc) return rc;
+	rc = mf_cg_slab_axpy2(n_own, scalars, x + own_off, search + own_off, residual + own_off, tmp + own_off, maxabs_dev, st);
+	if (rc) return rc;
+	return mf_mic_apply_dot_dev(sx, sy, sz, flags, tmp, residual, Aprecond, Ai, Aj, Ak, dot_dev, st);
+}
+int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float accuracy, int iter, int32_t* state_dev, int64_t own_off,
+                        int64_t n_own, float* search, const float* tmp, void* st) {
+	float* sc = (float*)scalars;
+	int rc = mf_cg_slab_beta(gathered, world, sc + 0, sc + 3, sc + 4, accuracy, iter, state_dev, st);
+	if (rc) return rc;
+	return mf_update_search_vec_dev(n_own, search + own_off, tmp + own_off, sc + 3, st);
+}
