@@ -188,15 +188,16 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 /* ------------------------------------------------------------------------------------------------
  * Advection (plugin/advection.cpp)
  * ---------------------------------------------------------------------------------------------- */
-/* SemiLagrange<Real>, advection.cpp:25-42 (orderSpace must be 1; orderTrace 1|2).  bnd=1: border untouched */
+/* SemiLagrange<Real>, advection.cpp:25-42 (orderTrace 1|2: first-order / midpoint back trace; orderSpace 1|2: linear interpolation,
+ * util/interpol.h, or cubic, util/interpolHigh.h -- Grid::getInterpolatedHi, grid.h:153-159).  bnd=1: border untouched */
 int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
-                          int orderTrace, void* stream);
+                          int orderTrace, int orderSpace, void* stream);
 /* SemiLagrange<Vec3> (cell-centred Vec3 grid, SoA) */
 int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
-                          int orderTrace, void* stream);
-/* SemiLagrangeMAC, advection.cpp:45-78 */
+                          int orderTrace, int orderSpace, void* stream);
+/* SemiLagrangeMAC, advection.cpp:45-78 (orderSpace 2: MACGrid::getInterpolatedComponentHi -> interpolCubicMAC) */
 int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
-                         int orderTrace, void* stream);
+                         int orderTrace, int orderSpace, void* stream);
 /* MacCormackCorrect<Real|Vec3> KERNEL(idx), advection.cpp:82-92; ncomp = 1 (Real) or 3 (Vec3 SoA) */
 int mf_maccormack_correct(int sx, int sy, int sz, int ncomp, const int32_t* flags, float* dst, const float* old,
                           const float* fwd, const float* bwd, float strength, void* stream);
@@ -370,13 +371,13 @@ int mf_grid_set_bound(int sx, int sy, int sz, float* grid, float value, int boun
  * "next" rows: resampling between grids of different size (wavelet-turbulence up-res helpers)
  * ---------------------------------------------------------------------------------------------- */
 /* interpolateGrid / interpolateGridVec3 -> knInterpolateGridTempl, grid.h:576-581, plugin/waveletturbulence.cpp:37-56
- * (orderSpace 1).  target(i,j,k) = source.getInterpolated(Vec3(i,j,k) * sourceFactor + offset); ncomp 1|3 (SoA planes);
+ * target(i,j,k) = source.getInterpolatedHi(Vec3(i,j,k) * sourceFactor + offset, orderSpace) (1 linear, 2 cubic); ncomp 1|3 (SoA planes);
  * sourceFactor / offset are the values calcGridSizeFactorMod (:27-34) produces. */
 int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
-                        float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream);
+                        float sfx, float sfy, float sfz, float ox, float oy, float oz, int orderSpace, void* stream);
 /* interpolateMACGrid -> KnInterpolateMACGrid, plugin/waveletturbulence.cpp:59-78: component c sampled at pos - 0.5 e_c */
 int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
-                            float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream);
+                            float sfx, float sfy, float sfz, float ox, float oy, float oz, int orderSpace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Wavelet noise (noisefield.{h,cpp}) and the noise-modulated smoke source of scenes/simpleplume.py
@@ -406,12 +407,14 @@ int mf_vorticity_confinement(int sx, int sy, int sz, float* vel, const int32_t* 
                              const float* strengthCell, float* velCenter, float* curl, float* norm, float* force, void* stream);
 /* computeWaveletCoeffs -> WaveletNoiseField::computeCoefficients, noisefield.cpp:191-297; temp1/temp2: Real scratch grids */
 int mf_compute_wavelet_coeffs(int sx, int sy, int sz, float* input, float* temp1, float* temp2, void* stream);
-/* applyNoiseVec3 -> knApplyNoiseVec3, waveletturbulence.cpp:120-178 (no uv grid): target += evaluateCurl((i,j,k)+0.5) *
- * scaleSpatial...) * scale * w, w = weight(i,j,k) or, when the weight grid has another size, weight.getInterpolated.
- * params as for mf_density_inflow; weight nullable. */
+/* applyNoiseVec3 -> knApplyNoiseVec3, waveletturbulence.cpp:120-178: target += evaluateCurl(pos * scaleSpatial) * scale * w with
+ * pos = (i,j,k)+0.5 or, with a uv grid (Grid<Vec3>, SoA), uv(i,j,k); w = weight(i,j,k).  When the uv grid (or, without one, the
+ * weight grid) has another size than the target, both are read with getInterpolated at (i,j,k) * sourceFactor and the uv value is
+ * divided by sourceFactor.  uv and weight must have the same size (usx.. / wsx.. both describe it).  params as for
+ * mf_density_inflow; weight and uv nullable. */
 int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* target, const float* tile,
                         const float* params_host, float scale, float scaleSpatial, const float* weight, int wsx, int wsy,
-                        int wsz, void* stream);
+                        int wsz, const float* uv, int usx, int usy, int usz, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * device-scalar variants for the multi-GPU PCG (no reference counterpart: same arithmetic as mf_grid_dot /

@@ -3,7 +3,7 @@
 import sys
 
 from .core import (BasicParticleSystem, FlagGrid, FluidSolver, Grid, IntGrid, LevelsetGrid, MACGrid, Mesh, ParticleIndexSystem,
-                   PdataInt, PdataReal, PdataVec3, RealGrid, Solver, Vec3Grid, VecGrid, vec3)
+                   PdataInt, PdataReal, PdataVec3, RealGrid, Solver, Vec3Grid, VecGrid, vec3, vec4)
 from .plugins import (Timings, cgSolveDiffusion, getComponent, setComponent, resetOutflow, apicMapPartsToMAC, apicMapMACGridToParts, extrapolateMACFromWeight, extrapolateMACSimple, markFluidCells, addBuoyancy, addGravity, addGravityNoScale, advectSemiLagrange, computePressureRhs,
                       correctVelocity, flipVelocityUpdate, lastCgStats, mapGridToParts, mapGridToPartsVec3, mapMACToParts,
                       mapPartsToGrid, mapPartsToGridVec3, mapPartsToMAC, setDeterministicP2G, setWallBcs, solvePressure,
@@ -57,6 +57,7 @@ def printBuildInfo():
 Real = float
 false, true = False, True
 Vec3 = vec3
+Vec4 = vec4
 
 
 def assertNumpy():

@@ -73,6 +73,27 @@ class vec3(object):
     def max(self): return max(self.x, self.y, self.z)
 
 
+class vec4(object):
+    """manta.vec4 (pvec3.cpp:280-389): float[4] with members x, y, z, t; built from nothing (zeros), one number (broadcast) or four;
+    unlike vec3 it has no arithmetic (tp_as_number is NULL in the reference)"""
+    __slots__ = ("x", "y", "z", "t")
+
+    def __init__(self, x=None, y=None, z=None, t=None):
+        if x is None:
+            if not (y is None and z is None and t is None):
+                raise RuntimeError("Invalid partial init of vec4")
+            x = y = z = t = 0.0
+        elif y is None and z is None and t is None:
+            y = z = t = x
+        elif y is None or z is None or t is None:
+            raise RuntimeError("Invalid partial init of vec4")
+        self.x, self.y, self.z, self.t = (float(np.float32(v)) for v in (x, y, z, t))
+
+    def __iter__(self): return iter((self.x, self.y, self.z, self.t))
+    def __getitem__(self, i): return (self.x, self.y, self.z, self.t)[i]
+    def __repr__(self): return "[%+4.6f,%+4.6f,%+4.6f,%+4.6f]" % (self.x, self.y, self.z, self.t)
+
+
 def _to_vec3(v, what="Vec3"):
     if isinstance(v, vec3):
         return v

@@ -25,8 +25,9 @@ struct __attribute__((packed, aligned(4))) F2u {
 };
 __device__ __forceinline__ F2u ld2(const float* __restrict__ p) { return *(const F2u*)p; }   // 8-byte load from a 4-byte aligned address
 
-// SemiLagrange<T>, advection.cpp:25-42.  NCOMP scalar planes (1 = Real, 3 = cell-centred Vec3).
-template <int NCOMP>
+// SemiLagrange<T>, advection.cpp:25-42.  NCOMP scalar planes (1 = Real, 3 = cell-centred Vec3); OS = orderSpace (1 linear, 2 cubic:
+// a kernel of its own, so that the common linear path keeps its registers)
+template <int NCOMP, int OS>
 __global__ void __launch_bounds__(BLOCK)
 k_semi_lagrange(Dim d, const float* __restrict__ vel, float* __restrict__ dst, const float* __restrict__ src, float dt, int orderTrace) {
 	CELL_IJK(d)
@@ -47,13 +48,24 @@ k_semi_lagrange(Dim d, const float* __restrict__ vel, float* __restrict__ dst, c
 		py = cy - uy * dt;
 		pz = cz - uz * dt;
 	}
+	if (OS == 2) {
+#pragma unroll
+		for (int c = 0; c < NCOMP; c++) dst[c * d.n + idx] = interpol_cubic<(NCOMP == 3)>(d, src + c * d.n, px, py, pz);
+		return;
+	}
 	const Bi b = build_index(d, px, py, pz);
 	const int64_t base = (int64_t)b.xi + d.Y * b.yi + d.Z * b.zi;
 #pragma unroll
 	for (int c = 0; c < NCOMP; c++) dst[c * d.n + idx] = tri8(src + c * d.n + base, d.Y, d.Z, b.t0, b.t1, b.s0, b.s1, b.f0, b.f1);
 }
 
+// MACGrid::getInterpolatedComponentHi<C>, grid.h:280-286
+template <int C, int OS>
+__device__ __forceinline__ float mac_component_hi(const Dim& d, const float* __restrict__ src, float x, float y, float z) {
+	return OS == 1 ? interpol1(d, src + (int64_t)C * d.n, x, y, z) : interpol_cubic_mac<C>(d, src, x, y, z);
+}
 // SemiLagrangeMAC, advection.cpp:45-78
+template <int OS>
 __global__ void __launch_bounds__(BLOCK)
 k_semi_lagrange_mac(Dim d, const float* __restrict__ vel, float* __restrict__ dst, const float* __restrict__ src, float dt, int orderTrace) {
 	CELL_IJK(d)
@@ -63,23 +75,23 @@ k_semi_lagrange_mac(Dim d, const float* __restrict__ vel, float* __restrict__ ds
 	float vx, vy, vz, rx, ry, rz;
 	if (orderTrace == 1) {
 		get_at_mac_x(d, vel, idx, vx, vy, vz);
-		rx = interpol1(d, src, cx - vx * dt, cy - vy * dt, cz - vz * dt);
+		rx = mac_component_hi<0, OS>(d, src, cx - vx * dt, cy - vy * dt, cz - vz * dt);
 		get_at_mac_y(d, vel, idx, vx, vy, vz);
-		ry = interpol1(d, src + d.n, cx - vx * dt, cy - vy * dt, cz - vz * dt);
+		ry = mac_component_hi<1, OS>(d, src, cx - vx * dt, cy - vy * dt, cz - vz * dt);
 		get_at_mac_z(d, vel, idx, vx, vy, vz);
-		rz = interpol1(d, src + 2 * d.n, cx - vx * dt, cy - vy * dt, cz - vz * dt);
+		rz = mac_component_hi<2, OS>(d, src, cx - vx * dt, cy - vy * dt, cz - vz * dt);
 	} else {
 		// the midpoint variant traces with `src`, not `vel` (advection.cpp:62-72)
 		float ux, uy, uz;
 		get_at_mac_x(d, src, idx, vx, vy, vz);
 		interpol_mac(d, src, (float)i - (vx * dt) * 0.5f, cy - (vy * dt) * 0.5f, cz - (vz * dt) * 0.5f, ux, uy, uz);
-		rx = interpol1(d, src, cx - ux * dt, cy - uy * dt, cz - uz * dt);
+		rx = mac_component_hi<0, OS>(d, src, cx - ux * dt, cy - uy * dt, cz - uz * dt);
 		get_at_mac_y(d, src, idx, vx, vy, vz);
 		interpol_mac(d, src, cx - (vx * dt) * 0.5f, (float)j - (vy * dt) * 0.5f, cz - (vz * dt) * 0.5f, ux, uy, uz);
-		ry = interpol1(d, src + d.n, cx - ux * dt, cy - uy * dt, cz - uz * dt);
+		ry = mac_component_hi<1, OS>(d, src, cx - ux * dt, cy - uy * dt, cz - uz * dt);
 		get_at_mac_z(d, src, idx, vx, vy, vz);
 		interpol_mac(d, src, cx - (vx * dt) * 0.5f, cy - (vy * dt) * 0.5f, (float)kg - (vz * dt) * 0.5f, ux, uy, uz);
-		rz = interpol1(d, src + 2 * d.n, cx - ux * dt, cy - uy * dt, cz - uz * dt);
+		rz = mac_component_hi<2, OS>(d, src, cx - ux * dt, cy - uy * dt, cz - uz * dt);
 	}
 	dst[idx] = rx;
 	dst[d.n + idx] = ry;
@@ -498,27 +510,42 @@ k_copy_changed_vels(Dim d, const int32_t* __restrict__ flags, const float* __res
 
 extern "C" {
 
-int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt, int orderTrace, void* stream) {
+int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt, int orderTrace, int orderSpace,
+                          void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order %d", orderTrace);
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order %d", orderSpace);
 	const Dim d = mkdim(sx, sy, sz);
-	hipLaunchKernelGGL((k_semi_lagrange<1>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
+	if (orderSpace == 2)
+		hipLaunchKernelGGL((k_semi_lagrange<1, 2>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
+	else
+		hipLaunchKernelGGL((k_semi_lagrange<1, 1>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
 	MF_LAUNCH_CHECK();
 	return 0;
 }
-int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt, int orderTrace, void* stream) {
+int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt, int orderTrace, int orderSpace,
+                          void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order %d", orderTrace);
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order %d", orderSpace);
 	const Dim d = mkdim(sx, sy, sz);
-	hipLaunchKernelGGL((k_semi_lagrange<3>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
+	if (orderSpace == 2)
+		hipLaunchKernelGGL((k_semi_lagrange<3, 2>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
+	else
+		hipLaunchKernelGGL((k_semi_lagrange<3, 1>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
 	MF_LAUNCH_CHECK();
 	return 0;
 }
-int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt, int orderTrace, void* stream) {
+int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt, int orderTrace, int orderSpace,
+                         void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order %d", orderTrace);
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order %d", orderSpace);
 	const Dim d = mkdim(sx, sy, sz);
-	hipLaunchKernelGGL(k_semi_lagrange_mac, dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
+	if (orderSpace == 2)
+		hipLaunchKernelGGL((k_semi_lagrange_mac<2>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
+	else
+		hipLaunchKernelGGL((k_semi_lagrange_mac<1>), dim3(nblk(d)), dim3(BLOCK), 0, (hipStream_t)stream, d, vel, dst, src, dt, orderTrace);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

@@ -242,6 +242,57 @@ __device__ __forceinline__ float interpol1(const Dim& d, const float* __restrict
 	const int64_t idx = (int64_t)b.xi + d.Y * b.yi + d.Z * b.zi;
 	return tri8(data + idx, d.Y, d.Z, b.t0, b.t1, b.s0, b.s1, b.f0, b.f1);
 }
+// ---- cubic interpolation, util/interpolHigh.h (orderSpace = 2 of getInterpolatedHi, grid.h:153-159 / 271-286) -------------------
+// cubicInterp<T> :22-39.  VEC = false: T = Real -- a2 and a3 are double expressions (3.0 * deltak - 2.0 * d0 - d1) rounded once;
+// VEC = true: one component of T = Vec3 -- every scalar * vector product is rounded to fp32 (vectorbase.h:277-284) before the fp32
+// vector sums.  The polynomial is fp32 either way, left to right.
+template <bool VEC>
+__device__ __forceinline__ float cubic_interp(float t, float p0, float p1, float p2, float p3) {
+	const float d0 = (float)((double)(p2 - p0) * 0.5), d1 = (float)((double)(p3 - p1) * 0.5);
+	const float dk = p2 - p1;
+	float a2, a3;
+	if (!VEC) {
+		a2 = (float)(3.0 * (double)dk - 2.0 * (double)d0 - (double)d1);
+		a3 = (float)(-2.0 * (double)dk + (double)d0 + (double)d1);
+	} else {
+		a2 = ((float)(3.0 * (double)dk) - (float)(2.0 * (double)d0)) - d1;
+		a3 = ((float)(-2.0 * (double)dk) + d0) + d1;
+	}
+	const float sq = t * t, cu = sq * t;
+	return a3 * cu + a2 * sq + d0 * t + p1;
+}
+// interpolCubic<T> / interpolCubic2D<T> :42-167 on one scalar plane: 4 x 4 (x 4) points around the cell of pos - 0.5; where that
+// neighbourhood leaves the grid the reference falls back to the linear interpol().  Positions are global (z-slab window).
+template <bool VEC>
+__device__ __forceinline__ float interpol_cubic(const Dim& d, const float* __restrict__ data, float x, float y, float z) {
+	const float px = x - 0.5f, py = y - 0.5f, pz = z - 0.5f;
+	const int x1 = (int)px, y1 = (int)py, z1 = (int)pz;
+	const int x0 = x1 - 1, x3 = x1 + 2, y0 = y1 - 1, y3 = y1 + 2, z0 = z1 - 1, z3 = z1 + 2;
+	if (x0 < 0 || y0 < 0 || x3 >= d.sx || y3 >= d.sy || (d.is3d && (z0 < 0 || z3 >= d.gsz))) return interpol1(d, data, x, y, z);
+	const float xi = px - (float)x1, yi = py - (float)y1, zi = pz - (float)z1;
+	float planes[4];
+	const int nzp = d.is3d ? 4 : 1;
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		if (c < nzp) {
+			const float* base = data + (d.is3d ? d.Z * (int64_t)(z0 + c - d.zoff) : 0) + x0;
+			float rows[4];
+#pragma unroll
+			for (int b = 0; b < 4; b++) {
+				const float* r = base + d.Y * (int64_t)(y0 + b);
+				rows[b] = cubic_interp<VEC>(xi, r[0], r[1], r[2], r[3]);
+			}
+			planes[c] = cubic_interp<VEC>(yi, rows[0], rows[1], rows[2], rows[3]);
+		}
+	}
+	return d.is3d ? cubic_interp<VEC>(zi, planes[0], planes[1], planes[2], planes[3]) : planes[0];
+}
+// interpolCubicMAC :169-176, component C: interpolCubic<Vec3>(pos + 0.5 e_C)[C]; 0 for the z component of a 2-D grid
+template <int C>
+__device__ __forceinline__ float interpol_cubic_mac(const Dim& d, const float* __restrict__ vel, float x, float y, float z) {
+	if (C == 2 && !d.is3d) return 0.f;
+	return interpol_cubic<true>(d, vel + (int64_t)C * d.n, C == 0 ? x + 0.5f : x, C == 1 ? y + 0.5f : y, C == 2 ? z + 0.5f : z);
+}
 // interpolMAC, interpol.h:131-164 (vel is SoA: x plane, y plane, z plane)
 __device__ __forceinline__ void interpol_mac(const Dim& d, const float* __restrict__ vel, float x, float y, float z,
                                              float& ox, float& oy, float& oz) {

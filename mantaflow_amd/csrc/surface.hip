@@ -408,7 +408,7 @@ k_ls_subtract(int64_t n, float* __restrict__ a, const float* __restrict__ b, con
 }
 
 // knInterpolateGridTempl (grid.h:576-581) / KnInterpolateMACGrid (waveletturbulence.cpp:59-71): one thread per target cell
-template <bool MAC>
+template <bool MAC, int OS>
 __global__ void __launch_bounds__(BLOCK)
 k_interpolate_grid(Dim t, float* __restrict__ target, Dim s, const float* __restrict__ source, int ncomp, float sfx, float sfy, float sfz,
                    float ox, float oy, float oz) {
@@ -417,7 +417,12 @@ k_interpolate_grid(Dim t, float* __restrict__ target, Dim s, const float* __rest
 	const int i = (int)(idx % t.sx), j = (int)((idx / t.sx) % t.sy), k = (int)(idx / ((int64_t)t.sx * t.sy));
 	const float px = (float)i * sfx + ox, py = (float)j * sfy + oy;
 	float pz = (float)(k + t.zoff) * sfz + oz;       // global plane of the target cell; the source samplers take global positions
-	if (MAC) {
+	if (MAC && OS == 2) {
+		// getInterpolatedHi(pos - 0.5 e_c, 2)[c] = interpolCubicMAC(..)[c] = interpolCubic<Vec3>((pos - 0.5 e_c) + 0.5 e_c)[c]
+		target[idx] = interpol_cubic_mac<0>(s, source, px - 0.5f, py, pz);
+		target[t.n + idx] = interpol_cubic_mac<1>(s, source, px, py - 0.5f, pz);
+		target[2 * t.n + idx] = s.is3d ? interpol_cubic_mac<2>(s, source, px, py, pz - 0.5f) : 0.f;
+	} else if (MAC) {
 		// MACGrid::getInterpolatedHi -> interpolMAC (grid.h:269-275); one component of each evaluation is kept
 		float vx, vy, vz;
 		interpol_mac(s, source, px - 0.5f, py, pz, vx, vy, vz);
@@ -432,28 +437,39 @@ k_interpolate_grid(Dim t, float* __restrict__ target, Dim s, const float* __rest
 		}
 	} else {
 		if (!s.is3d) pz = 0.f;
-		for (int c = 0; c < ncomp; c++) target[c * t.n + idx] = interpol1(s, source + c * s.n, px, py, pz);
+		for (int c = 0; c < ncomp; c++) {
+			if (OS == 2) target[c * t.n + idx] = (ncomp == 3) ? interpol_cubic<true>(s, source + c * s.n, px, py, pz) : interpol_cubic<false>(s, source + c * s.n, px, py, pz);
+			else target[c * t.n + idx] = interpol1(s, source + c * s.n, px, py, pz);
+		}
 	}
 }
 
 extern "C" {
 
 int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
-                        float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream) {
+                        float sfx, float sfy, float sfz, float ox, float oy, float oz, int orderSpace, void* stream) {
 	MF_TRY(check_dim(tsx, tsy, tsz));
 	MF_TRY(check_dim(ssx, ssy, ssz));
 	if (ncomp != 1 && ncomp != 3) return fail("ncomp must be 1 or 3");
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order %d", orderSpace);
 	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz);   // each grid under its own slab window
-	hipLaunchKernelGGL((k_interpolate_grid<false>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, ncomp, sfx, sfy, sfz, ox, oy, oz);
+	if (orderSpace == 2)
+		hipLaunchKernelGGL((k_interpolate_grid<false, 2>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, ncomp, sfx, sfy, sfz, ox, oy, oz);
+	else
+		hipLaunchKernelGGL((k_interpolate_grid<false, 1>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, ncomp, sfx, sfy, sfz, ox, oy, oz);
 	MF_LAUNCH_CHECK();
 	return 0;
 }
 int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
-                            float sfx, float sfy, float sfz, float ox, float oy, float oz, void* stream) {
+                            float sfx, float sfy, float sfz, float ox, float oy, float oz, int orderSpace, void* stream) {
 	MF_TRY(check_dim(tsx, tsy, tsz));
 	MF_TRY(check_dim(ssx, ssy, ssz));
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order %d", orderSpace);
 	const Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz);   // each grid under its own slab window
-	hipLaunchKernelGGL((k_interpolate_grid<true>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, 3, sfx, sfy, sfz, ox, oy, oz);
+	if (orderSpace == 2)
+		hipLaunchKernelGGL((k_interpolate_grid<true, 2>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, 3, sfx, sfy, sfz, ox, oy, oz);
+	else
+		hipLaunchKernelGGL((k_interpolate_grid<true, 1>), dim3(nblk_n(t.n)), dim3(BLOCK), 0, (hipStream_t)stream, t, target, s, source, 3, sfx, sfy, sfz, ox, oy, oz);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

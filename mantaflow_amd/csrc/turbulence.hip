@@ -263,7 +263,8 @@ __device__ void noise_evaluate_vec(const NoiseParams& P, const float* __restrict
 // knApplyNoiseVec3, waveletturbulence.cpp:120-154 (uv == NULL)
 __global__ void __launch_bounds__(BLOCK)
 k_apply_noise_vec3(Dim d, const int32_t* __restrict__ flags, float* __restrict__ target, const float* __restrict__ tile, NoiseParams P,
-                   float scale, float scaleSpatial, const float* __restrict__ weight, Dim wd, int interp, float sf0, float sf1, float sf2) {
+                   float scale, float scaleSpatial, const float* __restrict__ weight, Dim wd, int interp, float sf0, float sf1, float sf2,
+                   const float* __restrict__ uv) {
 	CELL_IJK(d)
 	if (!(flags[idx] & MF_FLUID)) return;
 	float w = 1;
@@ -272,6 +273,18 @@ k_apply_noise_vec3(Dim d, const int32_t* __restrict__ flags, float* __restrict__
 		else w = interpol1(wd, weight, (float)i * sf0, (float)j * sf1, (float)(k + d.zoff) * sf2);
 	}
 	float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)(k + d.zoff) + 0.5f};   // global cell centre (z-slab window)
+	if (uv) {
+		if (!interp) {
+#pragma unroll
+			for (int c = 0; c < 3; c++) pos[c] = uv[c * d.n + idx];
+		} else {
+			// uv->getInterpolated(Vec3(i,j,k) * sourceFactor), then pos /= sourceFactor (uv coordinates are in the uv grid's space)
+			const float sfv[3] = {sf0, sf1, sf2};
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+				pos[c] = interpol1(wd, uv + c * wd.n, (float)i * sf0, (float)j * sf1, (float)(k + d.zoff) * sf2) / sfv[c];
+		}
+	}
 #pragma unroll
 	for (int c = 0; c < 3; c++) pos[c] *= scaleSpatial;
 	float d0[3], d1[3], d2[3];
@@ -330,13 +343,20 @@ int mf_compute_wavelet_coeffs(int sx, int sy, int sz, float* input, float* temp1
 }
 
 int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* target, const float* tile, const float* params,
-                        float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, void* stream) {
+                        float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, const float* uv, int usx, int usy,
+                        int usz, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	Dim wd = d;
 	int interp = 0;
 	float sf[3] = {1.f, 1.f, 1.f};
-	if (weight) {
+	if (uv && weight && (usx != wsx || usy != wsy || usz != wsz)) return fail("UV and weight grid have to match!");
+	if (uv && !weight) {      // the size of the uv grid decides (waveletturbulence.cpp:161-166)
+		wsx = usx;
+		wsy = usy;
+		wsz = usz;
+	}
+	if (weight || uv) {
 		MF_TRY(check_dim(wsx, wsy, wsz));
 		wd = mkdim_src(wsx, wsy, wsz);       // a weight grid of another size lives under its own (source) slab window
 		interp = (wd.gsz != d.gsz || wsx != sx || wsy != sy);
@@ -358,7 +378,7 @@ int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* tar
 	P.clamp = params[15];
 	P.clampNeg = params[16];
 	P.clampPos = params[17];
-	hipLaunchKernelGGL(k_apply_noise_vec3, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, target, tile, P, scale, scaleSpatial, weight, wd, interp, sf[0], sf[1], sf[2]);
+	hipLaunchKernelGGL(k_apply_noise_vec3, dim3(nblk_n(d.n)), dim3(BLOCK), 0, (hipStream_t)stream, d, flags, target, tile, P, scale, scaleSpatial, weight, wd, interp, sf[0], sf[1], sf[2], uv);
 	MF_LAUNCH_CHECK();
 	return 0;
 }

@@ -118,9 +118,8 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
     _chk(grid, GridBase, "GridBase")
     if order not in (1, 2):
         raise RuntimeError("AdvectSemiLagrange: Only order 1 (regular SL) and 2 (MacCormack) supported")
-    if orderSpace != 1:
-        raise RuntimeError("advectSemiLagrange: orderSpace=2 (cubic interpolation, util/interpolHigh.h) is outside the "
-                           "MI355X hot path (SURVEY 2.4)")
+    if orderSpace not in (1, 2):
+        raise RuntimeError("Unknown interpolation order %s" % orderSpace)      # getInterpolatedHi, grid.h:157
     s = flags.parent
     lib, st = s.lib, s.stream
     sx, sy, sz = flags.dims
@@ -129,13 +128,13 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
     if t & GridBase.TypeMAC:
         # fnAdvectSemiLagrange<MACGrid>, advection.cpp:407-437
         fwd = MACGrid(s)
-        lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), st)
+        lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), int(orderSpace), st)
         if order == 1:
             _apply_outflow_bc(flags, fwd, grid, dt)
             grid.swap(fwd)
         else:
             bwd, newg = MACGrid(s), MACGrid(s)
-            lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), st)
+            lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), int(orderSpace), st)
             # MacCormackCorrectMAC + MacCormackClampMAC, fused (the clamp reads the corrected value of its own cell only)
             lib.call("mf_maccormack_correct_clamp_mac", sx, sy, sz, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength),
                      dt, int(clampMode), st)
@@ -147,12 +146,12 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
         G = type(grid)
         sl = "mf_semi_lagrange_real" if ncomp == 1 else "mf_semi_lagrange_vec3"
         fwd = G(s)
-        lib.call(sl, sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), st)
+        lib.call(sl, sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), int(orderSpace), st)
         if order == 1:
             grid.swap(fwd)
         else:
             bwd, newg = G(s), G(s)
-            lib.call(sl, sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), st)
+            lib.call(sl, sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), int(orderSpace), st)
             lib.call("mf_maccormack_correct_clamp", sx, sy, sz, ncomp, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr,
                      float(strength), dt, int(clampMode), st)
             grid.swap(newg)
@@ -603,12 +602,12 @@ def _size_factor(source, target, scale, offset, size):
 
 
 def _interpolate(target, source, scale, offset, size, orderSpace, ncomp):
-    if int(orderSpace) != 1:
-        raise RuntimeError("interpolateGrid: orderSpace=2 (cubic) is outside the hot path")
+    if int(orderSpace) not in (1, 2):
+        raise RuntimeError("Unknown interpolation order %s" % orderSpace)
     sf, off = _size_factor(source, target, scale, offset, size)
     s = target.parent
     s.lib.call2(source.parent, "mf_interpolate_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz, source.ptr,
-               ncomp, sf[0], sf[1], sf[2], off[0], off[1], off[2], s.stream)
+               ncomp, sf[0], sf[1], sf[2], off[0], off[1], off[2], int(orderSpace), s.stream)
 
 
 @plugin
@@ -626,12 +625,12 @@ def interpolateGridVec3(target, source, scale=vec3(1.), offset=vec3(0.), size=No
 @plugin
 def interpolateMACGrid(target, source, scale=vec3(1.), offset=vec3(0.), size=None, orderSpace=1):
     _chk(target, MACGrid, "MACGrid"); _chk(source, MACGrid, "MACGrid")
-    if int(orderSpace) != 1:
-        raise RuntimeError("interpolateMACGrid: orderSpace=2 (cubic) is outside the hot path")
+    if int(orderSpace) not in (1, 2):
+        raise RuntimeError("Unknown interpolation order %s" % orderSpace)
     sf, off = _size_factor(source, target, scale, offset, size)
     s = target.parent
     s.lib.call2(source.parent, "mf_interpolate_mac_grid", target.sx, target.sy, target.sz, target.ptr, source.sx, source.sy, source.sz,
-               source.ptr, sf[0], sf[1], sf[2], off[0], off[1], off[2], s.stream)
+               source.ptr, sf[0], sf[1], sf[2], off[0], off[1], off[2], int(orderSpace), s.stream)
 
 
 # =========================================================================================================
@@ -667,15 +666,18 @@ def vorticityConfinement(vel, flags, strength=0., strengthCell=None):
 
 @plugin
 def applyNoiseVec3(flags, target, noise, scale=1.0, scaleSpatial=1.0, weight=None, uv=None):
-    """waveletturbulence.cpp:120-178 (weight grid of any size; the uv variant is outside the hot path)"""
+    """waveletturbulence.cpp:120-178 (weight and uv grids of any size: sampled with getInterpolated when it differs from the target's)"""
     _chk(flags, FlagGrid, "FlagGrid"); _chk(target, VecGrid, "Grid<Vec3>")
-    if uv is not None:
-        raise RuntimeError("applyNoiseVec3: the uv-grid variant is outside the hot path")
     weight = _opt(weight, Grid, "Grid<Real>")
+    uv = _opt(uv, VecGrid, "Grid<Vec3>")
+    if uv is not None and weight is not None and uv.dims != weight.dims:
+        raise RuntimeError("UV and weight grid have to match!")
     s = flags.parent
     w = (None, 0, 0, 0) if weight is None else (weight.ptr, weight.sx, weight.sy, weight.sz)
-    s.lib.call2(s if weight is None else weight.parent, "mf_apply_noise_vec3", flags.sx, flags.sy, flags.sz, flags.ptr, target.ptr,
-                _ptr(noise._tile), noise._params(), float(scale), float(scaleSpatial), w[0], w[1], w[2], w[3], s.stream)
+    u = (None, 0, 0, 0) if uv is None else (uv.ptr, uv.sx, uv.sy, uv.sz)
+    src = uv.parent if uv is not None else (s if weight is None else weight.parent)
+    s.lib.call2(src, "mf_apply_noise_vec3", flags.sx, flags.sy, flags.sz, flags.ptr, target.ptr, _ptr(noise._tile), noise._params(),
+                float(scale), float(scaleSpatial), w[0], w[1], w[2], w[3], u[0], u[1], u[2], u[3], s.stream)
 
 
 @plugin

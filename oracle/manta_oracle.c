@@ -792,6 +792,51 @@ static inline float interpol1(const Dim* d, const float* data, float x, float y,
 	return ((data[idx] * b.t0 + data[idx + Y] * b.t1) * b.s0 + (data[idx + X] * b.t0 + data[idx + X + Y] * b.t1) * b.s1) * b.f0 +
 	       ((data[idx + Z] * b.t0 + data[idx + Y + Z] * b.t1) * b.s0 + (data[idx + X + Z] * b.t0 + data[idx + X + Y + Z] * b.t1) * b.s1) * b.f1;
 }
+/* ---- cubic interpolation, util/interpolHigh.h ------------------------------------------------------------------
+ * cubicInterp<T> :22-39.  vec = 0: T = Real -- a2 and a3 are double expressions (3.0 * deltak - 2.0 * d0 - d1) rounded once;
+ * vec = 1: one component of T = Vec3 -- every scalar * vector product is rounded to fp32 (vectorbase.h:277-284) before the fp32
+ * vector sums.  The polynomial itself is fp32 either way, left to right. */
+static inline float cubic_interp(float t, const float p[4], int vec) {
+	const float d0 = (float)((double)(p[2] - p[0]) * 0.5), d1 = (float)((double)(p[3] - p[1]) * 0.5);
+	const float dk = p[2] - p[1];
+	float a2, a3;
+	if (!vec) {
+		a2 = (float)(3.0 * (double)dk - 2.0 * (double)d0 - (double)d1);
+		a3 = (float)(-2.0 * (double)dk + (double)d0 + (double)d1);
+	} else {
+		a2 = ((float)(3.0 * (double)dk) - (float)(2.0 * (double)d0)) - d1;
+		a3 = ((float)(-2.0 * (double)dk) + d0) + d1;
+	}
+	const float sq = t * t, cu = sq * t;
+	return a3 * cu + a2 * sq + d0 * t + p[1];
+}
+/* interpolCubic<T> / interpolCubic2D<T> :42-167 on one scalar plane: 4 x 4 (x 4) points around the cell of pos - 0.5; where that
+ * neighbourhood leaves the grid the reference falls back to the linear interpol().  Positions are global (z-slab window). */
+static inline float interpol_cubic(const Dim* d, const float* data, float x, float y, float z, int vec) {
+	const float px = x - 0.5f, py = y - 0.5f, pz = z - 0.5f;
+	const int x1 = (int)px, y1 = (int)py, z1 = (int)pz;
+	const int x0 = x1 - 1, x3 = x1 + 2, y0 = y1 - 1, y3 = y1 + 2, z0 = z1 - 1, z3 = z1 + 2;
+	if (x0 < 0 || y0 < 0 || x3 >= d->sx || y3 >= d->sy || (d->is3d && (z0 < 0 || z3 >= d->gsz))) return interpol1(d, data, x, y, d->is3d ? z : z);
+	const float xi = px - (float)x1, yi = py - (float)y1, zi = pz - (float)z1;
+	float planes[4];
+	const int nzp = d->is3d ? 4 : 1;
+	for (int c = 0; c < nzp; c++) {
+		const int64_t zb = d->is3d ? d->Z * (int64_t)(z0 + c - d->zoff) : 0;
+		float rows[4];
+		for (int b = 0; b < 4; b++) {
+			const float* r = data + zb + d->Y * (int64_t)(y0 + b) + x0;
+			const float q[4] = {r[0], r[1], r[2], r[3]};
+			rows[b] = cubic_interp(xi, q, vec);
+		}
+		planes[c] = cubic_interp(yi, rows, vec);
+	}
+	return d->is3d ? cubic_interp(zi, planes, vec) : planes[0];
+}
+/* interpolCubicMAC :169-176, component c: interpolCubic<Vec3>(pos + 0.5 e_c)[c]; 0 for the z component of a 2-D grid */
+static inline float interpol_cubic_mac(const Dim* d, const float* vel, int c, float x, float y, float z) {
+	if (c == 2 && !d->is3d) return 0.f;
+	return interpol_cubic(d, vel + (int64_t)c * d->n, c == 0 ? x + 0.5f : x, c == 1 ? y + 0.5f : y, c == 2 ? z + 0.5f : z, 1);
+}
 /* interpolMAC, interpol.h:131-164 */
 static inline void interpol_mac(const Dim* d, const float* vel, float x, float y, float z, float out[3]) {
 	Bi b = build_index(d, x, y, z), s = build_index_shift(d, x, y, z);
@@ -849,9 +894,10 @@ static inline void get_at_mac_z(const Dim* d, const float* vel, int64_t idx, flo
  * ============================================================================================== */
 /* SemiLagrange<T>, advection.cpp:25-42; ncomp scalar planes of `src` (1 = Real, 3 = centred Vec3) */
 static int semi_lagrange(int sx, int sy, int sz, int ncomp, const float* vel, float* dst, const float* src, float dt,
-                         int orderTrace) {
+                         int orderTrace, int orderSpace) {
 	Dim d = mkdim(sx, sy, sz);
 	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order");
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order");
 #pragma omp parallel for
 	for (int k = K0(d, 1); k < K1(d, 1); k++)
 		for (int j = 1; j < sy - 1; j++)
@@ -874,27 +920,34 @@ static int semi_lagrange(int sx, int sy, int sz, int ncomp, const float* vel, fl
 					py = (j + 0.5f) - u[1] * dt;
 					pz = (kg + 0.5f) - u[2] * dt;
 				}
-				for (int c = 0; c < ncomp; c++) dst[c * d.n + idx] = interpol1(&d, src + c * d.n, px, py, pz);
+				for (int c = 0; c < ncomp; c++)
+					dst[c * d.n + idx] = orderSpace == 1 ? interpol1(&d, src + c * d.n, px, py, pz)
+					                                     : interpol_cubic(&d, src + c * d.n, px, py, pz, ncomp == 3);   /* getInterpolatedHi, grid.h:153-159 */
 			}
 	return 0;
 }
 int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
-                          int orderTrace, void* st) {
+                          int orderTrace, int orderSpace, void* st) {
 	(void)st;
-	return semi_lagrange(sx, sy, sz, 1, vel, dst, src, dt, orderTrace);
+	return semi_lagrange(sx, sy, sz, 1, vel, dst, src, dt, orderTrace, orderSpace);
 }
 int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
-                          int orderTrace, void* st) {
+                          int orderTrace, int orderSpace, void* st) {
 	(void)st;
-	return semi_lagrange(sx, sy, sz, 3, vel, dst, src, dt, orderTrace);
+	return semi_lagrange(sx, sy, sz, 3, vel, dst, src, dt, orderTrace, orderSpace);
 }
 /* SemiLagrangeMAC, advection.cpp:45-78 */
+/* MACGrid::getInterpolatedComponentHi<c>, grid.h:280-286 */
+static inline float mac_component_hi(const Dim* d, const float* src, int c, float x, float y, float z, int orderSpace) {
+	return orderSpace == 1 ? interpol1(d, src + (int64_t)c * d->n, x, y, z) : interpol_cubic_mac(d, src, c, x, y, z);
+}
 int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
-                         int orderTrace, void* st) {
+                         int orderTrace, int orderSpace, void* st) {
 	(void)st;
 	Dim d = mkdim(sx, sy, sz);
 	const int64_t n = d.n;
 	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order");
+	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order");
 #pragma omp parallel for
 	for (int k = K0(d, 1); k < K1(d, 1); k++)
 		for (int j = 1; j < sy - 1; j++)
@@ -904,26 +957,26 @@ int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, c
 				float v[3], r[3];
 				if (orderTrace == 1) {
 					get_at_mac_x(&d, vel, idx, v);
-					r[0] = interpol1(&d, src, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt);
+					r[0] = mac_component_hi(&d, src, 0, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt, orderSpace);
 					get_at_mac_y(&d, vel, idx, v);
-					r[1] = interpol1(&d, src + n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt);
+					r[1] = mac_component_hi(&d, src, 1, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt, orderSpace);
 					get_at_mac_z(&d, vel, idx, v);
-					r[2] = interpol1(&d, src + 2 * n, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt);
+					r[2] = mac_component_hi(&d, src, 2, (i + 0.5f) - v[0] * dt, (j + 0.5f) - v[1] * dt, (kg + 0.5f) - v[2] * dt, orderSpace);
 				} else {
 					float u[3];
 					const float p0x = (float)(i + 0.5), p0y = (float)(j + 0.5), p0z = (float)(kg + 0.5);
 					get_at_mac_x(&d, src, idx, v);
 					interpol_mac(&d, src, (float)i - (float)((v[0] * dt) * 0.5), (j + 0.5f) - (float)((v[1] * dt) * 0.5),
 					             (kg + 0.5f) - (float)((v[2] * dt) * 0.5), u);
-					r[0] = interpol1(&d, src, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
+					r[0] = mac_component_hi(&d, src, 0, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt, orderSpace);
 					get_at_mac_y(&d, src, idx, v);
 					interpol_mac(&d, src, (i + 0.5f) - (float)((v[0] * dt) * 0.5), (float)j - (float)((v[1] * dt) * 0.5),
 					             (kg + 0.5f) - (float)((v[2] * dt) * 0.5), u);
-					r[1] = interpol1(&d, src + n, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
+					r[1] = mac_component_hi(&d, src, 1, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt, orderSpace);
 					get_at_mac_z(&d, src, idx, v);
 					interpol_mac(&d, src, (i + 0.5f) - (float)((v[0] * dt) * 0.5), (j + 0.5f) - (float)((v[1] * dt) * 0.5),
 					             (float)kg - (float)((v[2] * dt) * 0.5), u);
-					r[2] = interpol1(&d, src + 2 * n, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt);
+					r[2] = mac_component_hi(&d, src, 2, p0x - u[0] * dt, p0y - u[1] * dt, p0z - u[2] * dt, orderSpace);
 				}
 				dst[idx] = r[0];
 				dst[n + idx] = r[1];
@@ -2364,7 +2417,7 @@ int mf_levelset_subtract(int64_t n, float* phi, const float* other, const int32_
 
 /* knInterpolateGridTempl, grid.h:576-581 */
 int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source, int ncomp,
-                        float sfx, float sfy, float sfz, float ox, float oy, float oz, void* st) {
+                        float sfx, float sfy, float sfz, float ox, float oy, float oz, int orderSpace, void* st) {
 	(void)st;
 	Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz); /* each grid under its own slab window */
 	for (int k = 0; k < tsz; k++)
@@ -2372,13 +2425,15 @@ int mf_interpolate_grid(int tsx, int tsy, int tsz, float* target, int ssx, int s
 			for (int i = 0; i < tsx; i++) {
 				float px = (float)i * sfx + ox, py = (float)j * sfy + oy, pz = (float)(k + t.zoff) * sfz + oz; /* global plane */
 				if (!s.is3d) pz = 0.f;
-				for (int c = 0; c < ncomp; c++) target[c * t.n + IDX(t, i, j, k)] = interpol1(&s, source + c * s.n, px, py, pz);
+				for (int c = 0; c < ncomp; c++)
+					target[c * t.n + IDX(t, i, j, k)] = orderSpace == 1 ? interpol1(&s, source + c * s.n, px, py, pz)
+					                                                    : interpol_cubic(&s, source + c * s.n, px, py, pz, ncomp == 3);
 			}
 	return 0;
 }
 /* KnInterpolateMACGrid, plugin/waveletturbulence.cpp:59-71 */
 int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
-                            float sfx, float sfy, float sfz, float ox, float oy, float oz, void* st) {
+                            float sfx, float sfy, float sfz, float ox, float oy, float oz, int orderSpace, void* st) {
 	(void)st;
 	Dim t = mkdim(tsx, tsy, tsz), s = mkdim_src(ssx, ssy, ssz); /* each grid under its own slab window */
 	for (int k = 0; k < tsz; k++)
@@ -2388,6 +2443,13 @@ int mf_interpolate_mac_grid(int tsx, int tsy, int tsz, float* target, int ssx, i
 				const int64_t idx = IDX(t, i, j, k);
 				/* MACGrid::getInterpolatedHi -> interpolMAC (grid.h:269-275), one component of each evaluation is kept */
 				float v[3];
+				if (orderSpace == 2) {
+					/* getInterpolatedHi(pos - 0.5 e_c, 2)[c] = interpolCubicMAC(...)[c] = interpolCubic<Vec3>((pos - 0.5 e_c) + 0.5 e_c)[c] */
+					target[idx] = interpol_cubic_mac(&s, source, 0, px - 0.5f, py, pz);
+					target[t.n + idx] = interpol_cubic_mac(&s, source, 1, px, py - 0.5f, pz);
+					target[2 * t.n + idx] = s.is3d ? interpol_cubic_mac(&s, source, 2, px, py, pz - 0.5f) : 0.f;
+					continue;
+				}
 				interpol_mac(&s, source, px - 0.5f, py, pz, v);
 				target[idx] = v[0];
 				interpol_mac(&s, source, px, py - 0.5f, pz, v);
@@ -2811,12 +2873,20 @@ static void noise_evaluate_vec(const float* P, const float* tile, float x, float
 }
 /* knApplyNoiseVec3, waveletturbulence.cpp:120-154 (uv == NULL) */
 int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* target, const float* tile, const float* P,
-                        float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, void* st) {
+                        float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, const float* uv, int usx, int usy,
+                        int usz, void* st) {
 	(void)st;
 	Dim d = mkdim(sx, sy, sz);
-	Dim wd = weight ? mkdim_src(wsx, wsy, wsz) : d; /* a weight grid of another size lives under its own (source) slab window */
-	const int interp = weight && (wd.gsz != d.gsz || wsx != sx || wsy != sy);
-	if (weight && !interp && (wsz != sz || wd.zoff != d.zoff)) return fail("applyNoiseVec3: weight grid of the same resolution must share the target's slab window");
+	if (uv && weight && (usx != wsx || usy != wsy || usz != wsz)) return fail("UV and weight grid have to match!");
+	if (uv && !weight) { /* the size of the uv grid decides, waveletturbulence.cpp:161-166 */
+		wsx = usx;
+		wsy = usy;
+		wsz = usz;
+	}
+	const int two = weight || uv;
+	Dim wd = two ? mkdim_src(wsx, wsy, wsz) : d; /* a weight / uv grid of another size lives under its own (source) slab window */
+	const int interp = two && (wd.gsz != d.gsz || wsx != sx || wsy != sy);
+	if (two && !interp && (wsz != sz || wd.zoff != d.zoff)) return fail("applyNoiseVec3: weight grid of the same resolution must share the target's slab window");
 	const float sf[3] = {(float)wsx / sx, (float)wsy / sy, (float)wd.gsz / d.gsz};   /* calcGridSizeFactor, grid.h:391-393 (whole-domain sizes) */
 	for (int k = 0; k < sz; k++)
 		for (int j = 0; j < sy; j++)
@@ -2829,6 +2899,14 @@ int mf_apply_noise_vec3(int sx, int sy, int sz, const int32_t* flags, float* tar
 					else w = interpol1(&wd, weight, (float)i * sf[0], (float)j * sf[1], (float)(k + d.zoff) * sf[2]);
 				}
 				float pos[3] = {(float)i + 0.5f, (float)j + 0.5f, (float)(k + d.zoff) + 0.5f}; /* global cell centre */
+				if (uv) { /* waveletturbulence.cpp:139-147 */
+					if (!interp) {
+						for (int c = 0; c < 3; c++) pos[c] = uv[c * d.n + idx];
+					} else {
+						for (int c = 0; c < 3; c++)
+							pos[c] = interpol1(&wd, uv + c * wd.n, (float)i * sf[0], (float)j * sf[1], (float)(k + d.zoff) * sf[2]) / sf[c];
+					}
+				}
 				for (int c = 0; c < 3; c++) pos[c] *= scaleSpatial;
 				float d0[3], d1[3], d2[3];
 				noise_evaluate_vec(P, tile, pos[0], pos[1], pos[2], 0, d0);

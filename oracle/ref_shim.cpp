@@ -865,20 +865,20 @@ int ref_grid_file(int sx, int sy, int sz, int kind, int write, const char* name,
 
 /* interpolateGrid / interpolateGridVec3 / interpolateMACGrid, plugin/waveletturbulence.cpp:37-78.  kind 0 Real, 1 Vec3, 2 MAC */
 int ref_interpolate_grid(int kind, int tsx, int tsy, int tsz, float* target, int ssx, int ssy, int ssz, const float* source,
-                         float scx, float scy, float scz, float ox, float oy, float oz, int zx, int zy, int zz) {
+                         float scx, float scy, float scz, float ox, float oy, float oz, int zx, int zy, int zz, int orderSpace) {
 	SHIM_TRY
 	Ctx ct(tsx, tsy, tsz, 1.f), cs(ssx, ssy, ssz, 1.f);
 	const Vec3 scale(scx, scy, scz), off(ox, oy, oz);
 	const Vec3i size(zx, zy, zz);
 	if (kind == 0) {
 		RealRef t(ct, target), s(cs, source);
-		interpolateGrid(t.ref(), s.ref(), scale, off, size, 1);
+		interpolateGrid(t.ref(), s.ref(), scale, off, size, orderSpace);
 	} else if (kind == 1) {
 		Vec3IO t(ct, target, true), s(cs, source, false);
-		interpolateGridVec3(t.g, s.g, scale, off, size, 1);
+		interpolateGridVec3(t.g, s.g, scale, off, size, orderSpace);
 	} else {
 		MacIO t(ct, target, true), s(cs, source, false);
-		interpolateMACGrid(t.g, s.g, scale, off, size, 1);
+		interpolateMACGrid(t.g, s.g, scale, off, size, orderSpace);
 	}
 	SHIM_CATCH
 }
@@ -1142,7 +1142,7 @@ int ref_set_open_bound(int sx, int sy, int sz, int32_t* flags, int bWidth, const
 }
 /* P as in ref_density_inflow; weight grid of size (wsx, wsy, wsz), nullable */
 int ref_apply_noise_vec3(int sx, int sy, int sz, float timeTotal, const int32_t* flags, float* target, int fixedSeed, const float* P,
-                         float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz) {
+                         float scale, float scaleSpatial, const float* weight, int wsx, int wsy, int wsz, const float* uv) {
 	SHIM_TRY
 	Ctx c(sx, sy, sz, 1.f);
 	c.solver.mTimeTotal = timeTotal;
@@ -1159,11 +1159,11 @@ int ref_apply_noise_vec3(int sx, int sy, int sz, float timeTotal, const int32_t*
 	nf.mTimeAnim = P[11];
 	std::unique_ptr<Ctx> cw;
 	std::unique_ptr<RealRef> w;
-	if (weight) {
-		cw.reset(new Ctx(wsx, wsy, wsz, 1.f));
-		w.reset(new RealRef(*cw, weight));
-	}
-	applyNoiseVec3(fl, t.g, nf, scale, scaleSpatial, w ? w->ptr() : nullptr, nullptr);
+	std::unique_ptr<Vec3IO> u;      /* the uv grid has the size (wsx, wsy, wsz) as well (the plugin asserts it) */
+	if (weight || uv) cw.reset(new Ctx(wsx, wsy, wsz, 1.f));
+	if (weight) w.reset(new RealRef(*cw, weight));
+	if (uv) u.reset(new Vec3IO(*cw, uv, false));
+	applyNoiseVec3(fl, t.g, nf, scale, scaleSpatial, w ? w->ptr() : nullptr, u ? &u->g : nullptr);
 	SHIM_CATCH
 }
 

@@ -809,10 +809,10 @@ INTERP_CASES = [  # (source dims, target dims, scale, offset, size)
 ]
 
 
-def run_interp_pkg(sd, td, scale, offset, size, fields):
+def run_interp_pkg(sd, td, scale, offset, size, fields, orderSpace=1):
     from mantaflow_amd import core, plugins
     ss, ts = _mk_solver(sd), _mk_solver(td)
-    kw = dict(scale=core.vec3(*scale), offset=core.vec3(*offset))
+    kw = dict(scale=core.vec3(*scale), offset=core.vec3(*offset), orderSpace=orderSpace)
     if size is not None:
         kw["size"] = size
     out = {}
@@ -829,7 +829,7 @@ def run_interp_pkg(sd, td, scale, offset, size, fields):
     return out
 
 
-def run_interp_ref(sd, td, scale, offset, size, fields):
+def run_interp_ref(sd, td, scale, offset, size, fields, orderSpace=1):
     cf = ctypes.c_float
     zs = size if size is not None else (-1, -1, -1)
     out = {}
@@ -837,7 +837,7 @@ def run_interp_ref(sd, td, scale, offset, size, fields):
         shape = (td[2], td[1], td[0]) if kind == 0 else (3, td[2], td[1], td[0])
         t = np.zeros(shape, np.float32)
         refcall("ref_interpolate_grid", kind, td[0], td[1], td[2], t, sd[0], sd[1], sd[2], src, cf(scale[0]), cf(scale[1]), cf(scale[2]),
-                cf(offset[0]), cf(offset[1]), cf(offset[2]), zs[0], zs[1], zs[2])
+                cf(offset[0]), cf(offset[1]), cf(offset[2]), zs[0], zs[1], zs[2], int(orderSpace))
         out[key] = t
     return out
 
@@ -998,7 +998,31 @@ def run_turb_pkg(dims, flags, vel, energy_in, weight_small, small_dims, t_total=
     t = soa_to_grid(core.VecGrid(s), vel)
     plugins.applyNoiseVec3(flags=fl, target=t, noise=noise)
     out["noise_plain"] = grid_to_soa(t)
+    # uv variant (waveletturbulence.cpp:139-147): positions from a uv grid of the same size (+ weight), and of another size (interpolated)
+    uv_same, uv_small = turb_uv(dims, small_dims)
+    t = soa_to_grid(core.VecGrid(s), vel)
+    plugins.applyNoiseVec3(flags=fl, target=t, noise=noise, scale=0.4, weight=w, uv=soa_to_grid(core.VecGrid(s), uv_same))
+    out["noise_uv_same"] = grid_to_soa(t)
+    t = soa_to_grid(core.VecGrid(s), vel)
+    plugins.applyNoiseVec3(flags=fl, target=t, noise=noise, scale=0.3, scaleSpatial=1.25, weight=soa_to_grid(core.Grid(ss), weight_small),
+                           uv=soa_to_grid(core.VecGrid(ss), uv_small))
+    out["noise_uv_interp"] = grid_to_soa(t)
+    t = soa_to_grid(core.VecGrid(s), vel)
+    plugins.applyNoiseVec3(flags=fl, target=t, noise=noise, uv=soa_to_grid(core.VecGrid(ss), uv_small))
+    out["noise_uv_only"] = grid_to_soa(t)
     s.sync()
+    return out
+
+
+def turb_uv(dims, small_dims):
+    """uv grids for applyNoiseVec3: advected-texture-like coordinates (cell centres + a smooth displacement) at both sizes"""
+    out = []
+    for dd, seed in ((dims, 81), (small_dims, 82)):
+        sx, sy, sz = dd
+        zz, yy, xx = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+        disp = util.smooth_vel(sx, sy, sz, seed, 1.5)
+        uv = np.stack([xx + 0.5, yy + 0.5, zz + 0.5]).astype(np.float32) + disp
+        out.append(np.ascontiguousarray(uv.astype(np.float32)))
     return out
 
 
@@ -1027,14 +1051,24 @@ def run_turb_ref(dims, flags, vel, energy_in, weight_small, small_dims, t_total=
     ps = np.float32(int(1.0 * dims[0])) * np.float32(0.5)
     P = np.array([ps, ps, ps, 0, 0, 0, 0.0, 1.0, 0, 0, 1, 0.1], np.float32)
     t = vel.copy()
-    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.4), cf(1.0), w, sx, sy, sz)
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.4), cf(1.0), w, sx, sy, sz, None)
     out["noise_same"] = t
     t = vel.copy()
-    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.24), cf(1.5), weight_small, small_dims[0], small_dims[1], small_dims[2])
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.24), cf(1.5), weight_small, small_dims[0], small_dims[1], small_dims[2], None)
     out["noise_interp"] = t
     t = vel.copy()
-    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(1.0), cf(1.0), None, 0, 0, 0)
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(1.0), cf(1.0), None, 0, 0, 0, None)
     out["noise_plain"] = t
+    uv_same, uv_small = turb_uv(dims, small_dims)
+    t = vel.copy()
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.4), cf(1.0), w, sx, sy, sz, uv_same)
+    out["noise_uv_same"] = t
+    t = vel.copy()
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(0.3), cf(1.25), weight_small, small_dims[0], small_dims[1], small_dims[2], uv_small)
+    out["noise_uv_interp"] = t
+    t = vel.copy()
+    refcall("ref_apply_noise_vec3", sx, sy, sz, cf(t_total), flags, t, -1, P, cf(1.0), cf(1.0), None, small_dims[0], small_dims[1], small_dims[2], uv_small)
+    out["noise_uv_only"] = t
     return out
 
 

@@ -301,6 +301,23 @@ def test_advect(hip_backend, oracle, dims, kind, order, clampMode, orderTrace):
     assert_bitexact(a, b, "advectSemiLagrange kind=%d" % kind)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D, (40, 17, 12)])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("order,orderTrace", [(1, 1), (2, 1), (2, 2)])
+def test_advect_cubic(hip_backend, oracle, dims, kind, order, orderTrace):
+    """orderSpace=2 (cubic interpolation, util/interpolHigh.h): bit-exact against the oracle (pinned to the compiled reference)"""
+    from mantaflow_amd import _lib
+    sx, sy, sz = dims
+    flags, vel = cases.advect_inputs(dims, 9, vmax=2.5, outflow=(kind == 2))
+    field = util.rand_real((sz, sy, sx), 10) if kind == 0 else util.rand_vel(sx, sy, sz, 10)
+    kw = dict(order=order, clampMode=2, orderTrace=orderTrace, orderSpace=2, strength=0.8 if order == 2 else 1.0)
+    a = cases.run_advect_pkg(dims, 0.9, flags, vel, field, kind, **kw)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_advect_pkg(dims, 0.9, flags, vel, field, kind, **kw)
+    _lib.reset()
+    assert_bitexact(a, b, "advectSemiLagrange(orderSpace=2) kind=%d" % kind)
+
+
 @pytest.mark.parametrize("dims", [(12, 10, 9), cases.SIZE_2D])
 @pytest.mark.parametrize("with_ptype", [False, True])
 def test_flip_transfers(hip_backend, dims, with_ptype):
@@ -528,17 +545,18 @@ def test_ordered_p2g_bitexact_at_scale(hip_backend, dims, per_cell):
         assert_bitexact(a[k], a2[k], k + " (re-run)")
 
 
+@pytest.mark.parametrize("orderSpace", [1, 2])
 @pytest.mark.parametrize("case", range(len(cases.INTERP_CASES)))
-def test_interpolate_between_grid_sizes(hip_backend, case):
+def test_interpolate_between_grid_sizes(hip_backend, case, orderSpace):
     from mantaflow_amd import _lib
     sd, td, scale, offset, size = cases.INTERP_CASES[case]
     fields = {"real": util.rand_real((sd[2], sd[1], sd[0]), 71), "vec": util.rand_vel(*sd, 72)}
-    a = cases.run_interp_pkg(sd, td, scale, offset, size, fields)
+    a = cases.run_interp_pkg(sd, td, scale, offset, size, fields, orderSpace)
     _lib.use_library(util.build_oracle(), "cpu")
-    b = cases.run_interp_pkg(sd, td, scale, offset, size, fields)
+    b = cases.run_interp_pkg(sd, td, scale, offset, size, fields, orderSpace)
     _lib.reset()
     for k in b:
-        assert_bitexact(a[k], b[k], "%s case %d" % (k, case))
+        assert_bitexact(a[k], b[k], "%s case %d orderSpace %d" % (k, case, orderSpace))
 
 
 def test_reductions_and_elementwise(hip, oracle):

@@ -123,6 +123,23 @@ def test_advect(oracle_backend, dims, kind, order, clampMode, orderTrace):
     assert_bitexact(a, b, "advectSemiLagrange kind=%d" % kind)
 
 
+@pytest.mark.parametrize("dims", [(14, 12, 10), cases.SIZE_2D])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("order,orderTrace", [(1, 1), (2, 1), (2, 2)])
+def test_advect_cubic(oracle_backend, dims, kind, order, orderTrace):
+    """orderSpace=2: cubic interpolation (util/interpolHigh.h) in the semi-Lagrangian gathers -- Real (double-precision coefficient
+    expressions), Vec3 and MAC (per-product fp32 rounding), with the linear fall-back where the 4^3 neighbourhood leaves the grid"""
+    sx, sy, sz = dims
+    flags, vel = cases.advect_inputs(dims, 9, vmax=2.5, outflow=(kind == 2))
+    field = util.rand_real((sz, sy, sx), 10) if kind == 0 else util.rand_vel(sx, sy, sz, 10)
+    if kind == 1 and sz == 1:
+        field[2] = util.rand_real((sz, sy, sx), 12)
+    kw = dict(order=order, clampMode=2, orderTrace=orderTrace, orderSpace=2, strength=0.8 if order == 2 else 1.0)
+    a = cases.run_advect_pkg(dims, 0.9, flags, vel, field, kind, **kw)
+    b = cases.run_advect_ref(dims, 0.9, flags, vel, field, kind, **kw)
+    assert_bitexact(a, b, "advectSemiLagrange(orderSpace=2) kind=%d" % kind)
+
+
 def test_advect_selfadvection_long_traces(oracle_backend):
     """velocity advecting itself with traces leaving the domain (|v| dt up to 6 cells)"""
     dims = (16, 14, 12)
@@ -283,16 +300,17 @@ def test_grid_files_interoperate_with_reference(oracle_backend, tmp_path, ext):
             core.Grid(s).load(str(tmp_path / "ours2.uni"))
 
 
+@pytest.mark.parametrize("orderSpace", [1, 2])
 @pytest.mark.parametrize("case", range(len(cases.INTERP_CASES)))
-def test_interpolate_between_grid_sizes(oracle_backend, case):
+def test_interpolate_between_grid_sizes(oracle_backend, case, orderSpace):
     """interpolateGrid / interpolateGridVec3 / interpolateMACGrid (waveletturbulence.cpp:37-78): up- and down-sampling,
-    anisotropic scale, offset, explicit size, 2-D"""
+    anisotropic scale, offset, explicit size, 2-D; linear and cubic (orderSpace 2, util/interpolHigh.h)"""
     sd, td, scale, offset, size = cases.INTERP_CASES[case]
     fields = {"real": util.rand_real((sd[2], sd[1], sd[0]), 71), "vec": util.rand_vel(*sd, 72)}
-    a = cases.run_interp_pkg(sd, td, scale, offset, size, fields)
-    b = cases.run_interp_ref(sd, td, scale, offset, size, fields)
+    a = cases.run_interp_pkg(sd, td, scale, offset, size, fields, orderSpace)
+    b = cases.run_interp_ref(sd, td, scale, offset, size, fields, orderSpace)
     for k in b:
-        assert_bitexact(a[k], b[k], "%s case %d" % (k, case))
+        assert_bitexact(a[k], b[k], "%s case %d orderSpace %d" % (k, case, orderSpace))
 
 
 SHAPES = [  # kind, 9 floats (see ref_shape_levelset), constructor

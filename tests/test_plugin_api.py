@@ -58,3 +58,20 @@ def test_introspection_attributes(oracle_backend):
     assert pp._class == "BasicParticleSystem"
     assert (pp.create(m.PdataVec3)._class, pp.create(m.PdataVec3)._T) == ("ParticleDataImpl", "Vec3")
     assert m.Vec3 is m.vec3 and m.Real is float and m.Vec3Grid is m.VecGrid
+
+
+def test_vec4_value_type():
+    """manta.vec4 (pvec3.cpp:280-389): members x, y, z, t; zero / broadcast / four-value construction; partial init is an error;
+    repr in the reference's format; no arithmetic"""
+    from manta import vec4, Vec4
+    assert Vec4 is vec4
+    v = vec4()
+    assert (v.x, v.y, v.z, v.t) == (0.0, 0.0, 0.0, 0.0)
+    v = vec4(1.5)
+    assert tuple(v) == (1.5, 1.5, 1.5, 1.5)
+    v = vec4(1, 2, 3, 0.1)
+    assert v.t == float(np.float32(0.1)) and repr(v) == "[+1.000000,+2.000000,+3.000000,+0.100000]"
+    with pytest.raises(RuntimeError, match="Invalid partial init of vec4"):
+        vec4(1, 2)
+    with pytest.raises(TypeError):
+        v + v

@@ -37,6 +37,7 @@ def run_script(name, workdir, gen):
 
 
 @pytest.mark.parametrize("name,min_checks", [("test_0010_io.py", 3), ("test_0011_inverted.py", 1), ("test_0020_shapes.py", 6),
+                                             ("test_0040_interpol2d.py", 1), ("test_0041_interpol3d.py", 1),
                                              ("test_0030_gridop.py", 9), ("test_0100_psolve.py", 4), ("test_0150_advect.py", 10),
                                              ("test_1010_plume2d.py", 2), ("test_1070_flip2d.py", 2), ("test_1080_ldc.py", 1), ("test_2010_plume3d.py", 2),
                                              ("test_2011_plume3d_open.py", 2), ("test_2020_obstacle.py", 2),

@@ -73,13 +73,13 @@ REF_PROTOS = {
     "ref_compute_wavelet_coeffs": [c_i, c_i, c_i, c_p],
     "ref_vorticity_confinement": [c_i, c_i, c_i, c_p, c_p, c_f, c_p],
     "ref_set_open_bound": [c_i, c_i, c_i, c_p, c_i, ctypes.c_char_p, c_i],
-    "ref_apply_noise_vec3": [c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_i, c_i, c_i],
+    "ref_apply_noise_vec3": [c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_p],
     "ref_waveletturbulence": [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "ref_simpleplume": [c_i, c_i, c_i, c_p, c_p],
     "ref_shape_levelset": [c_i, c_i, c_i, c_i, c_p, c_p],
     "ref_noise_tile": [c_p],
     "ref_density_inflow": [c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_f],
-    "ref_interpolate_grid": [c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i],
+    "ref_interpolate_grid": [c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i],
     "ref_sample_flags_with_particles": [c_i, c_i, c_i, c_p, c_i, c_f, c_l, c_p, c_p],
     "ref_init_domain": [c_i, c_i, c_i, c_p, c_i, c_s, c_s, c_s, c_s, c_i],
 }
