@@ -149,7 +149,12 @@ int mf_count_empty_cells(int64_t n, const int32_t* flags, int32_t* result_host, 
 int mf_fix_pressure(int sx, int sy, int sz, int64_t fixPidx, float value, float* rhs, float* A0, float* Ai,
                     float* Aj, float* Ak, void* stream);
 
-/* InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97 (3-D only).  Also records, for exactly these grids, which
+/* CONCURRENCY CONTRACT of the MIC sweeps (mf_mic_init*, mf_mic_apply*, mf_cg_solve, mf_pack_matrix): per device the library keeps ONE
+ * set of sweep state (ticket counters, generation tags, face exchange buffers, the bundle map and packed bytes of the last
+ * mf_mic_init).  Calls that use it must be issued from one host thread at a time and on one stream per device; two solves in flight
+ * on the same device (two streams, or two host threads) would share tickets and tags.  Different devices are independent.
+ *
+ * InitPreconditionModifiedIncompCholesky2, conjugategrad.cpp:66-97 (3-D only).  Also records, for exactly these grids, which
  * 8x8 bundles of x-rows hold no fluid cell and have no coupling into them: mf_mic_apply leaves those out when it is called
  * with the same flags / Aprecond / Aj / Ak pointers (as GridCg does); with other pointers it sweeps everything.  Changing the
  * contents of these grids between mf_mic_init and mf_mic_apply is a caller error (the reference's Aprecond would be stale too). */
