@@ -121,6 +121,115 @@ def cpu_baseline(sample_dims, vel, dens, flags, dt):
                       "input on its first %d z-planes as a %dx%dx%d domain, %.1f s" % (sz, sx, sy, sz, el)}
 
 
+def other_configs(torch, core, plugins):
+    """BASELINE configs 3 and 5 on one GPU, a few steps each, so that the driver's record carries a number for them as well (the
+    headline `value` stays config 2).  Config 3: the S-flip step of SURVEY 8d at 128^3 (flip01_simple.py's loop, 8 particles per cell
+    in a 0.4 x 0.6 x 1.0 block).  Config 5: the up-res loop of scenes/waveletTurbulence.py with a 256^3 coarse and a 512^3 fine grid
+    (the fine-grid MacCormack advection is the HBM-bound part)."""
+    from mantaflow_amd import scene
+    out = {}
+
+    def timed(step, steps, warm):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    # ---- config 3 ----
+    n = 128
+    s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
+    s.timestep = 0.5
+    flags = core.FlagGrid(s)
+    flags.initDomain(boundaryWidth=0)
+    flags.updateFromLevelset(scene.Box(parent=s, p0=core.vec3(0, 0, 0), p1=core.vec3(0.4 * n, 0.6 * n, n)).computeLevelset())
+    pp = core.BasicParticleSystem(s)
+    scene.sampleFlagsWithParticles(flags, pp, 2, 0.2)
+    pv = pp.create(core.PdataVec3)
+    pv.from_numpy(np.random.default_rng(9832).normal(0, 0.5, (pp.np, 3)).astype(np.float32))
+    vel, velOld, w, pres = core.MACGrid(s), core.MACGrid(s), core.VecGrid(s), core.Grid(s)
+
+    def flip_step():
+        pp.advectInGrid(flags, vel, 2, deleteInObstacle=False)
+        plugins.mapPartsToMAC(flags, vel, velOld, pp, pv, w)
+        plugins.extrapolateMACFromWeight(vel, w, distance=2)
+        plugins.markFluidCells(pp, flags)
+        plugins.addGravity(flags, vel, core.vec3(0, -0.002, 0))
+        plugins.setWallBcs(flags, vel)
+        plugins.solvePressure(vel, pres, flags)
+        plugins.extrapolateMACSimple(flags, vel)
+        plugins.flipVelocityUpdate(flags, vel, velOld, pp, pv, 0.97)
+        s.step()
+
+    t = timed(flip_step, 5, 2)
+    out["config3_sflip128"] = {"workload": "flip01_simple.py loop, 128^3, %d particles (ordered, bit-exact P2G)" % pp.np, "ms_per_step": round(t * 1e3, 3),
+                               "Mcells_per_s": round(n ** 3 / t / 1e6, 2), "Mparticles_per_s": round(pp.np / t / 1e6, 2),
+                               "cg_iterations_last": plugins.lastCgStats().get("iterations")}
+    del flags, pp, pv, vel, velOld, w, pres, s
+    # ---- config 5 ----
+    nc, up = 256, 2
+    gs, xgs = core.vec3(nc, nc, nc), core.vec3(nc * up, nc * up, nc * up)
+    sm, xl = core.Solver(gridSize=gs, dim=3), core.Solver(gridSize=xgs, dim=3)
+    sm.timestep = xl.timestep = 1.5
+    noise = scene.NoiseField(parent=sm, fixedSeed=265, loadFromFile=True)
+    noise.posScale, noise.clamp, noise.clampNeg, noise.clampPos, noise.valScale, noise.valOffset, noise.timeAnim = core.vec3(20), True, 0, 2, 1, 0.075, 0.3
+    source = scene.Cylinder(parent=sm, center=gs * core.vec3(0.3, 0.2, 0.5), radius=nc * 0.081, z=gs * core.vec3(0.081, 0, 0))
+    sourceVel = scene.Cylinder(parent=sm, center=gs * core.vec3(0.3, 0.2, 0.5), radius=nc * 0.15, z=gs * core.vec3(0.15, 0, 0))
+    xl_source = scene.Cylinder(parent=xl, center=xgs * core.vec3(0.3, 0.2, 0.5), radius=xgs.x * 0.081, z=xgs * core.vec3(0.081, 0, 0))
+    xl_noise = scene.NoiseField(parent=xl, fixedSeed=265, loadFromFile=True)
+    xl_noise.posScale, xl_noise.clamp, xl_noise.clampNeg, xl_noise.clampPos = noise.posScale, True, 0, 2
+    xl_noise.valScale, xl_noise.valOffset, xl_noise.timeAnim = 1, 0.075, noise.timeAnim * up
+    wl = []
+    for k in range(3):
+        f = scene.NoiseField(parent=xl, loadFromFile=True)
+        f.posScale, f.timeAnim = core.vec3(int(1.0 * nc)) * (0.5 * 2.0 ** k), 0.1
+        wl.append(f)
+    flags, vel, dens, pres, energy = core.FlagGrid(sm), core.MACGrid(sm), core.Grid(sm), core.Grid(sm), core.Grid(sm)
+    xfl, xvel, xdens, xw = core.FlagGrid(xl), core.MACGrid(xl), core.Grid(xl), core.Grid(xl)
+    flags.initDomain(); flags.fillGrid(); plugins.setOpenBound(flags, 0, "Y", 16 | 4)
+    xfl.initDomain(); xfl.fillGrid()
+    velInflow = core.vec3(0.025, 0, 0) * float(nc)
+    wlt = 0.4
+    t_fine = [0.0]
+
+    def wavelet_step():
+        plugins.advectSemiLagrange(flags, vel, dens, order=2)
+        plugins.advectSemiLagrange(flags, vel, vel, order=2)
+        scene.densityInflow(flags=flags, density=dens, noise=noise, shape=source, scale=1, sigma=0.5)
+        sourceVel.applyToGrid(grid=vel, value=velInflow)
+        plugins.setWallBcs(flags, vel)
+        plugins.addBuoyancy(flags, dens, vel, core.vec3(0, -1e-3, 0))
+        plugins.vorticityConfinement(vel, flags, strength=0.3)
+        plugins.solvePressure(vel, pres, flags, cgMaxIterFac=1.0, cgAccuracy=0.01)
+        plugins.setWallBcs(flags, vel)
+        plugins.computeEnergy(flags, vel, energy)
+        plugins.computeWaveletCoeffs(energy)
+        sm.step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plugins.interpolateGrid(target=xw, source=energy)
+        plugins.interpolateMACGrid(source=vel, target=xvel)
+        for k in range(3):
+            plugins.applyNoiseVec3(flags=xfl, target=xvel, noise=wl[k], scale=wlt * 0.6 ** k, weight=xw)
+        for _ in range(up):
+            plugins.advectSemiLagrange(xfl, xvel, xdens, order=2)
+        scene.densityInflow(flags=xfl, density=xdens, noise=xl_noise, shape=xl_source, scale=1, sigma=0.5)
+        e1.record()
+        xl.step()
+        torch.cuda.synchronize()
+        t_fine[0] = e0.elapsed_time(e1)
+
+    t = timed(wavelet_step, 3, 2)
+    nf = (nc * up) ** 3
+    out["config5_wavelet512"] = {"workload": "waveletTurbulence.py loop, coarse 256^3 (MIC-CG 1e-2) + fine 512^3 (resampling, 3 noise octaves, 2 MacCormack substeps)",
+                                 "ms_per_step": round(t * 1e3, 2), "fine_part_ms": round(t_fine[0], 2), "fine_Mcells_per_s": round(nf / t / 1e6, 1),
+                                 "cg_iterations_last": plugins.lastCgStats().get("iterations")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +237,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short single-GPU runs of BASELINE configs 3 and 5")
     ap.add_argument("--slab", action="store_true", help="N=1 only: run the z-slab code path with one rank (overhead check)")
     a = ap.parse_args()
 
@@ -260,6 +370,10 @@ def main():
                                                       "per CG iteration (ApplyMatrix 28 + 2 dot 16 + 2 axpy 24 + max-norm 8 + search update 12 + MIC apply 56)": CG_ITERATION_BYTES_PER_CELL,
                                                       "mean CG iterations": round(its, 1)}}
         del A0, Ai, Aj, Ak, src, dst, ap
+        if not a.no_other_configs and n == GRID:
+            del flags, vel, vel0, dens, pres, s
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_configs(torch, core, plugins)
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline((n, n, max(16, n // 4)), v_np, d_np, None, dt)
 
@@ -286,6 +400,8 @@ def main():
             line["roofline_mic"] = result["roofline_mic"]
         if "roofline_step" in result:
             line["roofline_step"] = result["roofline_step"]
+        if "other_configs" in result:
+            line["other_configs"] = result["other_configs"]
         if "cpu_baseline" in result:
             line["cpu_baseline"] = result["cpu_baseline"]
         if "notes" in result:
