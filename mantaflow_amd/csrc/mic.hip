@@ -1629,6 +1629,9 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 		if (need > f.sx_cap) {
 			if (f.sxj) MF_HIP(hipFree(f.sxj));
 			if (f.sxk) MF_HIP(hipFree(f.sxk));
+			// (fine-grained memory, hipExtMallocWithFlags, was tried for these: 0.45 instead of 0.71 us per idle hand-off in
+			// tools/micro/pingpong_scalar.hip, but no change of the sweep time -- 575.0 vs 576.4 us per apply at 256^3; so were four
+			// scalar-path poller waves (s_load_dwordx16 glc, 0.45 us per hand-off in the micro-benchmark): bit-exact, 700+ us)
 			MF_HIP(hipMalloc((void**)&f.sxj, need));
 			MF_HIP(hipMalloc((void**)&f.sxk, need));
 			f.sx_cap = need;
@@ -1852,13 +1855,22 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			// MF_ROWS_TRACE=<ticket>: per-block wall-clock stamps (100 MHz) of that bundle's compute wave, printed per launch
 			static long long* trace = nullptr;
 			static int trace_ticket = -2;
-			static const int trace_ticket2 = getenv("MF_ROWS_TRACE2") ? atoi(getenv("MF_ROWS_TRACE2")) : -1;
+			static int trace_ticket2 = getenv("MF_ROWS_TRACE2") ? atoi(getenv("MF_ROWS_TRACE2")) : -1;
 			if (trace_ticket == -2) {
 				const char* e = getenv("MF_ROWS_TRACE");
 				trace_ticket = e ? atoi(e) : -1;
 				if (trace_ticket >= 0) {
 					MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 12 * 4096));
 					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 12 * 4096));
+					if (trace_ticket2 < 0 && trace_ticket < f->nblocks) {
+						// second traced bundle = the j-successor of the first (the consumer of its j face); MF_ROWS_TRACEK: its k-successor
+						int* ho = (int*)malloc(sizeof(int) * f->nblocks);
+						MF_HIP(hipMemcpy(ho, f->border, sizeof(int) * f->nblocks, hipMemcpyDeviceToHost));
+						const int want = ho[trace_ticket] + (getenv("MF_ROWS_TRACEK") ? (1 << 12) : 1);
+						for (int i = 0; i < f->nblocks; i++)
+							if (ho[i] == want) trace_ticket2 = i;
+						free(ho);
+					}
 				}
 			}
 			static const bool noskip = getenv("MF_MIC_NOSKIP") != nullptr;

@@ -29,6 +29,16 @@ __device__ __forceinline__ bool poll_scalar(const unsigned long long* line, unsi
 	for (int q = 0; q < 8; q++) ok = ok && (v[2 * q + 1] == tag);
 	return ok;
 }
+// scalar poll of FOUR consecutive lines in one round trip (what a poller wave of the sweep would do: 64 SGPRs); only line 0 is checked
+__device__ __forceinline__ bool poll_scalar4(const unsigned long long* line, unsigned tag) {
+	u16v v, w1, w2, w3;
+	asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\ts_load_dwordx16 %2, %4, 0x80 glc\n\ts_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+	             : "=&s"(v), "=&s"(w1), "=&s"(w2), "=&s"(w3) : "s"(line) : "memory");
+	bool ok = true;
+#pragma unroll
+	for (int q = 0; q < 8; q++) ok = ok && (v[2 * q + 1] == tag);
+	return ok && (w1[1] + w2[1] + w3[1] != 0x12345u);
+}
 template <int SCALAR>
 __global__ void __launch_bounds__(256)
 pingpong(unsigned long long* A, unsigned long long* B, int n, int p1, int* info, const float4* big, size_t nbig, int background, float* sink) {
@@ -62,7 +72,7 @@ pingpong(unsigned long long* A, unsigned long long* B, int n, int p1, int* info,
 		if (me == 0) st_line(mine, lane, (float)i, (unsigned)i);
 		int spins = 0;
 		for (;;) {
-			const bool ok = SCALAR ? poll_scalar(theirs, (unsigned)i) : poll_vector(theirs, lane, (unsigned)i);
+			const bool ok = SCALAR == 2 ? poll_scalar4(theirs, (unsigned)i) : (SCALAR ? poll_scalar(theirs, (unsigned)i) : poll_vector(theirs, lane, (unsigned)i));
 			if (ok) break;
 			if (++spins > SPIN_LIMIT) { fail = 1; break; }
 		}
@@ -84,7 +94,7 @@ static void run(unsigned long long* A, unsigned long long* B, int* info, int p1,
 	hipEventRecord(e1); hipEventSynchronize(e1);
 	float ms; hipEventElapsedTime(&ms, e0, e1);
 	int h[4]; hipMemcpy(h, info, sizeof h, hipMemcpyDeviceToHost);
-	printf("%-12s %-6s poll, %s, blocks 0/%d (xcc %d/%d): %s %.3f us one way\n", mem, SCALAR ? "scalar" : "vector", background ? "HBM stream running" : "idle CU        ",
+	printf("%-12s %-6s poll, %s, blocks 0/%d (xcc %d/%d): %s %.3f us one way\n", mem, SCALAR == 2 ? "scal x4" : (SCALAR ? "scalar" : "vector"), background ? "HBM stream running" : "idle CU        ",
 	       p1, h[0], h[1], (h[2] || h[3]) ? "TIMED OUT (not coherent)" : "ok", ms * 1e3 / n / 2);
 }
 int main() {
@@ -107,6 +117,7 @@ int main() {
 			for (int bg = 0; bg < 2; bg++) {
 				run<0>(A, B, info, partners[q], big, nbig, bg, sink, mem);
 				run<1>(A, B, info, partners[q], big, nbig, bg, sink, mem);
+				run<2>(A, B, info, partners[q], big, nbig, bg, sink, mem);
 			}
 	}
 	return 0;
