@@ -545,7 +545,12 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	const bool packed = pack != nullptr && pack_ok[0] != 0;
 	constexpr bool REV = (MODE == 2);
 	if (sc && sc->done) return;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7;
+	// (A Gray-coded lane -> k mapping with DPP row_ror:8 / v_permlane16_swap / v_permlane32_swap instead of the ds_bpermute for the
+	// k-neighbour was tried -- tools/micro/permlane_swap.hip: bit-exact, 591 instead of 572 us per apply: the compute wave is bound
+	// by the NUMBER of instructions it issues per step (~8 cycles each), not by the latency of the one LDS permute.)
+	const int c = lane >> 3;
+	constexpr int CORNER = 63;                    // lane of (b, c) = (7, 7)
 	const int skew = b + c;
 	// the compute wave is the critical path: everything else yields to it
 	if (wave == 0) __builtin_amdgcn_s_setprio(3);
@@ -555,7 +560,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	__shared__ float sR[MODE == 2 ? 32 * 64 : 1];   // with_dot: var1 of the cell
 	__shared__ __attribute__((aligned(16))) float sFj[2][8][8];
 	__shared__ __attribute__((aligned(16))) float sFk[2][8][8];   // face values of a block [block parity][face lane][step]
-	__shared__ int s_ready[3], s_done, s_flushed, s_faces, s_ticket;
+	// s_flags = {chunks committed by loader wave 1, 2, 3, face blocks published}: one 16-byte LDS word, so that the compute wave
+	// reads all of them -- and, speculatively, the block's face values -- in ONE LDS round trip per block
+	__shared__ __attribute__((aligned(16))) int s_flags[4];
+	__shared__ int s_done, s_flushed, s_ticket;
+	int* const s_ready = s_flags;
 	const unsigned long long fresh0 = (unsigned long long)gen << 32;
 	const int X8 = nchunks * 8;
 	int spins = 0;
@@ -576,7 +585,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			s_ready[0] = s_ready[1] = s_ready[2] = 0;
 			s_done = 0;
 			s_flushed = 0;
-			s_faces = 0;
+			s_flags[3] = 0;
 		}
 		__syncthreads();
 		const int t = s_ticket;
@@ -632,6 +641,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				unsigned long long gj[8], gk[8];
 #pragma unroll
 				for (int a = 0; a < 8; a++) gj[a] = gk[a] = fresh0;
+				int pub = 0;
 				for (;;) {
 					if (has_pj) {
 #pragma unroll
@@ -641,33 +651,40 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 #pragma unroll
 						for (int a = 0; a < 8; a++) gk[a] = granule_load(in_k + (int64_t)(8 * m + 7 + a) * 8);
 					}
-					// tags only grow: the window is complete when its smallest tag is this sweep's generation
-					unsigned tmin = gen;
+					// tags only grow: a half window (4 steps) is complete when its smallest tag is this sweep's generation.  The
+					// halves are published separately: the compute wave starts a block on the first one, i.e. a consumer bundle
+					// runs 11 instead of 15 steps behind its producer (7 steps of skew + the granularity of the hand-off).
+					unsigned tminA = gen, tminB = gen;
 #pragma unroll
 					for (int a = 0; a < 8; a++) {
 						const bool in = (unsigned)(xq + a) < (unsigned)X8;
 						const unsigned tj_ = (unsigned)(gj[a] >> 32), tk_ = (unsigned)(gk[a] >> 32);
-						tmin = min(tmin, in ? min(tj_, tk_) : gen);
+						const unsigned tm = in ? min(tj_, tk_) : gen;
+						if (a < 4) tminA = min(tminA, tm);
+						else tminB = min(tminB, tm);
 					}
-					if (__all(tmin == gen) || ++spins > FLOW_SPIN_LIMIT) break;
+					const bool giveup = ++spins > FLOW_SPIN_LIMIT;
+					if (pub == 0 && (__all(tminA == gen) || giveup)) {
+						// the buffer of this parity was read by block m-2
+						if (m >= 2) {
+							while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m - 1) {
+								if (++spins > FLOW_SPIN_LIMIT) break;
+								__builtin_amdgcn_s_sleep(8);
+							}
+						}
+						if (b == 0) *(float4*)&sFj[m & 1][c][0] = make_float4(__uint_as_float((unsigned)gj[0]), __uint_as_float((unsigned)gj[1]), __uint_as_float((unsigned)gj[2]), __uint_as_float((unsigned)gj[3]));
+						if (c == 0) *(float4*)&sFk[m & 1][b][0] = make_float4(__uint_as_float((unsigned)gk[0]), __uint_as_float((unsigned)gk[1]), __uint_as_float((unsigned)gk[2]), __uint_as_float((unsigned)gk[3]));
+						__hip_atomic_store(&s_flags[3], 2 * m + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						pub = 1;
+					}
+					if (pub == 1 && (__all(tminB == gen) || giveup)) {
+						if (b == 0) *(float4*)&sFj[m & 1][c][4] = make_float4(__uint_as_float((unsigned)gj[4]), __uint_as_float((unsigned)gj[5]), __uint_as_float((unsigned)gj[6]), __uint_as_float((unsigned)gj[7]));
+						if (c == 0) *(float4*)&sFk[m & 1][b][4] = make_float4(__uint_as_float((unsigned)gk[4]), __uint_as_float((unsigned)gk[5]), __uint_as_float((unsigned)gk[6]), __uint_as_float((unsigned)gk[7]));
+						__hip_atomic_store(&s_flags[3], 2 * m + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						break;
+					}
 					__builtin_amdgcn_s_sleep(1);
 				}
-				// the buffer of this parity was read by block m-2
-				if (m >= 2) {
-					while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m - 1) {
-						if (++spins > FLOW_SPIN_LIMIT) break;
-						__builtin_amdgcn_s_sleep(8);
-					}
-				}
-				if (b == 0) {
-#pragma unroll
-					for (int a = 0; a < 8; a++) sFj[m & 1][c][a] = __uint_as_float((unsigned)gj[a]);
-				}
-				if (c == 0) {
-#pragma unroll
-					for (int a = 0; a < 8; a++) sFk[m & 1][b][a] = __uint_as_float((unsigned)gk[a]);
-				}
-				__hip_atomic_store(&s_faces, m + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		} else if (wave != 0) {
 			// ================= memory waves: waves 1-3 load + commit, wave 4 writes finished chunks back =================
@@ -796,9 +813,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			}
 		} else {
 			// ================= compute wave: LDS in, LDS + face granules out =================
-			// Lane 0 stands in for lane 63's k face (same step, but its own x' runs 14 ahead of lane 63's)
+			// Lane 0 stands in for the corner lane's k face (same step, but its own x' runs 14 ahead of the corner lane's)
 			const bool corner_proxy = (lane == 0) && sk_live;
-			const bool face_lane = has_sj || (has_sk && lane != 63) || corner_proxy;
+			const bool face_lane = has_sj || (has_sk && lane != CORNER) || corner_proxy;
 			const int fskew = corner_proxy ? -14 : 0;
 			unsigned long long* out_f = has_sj ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
 			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
@@ -819,30 +836,50 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				constexpr bool LOCAL = decltype(local_tag)::value;
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
 				ROWS_TRACE(0)
-				if (m < nchunks) {
-					int* flag = &s_ready[m % 3];
-					while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m + 1) {
-						if (++spins > FLOW_SPIN_LIMIT) break;
-						__builtin_amdgcn_s_sleep(1);
-					}
-				}
-				ROWS_TRACE(1)
-				while (__hip_atomic_load(&s_faces, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m + 1) {
+				// flags and face values in one batch of LDS reads: the LDS serves a wave's requests in order, and the poller
+				// publishes the values before the flag -- a flag read that shows block m is followed by reads that see its values
+				typedef int rows_i4 __attribute__((ext_vector_type(4)));
+				typedef float rows_f4 __attribute__((ext_vector_type(4)));
+				typedef const volatile __attribute__((address_space(3))) rows_i4* lflags;
+				typedef const volatile __attribute__((address_space(3))) rows_f4* lface;
+				rows_f4 j0, j1, k0, k1;
+				const int r3 = m % 3;
+				bool have2;
+				for (;;) {
+					const rows_i4 fg = *(lflags)s_flags;
+					j0 = *(lface)&sFj[m & 1][c][0];
+					j1 = *(lface)&sFj[m & 1][c][4];
+					k0 = *(lface)&sFk[m & 1][b][0];
+					k1 = *(lface)&sFk[m & 1][b][4];
+					const int rdy = r3 == 0 ? fg.x : (r3 == 1 ? fg.y : fg.z);
+					have2 = fg.w >= 2 * m + 2;         // second half there as well: j1 / k1 are its values
+					if (((m >= nchunks) || rdy >= m + 1) && fg.w >= 2 * m + 1) break;
 					if (++spins > FLOW_SPIN_LIMIT) break;
 					__builtin_amdgcn_s_sleep(1);
 				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+				ROWS_TRACE(1)
 				float gj[8], gk[8];
-				{
-					const float4 j0 = *(const float4*)&sFj[m & 1][c][0], j1 = *(const float4*)&sFj[m & 1][c][4];
-					const float4 k0 = *(const float4*)&sFk[m & 1][b][0], k1 = *(const float4*)&sFk[m & 1][b][4];
-					gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
-					gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
-				}
+				gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
+				gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
 				ROWS_TRACE(2)
 				const int base = (8 * m) & 31;
 				unsigned long long* pf = out_f + (int64_t)(8 * m) * 8;   // row h + 2 = 8m + s
 #pragma unroll
 				for (int s = 0; s < 8; s++) {
+					if (s == 4 && !have2) {
+						// second half of the block's face values
+						for (;;) {
+							const int fw = *(const volatile __attribute__((address_space(3))) int*)&s_flags[3];
+							j1 = *(lface)&sFj[m & 1][c][4];
+							k1 = *(lface)&sFk[m & 1][b][4];
+							if (fw >= 2 * m + 2 || ++spins > FLOW_SPIN_LIMIT) break;
+							__builtin_amdgcn_s_sleep(1);
+						}
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+						gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
+						gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
+					}
 					const float4 cA = nA;
 					const float2 cB = nB;
 					const int row = ((base + s) & 31) * 64 + lane;
@@ -870,8 +907,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						oi0 = oj0 = ok0 = valid ? val : 0.f;
 					}
 					// one face store per step: lanes b == 7 publish the j face, lanes c == 7 the k face, and lane 0 (never a
-					// face lane) publishes the k value of the corner lane 63, which is busy with its j value
-					const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), 63));
+					// face lane) publishes the k value of the corner lane (7, 7), which is busy with its j value
+					const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), CORNER));
 					const float fv = (lane == 0) ? corner : ((b == 7) ? oj0 : ok0);
 					if (valid) sA[row].x = val;
 					if (face_lane) {
