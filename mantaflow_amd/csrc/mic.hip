@@ -523,7 +523,8 @@ struct RowsChunk {
 	float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
 	unsigned long long W;     // packed path: 8 cells x {fluid, Ai == -1, Aj == -1, Ak == -1} bits
 };
-constexpr int ROWS_THREADS = 384;   // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the faces
+// wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the incoming faces, 6 publishes the outgoing ones
+constexpr int ROWS_THREADS = 448;
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(ROWS_THREADS)
 k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
@@ -550,7 +551,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	// k-neighbour was tried -- tools/micro/permlane_swap.hip: bit-exact, 591 instead of 572 us per apply: the compute wave is bound
 	// by the NUMBER of instructions it issues per step (~8 cycles each), not by the latency of the one LDS permute.)
 	const int c = lane >> 3;
-	constexpr int CORNER = 63;                    // lane of (b, c) = (7, 7)
 	const int skew = b + c;
 	// the compute wave is the critical path: everything else yields to it
 	if (wave == 0) __builtin_amdgcn_s_setprio(3);
@@ -564,6 +564,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	// reads all of them -- and, speculatively, the block's face values -- in ONE LDS round trip per block
 	__shared__ __attribute__((aligned(16))) int s_flags[4];
 	__shared__ int s_done, s_flushed, s_ticket;
+	__shared__ int s_half, s_pub;      // half blocks finished by the compute wave / published by wave 6
 	int* const s_ready = s_flags;
 	const unsigned long long fresh0 = (unsigned long long)gen << 32;
 	const int X8 = nchunks * 8;
@@ -586,6 +587,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			s_done = 0;
 			s_flushed = 0;
 			s_flags[3] = 0;
+			s_half = 0;
+			s_pub = 0;
 		}
 		__syncthreads();
 		const int t = s_ticket;
@@ -629,9 +632,46 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		const bool sj_live = (tjl + 1 < nbj) && (tj / jb == tj_succ / jb) && !(bempty && bempty[tk * nbj + tj_succ]);
 		const bool sk_live = (tkl + 1 < nbk) && !(bempty && bempty[tk_succ * nbj + tj]);
 		const bool has_pj = pj_live && (b == 0), has_pk = pk_live && (c == 0);
-		const bool has_sj = sj_live && (b == 7), has_sk = sk_live && (c == 7);
 		const int64_t XP = X8 + 2 * ROWS_PAD;
-		if (wave == 5) {
+		if (wave == 6) {
+			// ================= face publisher: the compute wave only leaves its results in the ring; this wave turns the outer rows /
+			// columns of every finished half block into face granules -- (val * Aj) * Aprecond resp. (val * Ak) * Aprecond, the same
+			// two fp32 products the compute wave feeds to its inner neighbours (forward sweep), or val itself (backward sweep).
+			// One store instruction per half block: lane = {face, face lane, step}.  (The compute wave is bound by the number of
+			// instructions it issues; the nine per step that published the faces are gone from it.)
+			const int fsel = lane >> 5, idx = (lane >> 2) & 7, st = lane & 3;
+			const int L = fsel == 0 ? idx * 8 + 7 : 56 + idx;            // source lane (b, c) = (7, idx) resp. (idx, 7)
+			const int skewL = (L & 7) + (L >> 3);
+			const bool live = fsel == 0 ? sj_live : sk_live;
+			unsigned long long* outp = (fsel == 0 ? xj : xk) + sid * XP * 8 + idx;
+			// plain (XCD-local) face stores only when every consumer of this bundle's faces runs on this XCD
+			const int nq_ = xt[17];
+			const bool local_faces = nq_ > 1 && ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk));
+			const int nhalf = 2 * (nchunks + 2);
+#pragma unroll 1
+			for (int n = 0; n < nhalf; n++) {
+				while (__hip_atomic_load(&s_half, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				const int h2 = 4 * n + st;                                  // ring row (= step + 2) of this lane's granule
+				const int xg = h2 - 2 - skewL;                              // its cell
+				if (live && (unsigned)xg < (unsigned)X8) {
+					const int slot = (h2 & 31) * 64 + L;
+					const float4 cA = sA[slot];
+					float fv = cA.x;
+					if (MODE == 1) {
+						const float p = sB[slot].x;
+						fv = (cA.x * (fsel == 0 ? cA.z : cA.w)) * p;
+					}
+					if (local_faces) granule_store_local(outp + (int64_t)h2 * 8, fv, gen);
+					else granule_store(outp + (int64_t)h2 * 8, fv, gen);
+				}
+				// the ring rows may be overwritten now (LDS-only release: the granule stores need not have been acknowledged)
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+				__hip_atomic_store(&s_pub, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		} else if (wave == 5) {
 			// ================= face poller: the only wave that loads granules (and it never stores to global memory) =====
 			const unsigned long long* in_j = xj + (sid - 1) * XP * 8 + c;          // + (h + 2) * 8
 			const unsigned long long* in_k = xk + (sid - nbj) * XP * 8 + b;
@@ -774,6 +814,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					issue(R, n);
 					// the ring rows of chunk n were last used by chunk n-4: it must have been written back
 					if (n >= 4) wait_for(&s_flushed, n - 3);
+					// ... and its outer rows / columns (finished with block n-2) must have been published
+					if (n >= 4) wait_for(&s_pub, 2 * (n - 2) + 2);
 					commit(R, n);
 					__hip_atomic_store(&s_ready[w], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
@@ -812,12 +854,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				}
 			}
 		} else {
-			// ================= compute wave: LDS in, LDS + face granules out =================
-			// Lane 0 stands in for the corner lane's k face (same step, but its own x' runs 14 ahead of the corner lane's)
-			const bool corner_proxy = (lane == 0) && sk_live;
-			const bool face_lane = has_sj || (has_sk && lane != CORNER) || corner_proxy;
-			const int fskew = corner_proxy ? -14 : 0;
-			unsigned long long* out_f = has_sj ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
+			// ================= compute wave: LDS in, LDS out (wave 6 publishes the faces) =================
 			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
 			float4 nA = sA[lane];                  // ring row of h = -2 (never valid)
 			float2 nB = sB[lane];
@@ -828,12 +865,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
 			}
 #define ROWS_TRACE(i) if (tr) trb[m * 4 + (i)] = wall_clock64();
-			// plain (XCD-local) face stores only when every consumer of this bundle's faces runs on this XCD
-			const int nq_ = xt[17];
-			const bool local_faces = nq_ > 1 && ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk));
-			auto block = [&](int m, auto edge_tag, auto local_tag) {
+			auto block = [&](int m, auto edge_tag) {
 				constexpr bool EDGE = decltype(edge_tag)::value;
-				constexpr bool LOCAL = decltype(local_tag)::value;
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
 				ROWS_TRACE(0)
 				// flags and face values in one batch of LDS reads: the LDS serves a wave's requests in order, and the poller
@@ -864,7 +897,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
 				ROWS_TRACE(2)
 				const int base = (8 * m) & 31;
-				unsigned long long* pf = out_f + (int64_t)(8 * m) * 8;   // row h + 2 = 8m + s
 #pragma unroll
 				for (int s = 0; s < 8; s++) {
 					if (s == 4 && !have2) {
@@ -906,35 +938,25 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						val = fl ? nv : val;
 						oi0 = oj0 = ok0 = valid ? val : 0.f;
 					}
-					// one face store per step: lanes b == 7 publish the j face, lanes c == 7 the k face, and lane 0 (never a
-					// face lane) publishes the k value of the corner lane (7, 7), which is busy with its j value
-					const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), CORNER));
-					const float fv = (lane == 0) ? corner : ((b == 7) ? oj0 : ok0);
 					if (valid) sA[row].x = val;
-					if (face_lane) {
-						const bool fvalid = !EDGE || ((unsigned)(xq + s + fskew) < (unsigned)X8);
-						if (fvalid) {
-							if (LOCAL) granule_store_local(pf + s * 8, fv, gen);
-							else granule_store(pf + s * 8, fv, gen);
-						}
+					if (s == 3) {
+						// first half of the block is in the ring (the LDS serves this wave's writes in order: no wait needed)
+						asm volatile("" ::: "memory");
+						*(volatile __attribute__((address_space(3))) int*)&s_half = 2 * m + 1;
 					}
 				}
-				// LDS-only release: the block's granule stores need not have been acknowledged before the next block starts
+				// LDS-only release
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 				__hip_atomic_store(&s_done, m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_store(&s_half, 2 * m + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				ROWS_TRACE(3)
 			};
 #pragma unroll 1
 			for (int m = 0; m <= nchunks + 1; m++) {
 				// interior: every lane's x' is inside [0, X8) for all 8 steps of the block
 				const bool interior = (m >= 2 && m <= nchunks - 1);
-				if (local_faces) {
-					if (interior) block(m, std::false_type{}, std::true_type{});
-					else block(m, std::true_type{}, std::true_type{});
-				} else {
-					if (interior) block(m, std::false_type{}, std::false_type{});
-					else block(m, std::true_type{}, std::false_type{});
-				}
+				if (interior) block(m, std::false_type{});
+				else block(m, std::true_type{});
 			}
 			if (trace && lane == 0 && t < 4096) trace[4 * 4096 + 2 * t + 1] = wall_clock64();
 #undef ROWS_TRACE
