@@ -525,6 +525,13 @@ struct RowsChunk {
 };
 // wave 0 computes, 1-3 load (chunk n -> wave 1 + n % 3), 4 writes back, 5 polls the incoming faces, 6 publishes the outgoing ones
 constexpr int ROWS_THREADS = 448;
+// steps of operands held in LDS (8 per chunk): the loader waves may run ROWS_RING / 8 - 1 chunks ahead of the write-back
+#ifndef ROWS_RING
+#define ROWS_RING 64
+#endif
+#ifndef ROWS_NAP
+#define ROWS_NAP 1
+#endif
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(ROWS_THREADS)
 k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
@@ -555,9 +562,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	// the compute wave is the critical path: everything else yields to it
 	if (wave == 0) __builtin_amdgcn_s_setprio(3);
 	else __builtin_amdgcn_s_setprio(0);
-	__shared__ float4 sA[32 * 64];   // {fluid ? rhs : dst  (-> result), Ai, Aj, Ak}     index = ((h + 2) & 31) * 64 + lane
-	__shared__ float2 sB[32 * 64];   // {Aprecond, fluid}
-	__shared__ float sR[MODE == 2 ? 32 * 64 : 1];   // with_dot: var1 of the cell
+	__shared__ float4 sA[ROWS_RING * 64];   // {fluid ? rhs : dst  (-> result), Ai, Aj, Ak}     index = ((h + 2) & (ROWS_RING - 1)) * 64 + lane
+	__shared__ float2 sB[ROWS_RING * 64];   // {Aprecond, fluid}
+	__shared__ float sR[MODE == 2 ? ROWS_RING * 64 : 1];   // with_dot: var1 of the cell
 	__shared__ __attribute__((aligned(16))) float sFj[2][8][8];
 	__shared__ __attribute__((aligned(16))) float sFk[2][8][8];   // face values of a block [block parity][face lane][step]
 	// s_flags = {chunks committed by loader wave 1, 2, 3, face blocks published}: one 16-byte LDS word, so that the compute wave
@@ -657,7 +664,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				const int h2 = 4 * n + st;                                  // ring row (= step + 2) of this lane's granule
 				const int xg = h2 - 2 - skewL;                              // its cell
 				if (live && (unsigned)xg < (unsigned)X8) {
-					const int slot = (h2 & 31) * 64 + L;
+					const int slot = (h2 & (ROWS_RING - 1)) * 64 + L;
 					const float4 cA = sA[slot];
 					float fv = cA.x;
 					if (MODE == 1) {
@@ -739,7 +746,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			auto wait_for = [&](int* flag, int need) {
 				while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
 					if (++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(8);
+					__builtin_amdgcn_s_sleep(ROWS_NAP);
 				}
 			};
 			if (wave <= 3) {
@@ -799,7 +806,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 							caj = r.Aj[a];
 							cak = r.Ak[a];
 						}
-						const int idx = ((p0 + a) & 31) * 64 + lane;
+						const int idx = ((p0 + a) & (ROWS_RING - 1)) * 64 + lane;
 						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], cai, caj, cak);
 						sB[idx] = make_float2(r.P[a], fl ? 1.f : 0.f);
 						if (MODE == 2 && with_dot) sR[idx] = r.V[a];     // 0 outside the grid (load_row8)
@@ -812,10 +819,10 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 #pragma unroll 1
 				for (int n = w; n < nchunks; n += 3) {
 					issue(R, n);
-					// the ring rows of chunk n were last used by chunk n-4: it must have been written back
-					if (n >= 4) wait_for(&s_flushed, n - 3);
+					// the ring rows of chunk n were last used by chunk n - ROWS_RING / 8: it must have been written back
+					if (n >= ROWS_RING / 8) wait_for(&s_flushed, n - ROWS_RING / 8 + 1);
 					// ... and its outer rows / columns (finished with block n-2) must have been published
-					if (n >= 4) wait_for(&s_pub, 2 * (n - 2) + 2);
+					if (n >= ROWS_RING / 8) wait_for(&s_pub, 2 * (n - ROWS_RING / 8 + 2) + 2);
 					commit(R, n);
 					__hip_atomic_store(&s_ready[w], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
@@ -831,7 +838,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					float w[8];
 #pragma unroll
 					for (int e = 0; e < 8; e++) {
-						const int slot = ((p0 + e) & 31) * 64 + lane;
+						const int slot = ((p0 + e) & (ROWS_RING - 1)) * 64 + lane;
 						const float res = sA[slot].x;
 						w[REV ? 7 - e : e] = res;
 						if (MODE == 2 && with_dot) dacc += (double)(res * sR[slot]);
@@ -896,7 +903,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
 				gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
 				ROWS_TRACE(2)
-				const int base = (8 * m) & 31;
+				const int base = (8 * m) & (ROWS_RING - 1);
 #pragma unroll
 				for (int s = 0; s < 8; s++) {
 					if (s == 4 && !have2) {
@@ -914,8 +921,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					}
 					const float4 cA = nA;
 					const float2 cB = nB;
-					const int row = ((base + s) & 31) * 64 + lane;
-					const int nrow = ((base + s + 1) & 31) * 64 + lane;
+					const int row = ((base + s) & (ROWS_RING - 1)) * 64 + lane;
+					const int nrow = ((base + s + 1) & (ROWS_RING - 1)) * 64 + lane;
 					nA = sA[nrow];
 					nB = sB[nrow];
 					const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
