@@ -680,6 +680,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			}
 		} else if (wave == 5) {
 			// ================= face poller: the only wave that loads granules (and it never stores to global memory) =====
+			// (Tried on top of this: a second poller wave out of phase with the first (497 instead of 468 us per apply at 256^3), two
+			// polls in flight in this wave with hand-written loads and vmcnt waits (the compiler copies the load targets before the
+			// wait: wrong values), four scalar-path poller waves (tools/micro/rows_scalar_poller.diff: bit-exact, 700+ us).)
 			const unsigned long long* in_j = xj + (sid - 1) * XP * 8 + c;          // + (h + 2) * 8
 			const unsigned long long* in_k = xk + (sid - nbj) * XP * 8 + b;
 #pragma unroll 1
@@ -952,10 +955,10 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						*(volatile __attribute__((address_space(3))) int*)&s_half = 2 * m + 1;
 					}
 				}
-				// LDS-only release
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-				__hip_atomic_store(&s_done, m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_store(&s_half, 2 * m + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				// the block is in the ring (in-order LDS again: the counters are written after the results, without a wait)
+				asm volatile("" ::: "memory");
+				*(volatile __attribute__((address_space(3))) int*)&s_done = m + 1;
+				*(volatile __attribute__((address_space(3))) int*)&s_half = 2 * m + 2;
 				ROWS_TRACE(3)
 			};
 #pragma unroll 1
