@@ -356,6 +356,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         raise RuntimeError("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.")
     if stats is not None:
         stats["iterations"], stats["residual"] = iters, float(resNorm)
+        stats["mic_blocking"] = (jblock, xblock)     # rows along y / cells along x of a preconditioner block (0: not cut)
     # knReplaceClampedGhostFluidVels reads the CORRECTED z-velocity of the planes below and above: the first ghost plane must come
     # out right as well, and its correction reads the pressure of the second one
     dom.exchange(pressure, 1 if phi is None else 2)

@@ -286,7 +286,7 @@ def main():
     plugins.advectSemiLagrange(fg, vg, dg, order=1)      # ... and the plain solver again
     np.savez(out + ".%d.npz" % dom.comm.rank, z0=dom.z0, z1=dom.z1, dens=dom.gather_owned(dens), vel_adv=vel_adv,
              vel=dom.gather_owned(vel), pres=dom.gather_owned(pres), div=dom.gather_owned(rhs), iters=st["iterations"], res=st["residual"],
-             plain_dens=cases.grid_to_soa(dg))
+             plain_dens=cases.grid_to_soa(dg), mic_blocking=np.array(st["mic_blocking"]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,23 @@ def test_slab_two_ranks_on_hip(tmp_path):
     assert util.rel_err(single["pres"], ora["pres"]) < 1e-5
 
 
+def test_slab_two_ranks_blocked_preconditioner_on_hip(tmp_path):
+    """256 x 128 x 20: the y- and x-cuts of the P > 1 preconditioner (64 rows, 128 cells) are both active in the slab solver, with ghost
+    planes, obstacle flags and the packed ApplyMatrix -- 2 ranks on the HIP library against the undivided run and against the oracle's
+    2-rank run (same blocked sweeps => same iteration count)"""
+    dims = "256x128x20"
+    single = run_world(tmp_path, 1, "hip", dims=dims)
+    multi = run_world(tmp_path, 2, "hip", dims=dims)
+    assert multi["mic_blocking"] == [(64, 128), (64, 128)] and single["mic_blocking"] == [(0, 0)]
+    check_against_single(single, multi)
+    ora = run_world(tmp_path, 2, "oracle", dims=dims)
+    util.assert_bitexact(multi["dens"], ora["dens"], "density hip vs oracle, 2 slabs")
+    util.assert_bitexact(multi["vel_adv"], ora["vel_adv"], "velocity hip vs oracle, 2 slabs")
+    assert multi["iters"] == ora["iters"]
+    assert util.rel_err(multi["pres"], ora["pres"]) < 1e-4
+    print("CG iterations 256x128x20: undivided %d, 2 slabs with 64 x 128 blocks %d" % (single["iters"][0], multi["iters"][0]))
+
+
 def test_flip_slab_two_ranks_on_hip(tmp_path):
     """FLIP on slabs through the HIP library: migration + reverse halo with 2 ranks on the one GPU; the single-rank HIP run
     equals the oracle's single-rank run bit for bit (positions, P2G sums)"""

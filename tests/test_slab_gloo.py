@@ -34,7 +34,8 @@ def run_world(tmp_path, world, backend, dims="20x16x36"):
     parts = [dict(np.load(out + ".%d.npz" % r)) for r in range(world)]
     cat = lambda k, ax: np.concatenate([p[k] for p in parts], axis=ax)
     return dict(dens=cat("dens", 0), vel_adv=cat("vel_adv", 1), vel=cat("vel", 1), pres=cat("pres", 0), div=cat("div", 0),
-                iters=[int(p["iters"]) for p in parts], res=[float(p["res"]) for p in parts], plain_dens=[p["plain_dens"] for p in parts])
+                iters=[int(p["iters"]) for p in parts], res=[float(p["res"]) for p in parts], plain_dens=[p["plain_dens"] for p in parts],
+                mic_blocking=[tuple(int(v) for v in p["mic_blocking"]) for p in parts])
 
 
 def check_against_single(single, multi):
@@ -80,6 +81,20 @@ def test_single_rank_slab_equals_plugin_path(single, oracle_backend):
 def test_slab_world(tmp_path, single, world):
     multi = run_world(tmp_path, world, "oracle")
     check_against_single(single, multi)
+
+
+def test_slab_world_with_blocked_preconditioner(tmp_path):
+    """A domain wide enough (256 x 128) that BOTH cuts of the P > 1 preconditioner are active in the slab solver (blocks of 64 rows along
+    y and 128 cells along x, on top of the z-cut), together with ghost planes and the packed ApplyMatrix: 2 ranks against the undivided
+    run, at converged-solution level; the iteration counts are logged."""
+    dims = "256x128x20"
+    single = run_world(tmp_path, 1, "oracle", dims)
+    multi = run_world(tmp_path, 2, "oracle", dims)
+    assert single["mic_blocking"] == [(0, 0)]
+    assert multi["mic_blocking"] == [(64, 128), (64, 128)]
+    check_against_single(single, multi)
+    print("CG iterations 256x128x20: undivided %d, 2 slabs with 64 x 128 blocks %d" % (single["iters"][0], multi["iters"][0]))
+    assert multi["iters"][0] < 2.5 * single["iters"][0]
 
 
 # ---- FLIP on slabs (SURVEY 8e: P2G with reverse halo, G2P / advectInGrid with particle migration) ------------------------
