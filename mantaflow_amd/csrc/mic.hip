@@ -638,7 +638,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		const bool pk_live = (tkl > 0) && !(bempty && bempty[tk_pred * nbj + tj]);
 		const bool sj_live = (tjl + 1 < nbj) && (tj / jb == tj_succ / jb) && !(bempty && bempty[tk * nbj + tj_succ]);
 		const bool sk_live = (tkl + 1 < nbk) && !(bempty && bempty[tk_succ * nbj + tj]);
-		const bool has_pj = pj_live && (b == 0), has_pk = pk_live && (c == 0);
 		const int64_t XP = X8 + 2 * ROWS_PAD;
 		if (wave == 6) {
 			// ================= face publisher: the compute wave only leaves its results in the ring; this wave turns the outer rows /
@@ -683,53 +682,42 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			// (Tried on top of this: a second poller wave out of phase with the first (497 instead of 468 us per apply at 256^3), two
 			// polls in flight in this wave with hand-written loads and vmcnt waits (the compiler copies the load targets before the
 			// wait: wrong values), four scalar-path poller waves (tools/micro/rows_scalar_poller.diff: bit-exact, 700+ us).)
-			const unsigned long long* in_j = xj + (sid - 1) * XP * 8 + c;          // + (h + 2) * 8
-			const unsigned long long* in_k = xk + (sid - nbj) * XP * 8 + b;
+			// One load instruction fetches a whole half window of BOTH faces: lane = {face, step within the half window, face lane}
+			// (4 steps x 8 face lanes = 32 granules per face).  Two instructions per poll instead of sixteen 8-lane ones: the
+			// round trip of a poll is that of its slowest load, and every load queues behind the CU's operand stream.
+			const int pf_ = lane >> 5, pr = (lane >> 3) & 3, pidx = lane & 7;
+			const bool plive = pf_ == 0 ? pj_live : pk_live;
+			const unsigned long long* in_f = (pf_ == 0 ? xj + (sid - 1) * XP * 8 : xk + (sid - nbj) * XP * 8) + pidx;     // + (h + 2) * 8
+			float* const sF = pf_ == 0 ? &sFj[0][0][0] : &sFk[0][0][0];       // [block parity][face lane][step]
 #pragma unroll 1
 			for (int m = 0; m <= nchunks + 1; m++) {
-				const int xq = 8 * m - 2 - skew;
-				unsigned long long gj[8], gk[8];
-#pragma unroll
-				for (int a = 0; a < 8; a++) gj[a] = gk[a] = fresh0;
+				// the consumer lane of this granule (b, c) = (0, pidx) resp. (pidx, 0) works on x' = 8m - 2 - pidx + step
+				const int x0 = 8 * m - 2 - pidx + pr;
+				const bool in0 = plive && (unsigned)x0 < (unsigned)X8, in1 = plive && (unsigned)(x0 + 4) < (unsigned)X8;
+				const unsigned long long* p0 = in_f + (int64_t)(8 * m + 7 + pr) * 8;
+				unsigned long long g0 = fresh0, g1 = fresh0;
 				int pub = 0;
 				for (;;) {
-					if (has_pj) {
-#pragma unroll
-						for (int a = 0; a < 8; a++) gj[a] = granule_load(in_j + (int64_t)(8 * m + 7 + a) * 8);
-					}
-					if (has_pk) {
-#pragma unroll
-						for (int a = 0; a < 8; a++) gk[a] = granule_load(in_k + (int64_t)(8 * m + 7 + a) * 8);
-					}
-					// tags only grow: a half window (4 steps) is complete when its smallest tag is this sweep's generation.  The
-					// halves are published separately: the compute wave starts a block on the first one, i.e. a consumer bundle
+					// tags only grow: a half window (4 steps) is complete when every granule in range carries this sweep's generation.
+					// The halves are published separately: the compute wave starts a block on the first one, i.e. a consumer bundle
 					// runs 11 instead of 15 steps behind its producer (7 steps of skew + the granularity of the hand-off).
-					unsigned tminA = gen, tminB = gen;
-#pragma unroll
-					for (int a = 0; a < 8; a++) {
-						const bool in = (unsigned)(xq + a) < (unsigned)X8;
-						const unsigned tj_ = (unsigned)(gj[a] >> 32), tk_ = (unsigned)(gk[a] >> 32);
-						const unsigned tm = in ? min(tj_, tk_) : gen;
-						if (a < 4) tminA = min(tminA, tm);
-						else tminB = min(tminB, tm);
-					}
+					if (pub == 0 && in0) g0 = granule_load(p0);
+					if (in1) g1 = granule_load(p0 + 4 * 8);
 					const bool giveup = ++spins > FLOW_SPIN_LIMIT;
-					if (pub == 0 && (__all(tminA == gen) || giveup)) {
+					if (pub == 0 && (__all((unsigned)(g0 >> 32) == gen) || giveup)) {
 						// the buffer of this parity was read by block m-2
 						if (m >= 2) {
 							while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m - 1) {
 								if (++spins > FLOW_SPIN_LIMIT) break;
-								__builtin_amdgcn_s_sleep(8);
+								__builtin_amdgcn_s_sleep(ROWS_NAP);
 							}
 						}
-						if (b == 0) *(float4*)&sFj[m & 1][c][0] = make_float4(__uint_as_float((unsigned)gj[0]), __uint_as_float((unsigned)gj[1]), __uint_as_float((unsigned)gj[2]), __uint_as_float((unsigned)gj[3]));
-						if (c == 0) *(float4*)&sFk[m & 1][b][0] = make_float4(__uint_as_float((unsigned)gk[0]), __uint_as_float((unsigned)gk[1]), __uint_as_float((unsigned)gk[2]), __uint_as_float((unsigned)gk[3]));
+						sF[((m & 1) * 8 + pidx) * 8 + pr] = __uint_as_float((unsigned)g0);
 						__hip_atomic_store(&s_flags[3], 2 * m + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 						pub = 1;
 					}
-					if (pub == 1 && (__all(tminB == gen) || giveup)) {
-						if (b == 0) *(float4*)&sFj[m & 1][c][4] = make_float4(__uint_as_float((unsigned)gj[4]), __uint_as_float((unsigned)gj[5]), __uint_as_float((unsigned)gj[6]), __uint_as_float((unsigned)gj[7]));
-						if (c == 0) *(float4*)&sFk[m & 1][b][4] = make_float4(__uint_as_float((unsigned)gk[4]), __uint_as_float((unsigned)gk[5]), __uint_as_float((unsigned)gk[6]), __uint_as_float((unsigned)gk[7]));
+					if (pub == 1 && (__all((unsigned)(g1 >> 32) == gen) || giveup)) {
+						sF[((m & 1) * 8 + pidx) * 8 + 4 + pr] = __uint_as_float((unsigned)g1);
 						__hip_atomic_store(&s_flags[3], 2 * m + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 						break;
 					}
