@@ -721,7 +721,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						__hip_atomic_store(&s_flags[3], 2 * m + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 						break;
 					}
-					__builtin_amdgcn_s_sleep(1);
 				}
 			}
 		} else if (wave != 0) {
@@ -1903,8 +1902,10 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				int dev = 0, ncu = 256;
 				(void)hipGetDevice(&dev);
 				(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-				// one bundle per CU measured best (256^3: 834 us per apply with 256 workgroups, 1040 us with 512): the
-				// sweep is bound by the chain of face hand-offs, and a second bundle per CU slows both
+				// one bundle per CU measured best (round 1: 834 us per apply with 256 workgroups, 1040 us with 512).  Round 2, with a
+				// packed-only variant of the kernel (<= 128 VGPRs, 32-step ring = 56 KB of LDS, two workgroups per CU): 445 vs 412 us --
+				// the 32-step ring costs 28 us and the second workgroup per CU gains nothing: mid-sweep the 256 bundles already
+				// stream ~4 TB/s, the rest of the sweep is the dependency chain
 				rwgs = e ? atoi(e) : ncu;
 				if (rwgs < 1) rwgs = 1;
 			}
