@@ -555,8 +555,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	if (sc && sc->done) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7;
 	// (A Gray-coded lane -> k mapping with DPP row_ror:8 / v_permlane16_swap / v_permlane32_swap instead of the ds_bpermute for the
-	// k-neighbour was tried -- tools/micro/permlane_swap.hip: bit-exact, 591 instead of 572 us per apply: the compute wave is bound
-	// by the NUMBER of instructions it issues per step (~8 cycles each), not by the latency of the one LDS permute.)
+	// k-neighbour was tried twice -- tools/micro/permlane_swap.hip: bit-exact, 591 instead of 572 us per apply mid-round and 431 instead
+	// of 412 us on the final kernel: the swaps and the selects behind them are no shorter than the one LDS permute.)
 	const int c = lane >> 3;
 	const int skew = b + c;
 	// the compute wave is the critical path: everything else yields to it
