@@ -581,7 +581,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		if (threadIdx.x == 0) {
 			// xt[0..7] tickets, xt[8..16] bounds of the per-XCD queues inside `order`, xt[17] = number of queues (1: one
 			// global queue; 8: bundles are queued per XCD by k-slab, so that most faces are handed over inside one XCD's L2)
-			const int nq = xt[17];
+			const int nq = xt[17] & 0xff;
 			const int q = nq > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;   // HW_REG_XCC_ID
 			const int lo = xt[8 + q], hi = xt[9 + q];
 			int tk = nstreams;
@@ -651,8 +651,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			const bool live = fsel == 0 ? sj_live : sk_live;
 			unsigned long long* outp = (fsel == 0 ? xj : xk) + sid * XP * 8 + idx;
 			// plain (XCD-local) face stores only when every consumer of this bundle's faces runs on this XCD
-			const int nq_ = xt[17];
-			const bool local_faces = nq_ > 1 && ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk));
+			// (k-slab queues, MF_ROWS_XCD=1: both faces unless the k-successor belongs to the next slab; queues interleaved in k,
+			// MF_ROWS_XCD=2: the j face always -- same tkl, same XCD --, the k face never)
+			const int nq_ = xt[17] & 0xff;
+			const bool inter_ = (xt[17] >> 8) != 0;
+			const bool local_faces = nq_ > 1 && (inter_ ? (fsel == 0) : ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk)));
 			const int nhalf = 2 * (nchunks + 2);
 #pragma unroll 1
 			for (int n = 0; n < nhalf; n++) {
@@ -1640,6 +1643,9 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 	if (nbj > 4095 || nbk > 4095 || nxb > 127) return fail("grid too large for the MIC bundle order table");
 	int jb = jblock_rows > 0 ? jblock_rows / 8 : nbj;
 	if (jb < 1 || jb > nbj) jb = nbj;
+	// MF_ROWS_XCD=1: one ticket queue per XCD = k-slab of bundles (256^3: 549 us per apply, 32 workgroups cannot cover a 4-bundle-wide band);
+	// =2: queues interleaved in k (tkl % 8: balanced; j faces stay inside an XCD's L2, k faces cross): 409 vs 416 us at 256^3, 192 vs 194 at
+	// 128^3, 2023 vs 1963 at 512^3 -- not the default
 	static const int use_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : 0;
 	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
 	if (!f.ctl) {
@@ -1661,7 +1667,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 				if (x < nq)
 					for (int L = 0; L <= nbj + nbk - 2; L++)
 						for (int bk = 0; bk < nbk; bk++) {
-							if ((bk * nq) / nbk != x) continue;
+							if (use_xcd == 2 ? (bk % nq != x) : ((bk * nq) / nbk != x)) continue;
 							for (int bjl = 0; bjl < nbj; bjl++) {
 								const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
 								const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
@@ -1672,7 +1678,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 						}
 			}
 			xt[rev][16] = q;
-			xt[rev][17] = nq;
+			xt[rev][17] = nq | ((nq > 1 && use_xcd == 2) ? 0x100 : 0);      // bit 8: queues interleaved in k (tkl % 8) instead of k-slabs
 		}
 		if (!f.rows_xt) MF_HIP(hipMalloc((void**)&f.rows_xt, sizeof(xt)));
 		MF_HIP(hipMemcpy(f.rows_xt, xt, sizeof(xt), hipMemcpyHostToDevice));
