@@ -858,13 +858,13 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
 			float4 nA = sA[lane];                  // ring row of h = -2 (never valid)
 			float2 nB = sB[lane];
-			const bool tr = trace && (t == trace_ticket || t == trace_ticket2) && lane == 0;
+			const bool tr = trace && (t == trace_ticket || t == trace_ticket2);      // wave-uniform: one scalar branch per stamp
 			long long* trb = trace + (t == trace_ticket2 ? 8 * 4096 : 0);
 			if (trace && lane == 0 && t < 4096) {
 				trace[4 * 4096 + 2 * t] = wall_clock64();
 				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
 			}
-#define ROWS_TRACE(i) if (tr) trb[m * 4 + (i)] = wall_clock64();
+#define ROWS_TRACE(i) if (__builtin_expect(tr, 0)) { if (lane == 0) trb[m * 4 + (i)] = wall_clock64(); }
 			auto block = [&](int m, auto edge_tag) {
 				constexpr bool EDGE = decltype(edge_tag)::value;
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
@@ -918,7 +918,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					const int nrow = ((base + s + 1) & (ROWS_RING - 1)) * 64 + lane;
 					nA = sA[nrow];
 					nB = sB[nrow];
-					const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
+					const float dj = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oj0), 0x111, 0xf, 0xf, true));   // row_shr:1; lanes b == 0 take the face value
 					const float sk = __shfl_up(ok0, 8, 64);
 					const float ij0 = (b == 0) ? gj[s] : dj;
 					const float ik0 = (c == 0) ? gk[s] : sk;
