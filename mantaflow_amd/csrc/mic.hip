@@ -671,7 +671,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					float fv = cA.x;
 					if (MODE == 1) {
 						const float p = sB[slot].x;
-						fv = (cA.x * (fsel == 0 ? cA.z : cA.w)) * p;
+						const float t = cA.x * (fsel == 0 ? cA.z : cA.w);
+						fv = packed ? t : t * p;
 					}
 					if (local_faces) granule_store_local(outp + (int64_t)h2 * 8, fv, gen);
 					else granule_store(outp + (int64_t)h2 * 8, fv, gen);
@@ -800,6 +801,14 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 							cak = r.Ak[a];
 						}
 						const int idx = ((p0 + a) & (ROWS_RING - 1)) * 64 + lane;
+						// packed operands: the ring holds A * Aprecond instead of A.  For A in {+0, -1} (what the packed bytes certify)
+						// (x * A) * p == x * (A * p) bit for bit, for every x and p (signed zeros, infinities and NaNs included): the
+						// compute wave saves a multiplication per neighbour and per step, on its dependency chain
+						if (packed) {
+							cai = cai * r.P[a];
+							caj = caj * r.P[a];
+							cak = cak * r.P[a];
+						}
 						sA[idx] = make_float4((MODE == 1 && fl) ? r.V[a] : r.D[a], cai, caj, cak);
 						sB[idx] = make_float2(r.P[a], fl ? 1.f : 0.f);
 						if (MODE == 2 && with_dot) sR[idx] = r.V[a];     // 0 outside the grid (load_row8)
@@ -865,8 +874,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
 			}
 #define ROWS_TRACE(i) if (__builtin_expect(tr, 0)) { if (lane == 0) trb[m * 4 + (i)] = wall_clock64(); }
-			auto block = [&](int m, auto edge_tag) {
+			auto block = [&](int m, auto edge_tag, auto pre_tag) {
 				constexpr bool EDGE = decltype(edge_tag)::value;
+				constexpr bool PRE = decltype(pre_tag)::value;      // the ring holds A * Aprecond (packed operands)
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
 				ROWS_TRACE(0)
 				// flags and face values in one batch of LDS reads: the LDS serves a wave's requests in order, and the poller
@@ -914,8 +924,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					}
 					const float4 cA = nA;
 					const float2 cB = nB;
-					const int row = ((base + s) & (ROWS_RING - 1)) * 64 + lane;
-					const int nrow = ((base + s + 1) & (ROWS_RING - 1)) * 64 + lane;
+					// base is a multiple of 8: the rows of a block never wrap inside it (immediate LDS offsets from one address)
+					const int row = (base + s) * 64 + lane;
+					const int nrow = (s < 7) ? (base + s + 1) * 64 + lane : ((base + 8) & (ROWS_RING - 1)) * 64 + lane;
 					nA = sA[nrow];
 					nB = sB[nrow];
 					const float dj = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oj0), 0x111, 0xf, 0xf, true));   // row_shr:1; lanes b == 0 take the face value
@@ -930,11 +941,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					if (MODE == 1) {
 						const float nv = p * (val - ii0 - ij0 - ik0);
 						val = fl ? nv : val;
-						oi0 = valid ? (val * ai) * p : 0.f;
-						oj0 = valid ? (val * aj) * p : 0.f;
-						ok0 = valid ? (val * ak) * p : 0.f;
+						oi0 = valid ? (PRE ? val * ai : (val * ai) * p) : 0.f;
+						oj0 = valid ? (PRE ? val * aj : (val * aj) * p) : 0.f;
+						ok0 = valid ? (PRE ? val * ak : (val * ak) * p) : 0.f;
 					} else {
-						const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
+						const float nv = PRE ? p * (val - ii0 * ai - ij0 * aj - ik0 * ak) : p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
 						val = fl ? nv : val;
 						oi0 = oj0 = ok0 = valid ? val : 0.f;
 					}
@@ -955,8 +966,13 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			for (int m = 0; m <= nchunks + 1; m++) {
 				// interior: every lane's x' is inside [0, X8) for all 8 steps of the block
 				const bool interior = (m >= 2 && m <= nchunks - 1);
-				if (interior) block(m, std::false_type{});
-				else block(m, std::true_type{});
+				if (packed) {
+					if (interior) block(m, std::false_type{}, std::true_type{});
+					else block(m, std::true_type{}, std::true_type{});
+				} else {
+					if (interior) block(m, std::false_type{}, std::false_type{});
+					else block(m, std::true_type{}, std::false_type{});
+				}
 			}
 			if (trace && lane == 0 && t < 4096) trace[4 * 4096 + 2 * t + 1] = wall_clock64();
 #undef ROWS_TRACE
