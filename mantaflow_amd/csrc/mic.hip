@@ -1661,14 +1661,18 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 	if (jb < 1 || jb > nbj) jb = nbj;
 	// MF_ROWS_XCD=1: one ticket queue per XCD = k-slab of bundles (256^3: 549 us per apply, 32 workgroups cannot cover a 4-bundle-wide band);
 	// =2: queues interleaved in k (tkl % 8: balanced; j faces stay inside an XCD's L2, k faces cross): 409 vs 416 us at 256^3, 192 vs 194 at
-	// 128^3, 2023 vs 1963 at 512^3 -- not the default
-	static const int use_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : 0;
+	// 128^3, 2023 vs 1963 at 512^3 (mid-round figures)
+	// default: interleaved queues where the sweep is bound by its chain of hand-offs (a few bundles per workgroup: 397 vs 402 us at 256^3),
+	// one global queue where it is bound by the number of workgroups (512^3: 1920 vs 2034 us) or too small to matter
+	static const int env_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : -1;
+	const int nb_all = nbj * nbk * nxb;
+	const int use_xcd = env_xcd >= 0 ? env_xcd : ((nb_all >= 512 && nb_all <= 2048) ? 2 : 0);
 	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
 	if (!f.ctl) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 	}
-	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != nq || f.nxb != nxb) {
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != (nq | (use_xcd << 8)) || f.nxb != nxb) {
 		MF_HIP(hipStreamSynchronize(st));
 		const int nb = nbj * nbk * nxb;
 		int* h = (int*)malloc(sizeof(int) * 2 * nb);
@@ -1723,7 +1727,7 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 		f.nblocks = nb;
 		f.nchunks = nchunks;
 		f.jb = jb;
-		f.nq = nq;
+		f.nq = nq | (use_xcd << 8);
 		f.nxb = nxb;
 	}
 	*out = &f;
