@@ -1662,11 +1662,12 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 	// MF_ROWS_XCD=1: one ticket queue per XCD = k-slab of bundles (256^3: 549 us per apply, 32 workgroups cannot cover a 4-bundle-wide band);
 	// =2: queues interleaved in k (tkl % 8: balanced; j faces stay inside an XCD's L2, k faces cross): 409 vs 416 us at 256^3, 192 vs 194 at
 	// 128^3, 2023 vs 1963 at 512^3 (mid-round figures)
-	// default: interleaved queues where the sweep is bound by its chain of hand-offs (a few bundles per workgroup: 397 vs 402 us at 256^3),
+	// default: interleaved queues where the sweep is bound by its chain of hand-offs (up to ~4 bundles per workgroup: 397 vs 402 us at 256^3,
+	// 269 vs 276 at 192^3; 320^3 already prefers one queue, 645 vs 666),
 	// one global queue where it is bound by the number of workgroups (512^3: 1920 vs 2034 us) or too small to matter
 	static const int env_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : -1;
 	const int nb_all = nbj * nbk * nxb;
-	const int use_xcd = env_xcd >= 0 ? env_xcd : ((nb_all >= 512 && nb_all <= 2048) ? 2 : 0);
+	const int use_xcd = env_xcd >= 0 ? env_xcd : ((nb_all >= 512 && nb_all <= 1280) ? 2 : 0);
 	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
 	if (!f.ctl) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
