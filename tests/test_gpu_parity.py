@@ -93,6 +93,46 @@ def test_mic(hip, oracle, dims):
         assert_bitexact(dst, dst_o, "mic apply")
 
 
+@pytest.mark.parametrize("dims", [(64, 16, 16), (128, 24, 16), (40, 17, 12)])
+def test_mic_apply_signed_zeros_negative_and_huge_operands(hip, oracle, dims):
+    """The packed path of the row sweeps keeps A * Aprecond in its operand ring and forms x * (A * p) where the reference forms
+    (x * A) * p -- equal bit for bit for A in {+0, -1} whatever x and p are.  Checked here on operands the solver never produces:
+    Aprecond with negative, zero, -0.0 and denormal entries, a right-hand side with signed zeros, denormals and values large enough to
+    overflow to +-inf (and then NaN) inside the sweep.  Non-NaN results must agree bit for bit, NaNs must sit in the same cells."""
+    sx, sy, sz = dims
+    flags, A, src = cases.system_inputs(dims, 7)
+    rng = np.random.default_rng(99)
+    src = src.copy()
+    src[rng.random(src.shape) < 0.15] = 0.0
+    src[rng.random(src.shape) < 0.10] = -0.0
+    src[rng.random(src.shape) < 0.03] = np.float32(1e-41)
+    src[rng.random(src.shape) < 0.002] = np.float32(3e37)
+    res = []
+    for impl in (hip, oracle):
+        f = impl.dev(flags)
+        dA = [impl.dev(a) for a in A]
+        ap = impl.dev(np.zeros((sz, sy, sx), np.float32))
+        impl.call("mf_mic_init", sx, sy, sz, f, ap, dA[0], dA[1], dA[2], dA[3], None)
+        impl.sync()
+        ap_h = impl.host(ap).copy()
+        r2 = np.random.default_rng(5)
+        ap_h[r2.random(ap_h.shape) < 0.10] *= np.float32(-1.0)
+        ap_h[r2.random(ap_h.shape) < 0.05] = 0.0
+        ap_h[r2.random(ap_h.shape) < 0.05] = -0.0
+        ap_h[r2.random(ap_h.shape) < 0.02] = np.float32(1e-40)
+        ap2 = impl.dev(ap_h)
+        dst = impl.dev(np.full((sz, sy, sx), 0.25, np.float32))
+        impl.call("mf_mic_apply", sx, sy, sz, f, dst, impl.dev(src), ap2, dA[1], dA[2], dA[3], None)
+        impl.sync()
+        res.append(impl.host(dst))
+    got, want = res
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), "NaNs in different cells: %d vs %d" % (nan_g.sum(), nan_w.sum())
+    assert (~nan_w).sum() > 0.2 * want.size
+    assert np.array_equal(got[~nan_w].view(np.uint32), want[~nan_w].view(np.uint32)), "finite results differ in %d cells" % (
+        (got[~nan_w].view(np.uint32) != want[~nan_w].view(np.uint32)).sum())
+
+
 @pytest.mark.parametrize("mode", ["rows", "rows-sb", "tiles", "levels"])
 @pytest.mark.parametrize("dims", [(32, 24, 40), (37, 21, 19), (64, 64, 64), (24, 40, 9), (16, 8, 136), (40, 33, 27), (128, 40, 24), (32, 8, 8),
                                   (96, 72, 17)])
