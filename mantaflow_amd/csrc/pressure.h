@@ -7,6 +7,7 @@
 struct CgScalars {
 	float sigma, alpha, nalpha, beta, resNorm, dp, sigmaNew, accuracy;
 	int iterations, done, diverged, useL2;
+	int xpending;     // mf_cg_solve only: this iteration's dst += alpha * search is still to be done (by k_cg_update_search_x)
 };
 
 namespace mf {

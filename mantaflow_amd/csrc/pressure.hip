@@ -615,11 +615,17 @@ __global__ void __launch_bounds__(BLOCK) k_cg_begin(CgScalars* sc, int nb, const
 }
 // alpha = sigma / dp, conjugategrad.cpp:250-252
 __global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const double* __restrict__ partials) {
-	if (sc->done) return;
+	if (sc->done) {
+		if (threadIdx.x == 0) sc->xpending = 0;
+		return;
+	}
 	if (sc->diverged) {
 		// the iteration that diverged has finished its search update (the reference throws after it): stop everything queued
 		// behind it.  (This iteration's ApplyMatrix has already run; it only wrote tmp.)
-		if (threadIdx.x == 0) sc->done = 1;
+		if (threadIdx.x == 0) {
+			sc->done = 1;
+			sc->xpending = 0;
+		}
 		return;
 	}
 	double acc = strided_sum(partials, nb);
@@ -632,6 +638,55 @@ __global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const
 		sc->alpha = alpha;
 		sc->nalpha = -alpha;
 		sc->iterations++;
+		sc->xpending = 1;
+	}
+}
+// residual += (-alpha)*tmp ; [PC_NONE: tmp = residual] ; partial min/max (or sum of squares) of the new residual: k_cg_axpy2 without
+// the dst update, which mf_cg_solve leaves to k_cg_update_search_x (one pass over `search` less per iteration)
+template <bool COPY_TMP>
+__global__ void __launch_bounds__(BLOCK)
+k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart,
+            double* __restrict__ dpart) {
+	if (sc->done) return;
+	const float nalpha = sc->nalpha;
+	const bool l2 = sc->useL2 != 0;
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	double ss = 0.0;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		float4 r = ((float4*)residual)[q];
+		const float4 t = ((const float4*)tmp)[q];
+		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
+		((float4*)residual)[q] = r;
+		if (COPY_TMP) ((float4*)tmp)[q] = r;
+		if (l2) {
+			ss += (double)r.x * (double)r.x;
+			ss += (double)r.y * (double)r.y;
+			ss += (double)r.z * (double)r.z;
+			ss += (double)r.w * (double)r.w;
+		} else {
+			lo = fminf(fminf(lo, r.x), fminf(r.y, fminf(r.z, r.w)));
+			hi = fmaxf(fmaxf(hi, r.x), fmaxf(r.y, fmaxf(r.z, r.w)));
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		const float r = residual[i] + nalpha * tmp[i];
+		residual[i] = r;
+		if (COPY_TMP) tmp[i] = r;
+		if (l2) ss += (double)r * (double)r;
+		lo = fminf(lo, r);
+		hi = fmaxf(hi, r);
+	}
+	if (l2) {
+		ss = block_sum(ss);
+		if (threadIdx.x == 0) dpart[blockIdx.x] = ss;
+	} else {
+		block_minmax(lo, hi);
+		if (threadIdx.x == 0) {
+			fpart[2 * blockIdx.x] = lo;
+			fpart[2 * blockIdx.x + 1] = hi;
+		}
 	}
 }
 // dst += alpha*search ; residual += (-alpha)*tmp ; [PC_NONE: tmp = residual] ; partial min/max (or sum of
@@ -769,6 +824,33 @@ k_cg_update_search(int64_t n, CgScalars* __restrict__ sc, float* __restrict__ se
 	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
 		const int64_t i = (n4 << 2) + threadIdx.x;
 		search[i] = tmp[i] + beta * search[i];
+	}
+}
+
+// dst += alpha*search (conjugategrad.cpp:254, left over from this iteration: xpending) and, unless the iteration has converged,
+// search = tmp + beta*search (:283) -- `search` is read once for both
+__global__ void __launch_bounds__(BLOCK)
+k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp) {
+	if (!sc->xpending) return;
+	const bool upd = !sc->done;
+	const float alpha = sc->alpha, beta = sc->beta;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		float4 s = ((float4*)search)[q];
+		float4 x = ((float4*)dst)[q];
+		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
+		((float4*)dst)[q] = x;
+		if (upd) {
+			const float4 t = ((const float4*)tmp)[q];
+			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
+			((float4*)search)[q] = s;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		const float s = search[i];
+		dst[i] = dst[i] + alpha * s;
+		if (upd) search[i] = tmp[i] + beta * s;
 	}
 }
 
@@ -1045,19 +1127,19 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
-				hipLaunchKernelGGL((k_cg_axpy2<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
+				hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
 				// sigma_new = dot(tmp, residual) comes out of the backward sweep's write-back (one partial per row bundle)
 				MF_TRY(mic_launch_dot(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, p_sig, &nsig, st));
 			} else {
-				hipLaunchKernelGGL((k_cg_axpy2<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, residual, tmp, p_mm, p_res);
+				hipLaunchKernelGGL((k_cg_axpy_r<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 			}
 			if (nsig == 0) {
 				hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
 				nsig = nbs;
 			}
 			hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
-			hipLaunchKernelGGL(k_cg_update_search, dim3(nbs), dim3(BLOCK), 0, st, n, sc, search, tmp);
+			hipLaunchKernelGGL(k_cg_update_search_x, dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
 		}
 		MF_LAUNCH_CHECK();
 		issued += todo;
