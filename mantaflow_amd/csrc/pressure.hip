@@ -643,6 +643,9 @@ __global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const
 }
 // residual += (-alpha)*tmp ; [PC_NONE: tmp = residual] ; partial min/max (or sum of squares) of the new residual: k_cg_axpy2 without
 // the dst update, which mf_cg_solve leaves to k_cg_update_search_x (one pass over `search` less per iteration)
+// (Folding this pass into the loader waves of the forward MIC sweep -- they read residual and tmp anyway -- was built and measured:
+// bit-exact, the 30 us of this kernel go away and the sweep gets 21 us slower (its middle third already streams ~4 TB/s): 75.5 ms per
+// 256^3 step either way.  Not kept.)
 template <bool COPY_TMP>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart,
