@@ -990,6 +990,329 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// InitPreconditionModifiedIncompCholesky2 (conjugategrad.cpp:66-97) as a row-streaming dataflow sweep: the forward sweep's roles and
+// hand-off machinery (k_mic_rows), one launch instead of one per tile hyperplane (94 at 256^3).  Differences: the operands are A0,
+// Ai, Aj, Ak and the flags (nothing is packed yet -- mf_mic_init builds the packed bytes from its own output), and TWO values cross
+// every neighbour relation: (A_dir * Aprecond)^2 and A_dir * (A_o1 + A_o2) * Aprecond^2 of the predecessor cell -- two DPP moves,
+// two LDS permutes, two granules per face lane and step (arrays xj / xj1, xk / xk1).  Per-cell arithmetic = k_mic_tiles<0>.
+// ---------------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(ROWS_THREADS)
+k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
+                unsigned long long* xj, unsigned long long* xk, unsigned long long* xj1, unsigned long long* xk1, unsigned gen,
+                const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ A0,
+                const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak) {
+	constexpr bool REV = false;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
+	const int skew = b + c;
+	if (wave == 0) __builtin_amdgcn_s_setprio(3);
+	else __builtin_amdgcn_s_setprio(0);
+	__shared__ float4 sA[ROWS_RING * 64];   // {fluid ? A0 : 0  (-> Aprecond), Ai, Aj, Ak}     index = ((h + 2) & (ROWS_RING - 1)) * 64 + lane
+	__shared__ float sB[ROWS_RING * 64];    // fluid
+	__shared__ __attribute__((aligned(16))) float sFj[2][2][8][8];     // [value][block parity][face lane][step]
+	__shared__ __attribute__((aligned(16))) float sFk[2][2][8][8];
+	__shared__ __attribute__((aligned(16))) int s_flags[4];
+	__shared__ int s_done, s_flushed, s_ticket, s_half, s_pub;
+	int* const s_ready = s_flags;
+	const unsigned long long fresh0 = (unsigned long long)gen << 32;
+	const int X8 = nchunks * 8;
+	int spins = 0;
+
+	for (;;) {
+		if (threadIdx.x == 0) {
+			const int nq = xt[17] & 0xff;
+			const int q = nq > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;   // HW_REG_XCC_ID
+			const int lo = xt[8 + q], hi = xt[9 + q];
+			int tk = nstreams;
+			if (lo < hi) {
+				const int tl = atomicAdd(&xt[q], 1);
+				if (lo + tl < hi) tk = lo + tl;
+			}
+			s_ticket = tk;
+			s_ready[0] = s_ready[1] = s_ready[2] = 0;
+			s_done = 0;
+			s_flushed = 0;
+			s_flags[3] = 0;
+			s_half = 0;
+			s_pub = 0;
+		}
+		__syncthreads();
+		const int t = s_ticket;
+		if (t >= nstreams) break;
+		const int pk = order[t];
+		const int tjl = pk & 0xfff, tkl = (pk >> 12) & 0xfff, xb = pk >> 24;
+		const int tj = tjl, tk = tkl;
+		const int j = tj * 8 + b, k = tk * 8 + c;
+		const bool row_in = (j < d.sy) && (k < d.sz);
+		const int xoff = xb * X8;
+		const int xlim = d.sx - xoff < X8 ? d.sx - xoff : X8;
+		const int64_t rowbase = d.Y * j + d.Z * k + xoff;
+		const int64_t sid = ((int64_t)xb * nbk + tkl) * nbj + tjl;
+		const bool pj_live = (tjl > 0) && (tj / jb == (tj - 1) / jb);
+		const bool pk_live = (tkl > 0);
+		const bool sj_live = (tjl + 1 < nbj) && (tj / jb == (tj + 1) / jb);
+		const bool sk_live = (tkl + 1 < nbk);
+		const int64_t XP = X8 + 2 * ROWS_PAD;
+		if (wave == 6) {
+			// ================= face publisher: both hand-off values of the outer rows / columns, recomputed from the ring =========
+			const int fsel = lane >> 5, idx = (lane >> 2) & 7, st = lane & 3;
+			const int L = fsel == 0 ? idx * 8 + 7 : 56 + idx;
+			const int skewL = (L & 7) + (L >> 3);
+			const bool live = fsel == 0 ? sj_live : sk_live;
+			unsigned long long* out0 = (fsel == 0 ? xj : xk) + sid * XP * 8 + idx;
+			unsigned long long* out1 = (fsel == 0 ? xj1 : xk1) + sid * XP * 8 + idx;
+			const int nq_ = xt[17] & 0xff;
+			const bool inter_ = (xt[17] >> 8) != 0;
+			const bool local_faces = nq_ > 1 && (inter_ ? (fsel == 0) : ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk)));
+			const int nhalf = 2 * (nchunks + 2);
+#pragma unroll 1
+			for (int n = 0; n < nhalf; n++) {
+				while (__hip_atomic_load(&s_half, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				const int h2 = 4 * n + st;
+				const int xg = h2 - 2 - skewL;
+				if (live && (unsigned)xg < (unsigned)X8) {
+					const int slot = (h2 & (ROWS_RING - 1)) * 64 + L;
+					const float4 cA = sA[slot];
+					const float ap = cA.x;
+					const float adir = fsel == 0 ? cA.z : cA.w;
+					const float osum = fsel == 0 ? (cA.y + cA.w) : (cA.y + cA.z);
+					const float t_ = adir * ap;
+					const float ap2 = ap * ap;
+					const float h0 = t_ * t_;
+					const float h1 = adir * osum * ap2;
+					if (local_faces) {
+						granule_store_local(out0 + (int64_t)h2 * 8, h0, gen);
+						granule_store_local(out1 + (int64_t)h2 * 8, h1, gen);
+					} else {
+						granule_store(out0 + (int64_t)h2 * 8, h0, gen);
+						granule_store(out1 + (int64_t)h2 * 8, h1, gen);
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+				__hip_atomic_store(&s_pub, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		} else if (wave == 5) {
+			// ================= face poller: one load per half window, face and value array =================
+			const int pf_ = lane >> 5, pr = (lane >> 3) & 3, pidx = lane & 7;
+			const bool plive = pf_ == 0 ? pj_live : pk_live;
+			const int64_t foff = (pf_ == 0 ? (sid - 1) : (sid - nbj)) * XP * 8 + pidx;
+			const unsigned long long* in_f0 = (pf_ == 0 ? xj : xk) + foff;
+			const unsigned long long* in_f1 = (pf_ == 0 ? xj1 : xk1) + foff;
+			float* const sF0 = pf_ == 0 ? &sFj[0][0][0][0] : &sFk[0][0][0][0];
+			float* const sF1 = pf_ == 0 ? &sFj[1][0][0][0] : &sFk[1][0][0][0];
+#pragma unroll 1
+			for (int m = 0; m <= nchunks + 1; m++) {
+				const int x0 = 8 * m - 2 - pidx + pr;
+				const bool in0 = plive && (unsigned)x0 < (unsigned)X8, in1 = plive && (unsigned)(x0 + 4) < (unsigned)X8;
+				const int64_t r0 = (int64_t)(8 * m + 7 + pr) * 8;
+				unsigned long long g0a = fresh0, g0b = fresh0, g1a = fresh0, g1b = fresh0;
+				int pub = 0;
+				for (;;) {
+					if (pub == 0 && in0) {
+						g0a = granule_load(in_f0 + r0);
+						g0b = granule_load(in_f1 + r0);
+					}
+					if (in1) {
+						g1a = granule_load(in_f0 + r0 + 4 * 8);
+						g1b = granule_load(in_f1 + r0 + 4 * 8);
+					}
+					const bool giveup = ++spins > FLOW_SPIN_LIMIT;
+					if (pub == 0 && (__all((unsigned)(g0a >> 32) == gen && (unsigned)(g0b >> 32) == gen) || giveup)) {
+						if (m >= 2) {
+							while (__hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < m - 1) {
+								if (++spins > FLOW_SPIN_LIMIT) break;
+								__builtin_amdgcn_s_sleep(ROWS_NAP);
+							}
+						}
+						sF0[((m & 1) * 8 + pidx) * 8 + pr] = __uint_as_float((unsigned)g0a);
+						sF1[((m & 1) * 8 + pidx) * 8 + pr] = __uint_as_float((unsigned)g0b);
+						__hip_atomic_store(&s_flags[3], 2 * m + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						pub = 1;
+					}
+					if (pub == 1 && (__all((unsigned)(g1a >> 32) == gen && (unsigned)(g1b >> 32) == gen) || giveup)) {
+						sF0[((m & 1) * 8 + pidx) * 8 + 4 + pr] = __uint_as_float((unsigned)g1a);
+						sF1[((m & 1) * 8 + pidx) * 8 + 4 + pr] = __uint_as_float((unsigned)g1b);
+						__hip_atomic_store(&s_flags[3], 2 * m + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						break;
+					}
+				}
+			}
+		} else if (wave != 0) {
+			auto chunk_geom = [&](int m, int64_t& rowidx, int& nv) {
+				const int x0 = m * 8;
+				const int nvx = xlim - x0 < 8 ? xlim - x0 : 8;
+				nv = row_in ? nvx : 0;
+				rowidx = rowbase + x0;
+			};
+			auto wait_for = [&](int* flag, int need) {
+				while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(ROWS_NAP);
+				}
+			};
+			if (wave <= 3) {
+				// ================= loaders =================
+				const int w = wave - 1;
+#pragma unroll 1
+				for (int n = w; n < nchunks; n += 3) {
+					int64_t rowidx;
+					int nv;
+					chunk_geom(n, rowidx, nv);
+					int rF[8];
+					float r0[8], ri[8], rj[8], rk[8];
+					load_row8i<VEC, REV>(flags, rowidx, nv, rF);
+					load_row8<VEC, REV>(A0, rowidx, nv, r0);
+					load_row8<VEC, REV>(Ai, rowidx, nv, ri);
+					load_row8<VEC, REV>(Aj, rowidx, nv, rj);
+					load_row8<VEC, REV>(Ak, rowidx, nv, rk);
+					if (n >= ROWS_RING / 8) wait_for(&s_flushed, n - ROWS_RING / 8 + 1);
+					if (n >= ROWS_RING / 8) wait_for(&s_pub, 2 * (n - ROWS_RING / 8 + 2) + 2);
+					const int p0 = 8 * n + skew + 2;
+#pragma unroll
+					for (int a = 0; a < 8; a++) {
+						const bool fl = (a < nv) && (rF[a] & MF_FLUID);
+						const int idx = ((p0 + a) & (ROWS_RING - 1)) * 64 + lane;
+						sA[idx] = make_float4(fl ? r0[a] : 0.f, ri[a], rj[a], rk[a]);
+						sB[idx] = fl ? 1.f : 0.f;
+					}
+					__hip_atomic_store(&s_ready[w], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			} else {
+				// ================= write-back: Aprecond of finished chunks =================
+#pragma unroll 1
+				for (int q = 0; q < nchunks; q++) {
+					wait_for(&s_done, q + 3);
+					int64_t rowidx;
+					int nv;
+					chunk_geom(q, rowidx, nv);
+					const int p0 = 8 * q + skew + 2;
+					float w[8];
+#pragma unroll
+					for (int e = 0; e < 8; e++) w[e] = sA[((p0 + e) & (ROWS_RING - 1)) * 64 + lane].x;
+					__hip_atomic_store(&s_flushed, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (VEC) {
+						if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
+						if (nv > 4) *(float4*)(dst + rowidx + 4) = make_float4(w[4], w[5], w[6], w[7]);
+					} else {
+#pragma unroll
+						for (int e = 0; e < 8; e++)
+							if (e < nv) dst[rowidx + e] = w[e];
+					}
+				}
+			}
+		} else {
+			// ================= compute wave =================
+			float oi0 = 0.f, oi1 = 0.f, oj0 = 0.f, oj1 = 0.f, ok0 = 0.f, ok1 = 0.f;
+			float4 nA = sA[lane];
+			float nB = sB[lane];
+			typedef int rows_i4 __attribute__((ext_vector_type(4)));
+			typedef float rows_f4 __attribute__((ext_vector_type(4)));
+			typedef const volatile __attribute__((address_space(3))) rows_i4* lflags;
+			typedef const volatile __attribute__((address_space(3))) rows_f4* lface;
+			auto block = [&](int m, auto edge_tag) {
+				constexpr bool EDGE = decltype(edge_tag)::value;
+				const int xq = 8 * m - 2 - skew;
+				rows_f4 f[8];      // {j h0, j h1, k h0, k h1} x {first, second half}
+				const int r3 = m % 3;
+				bool have2;
+				for (;;) {
+					const rows_i4 fg = *(lflags)s_flags;
+#pragma unroll
+					for (int v = 0; v < 2; v++) {
+						f[v * 2 + 0] = *(lface)&sFj[v][m & 1][c][0];
+						f[v * 2 + 1] = *(lface)&sFj[v][m & 1][c][4];
+						f[4 + v * 2 + 0] = *(lface)&sFk[v][m & 1][b][0];
+						f[4 + v * 2 + 1] = *(lface)&sFk[v][m & 1][b][4];
+					}
+					const int rdy = r3 == 0 ? fg.x : (r3 == 1 ? fg.y : fg.z);
+					have2 = fg.w >= 2 * m + 2;
+					if (((m >= nchunks) || rdy >= m + 1) && fg.w >= 2 * m + 1) break;
+					if (++spins > FLOW_SPIN_LIMIT) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+				const int base = (8 * m) & (ROWS_RING - 1);
+#pragma unroll
+				for (int s = 0; s < 8; s++) {
+					if (s == 4 && !have2) {
+						for (;;) {
+							const int fw = *(const volatile __attribute__((address_space(3))) int*)&s_flags[3];
+#pragma unroll
+							for (int v = 0; v < 2; v++) {
+								f[v * 2 + 1] = *(lface)&sFj[v][m & 1][c][4];
+								f[4 + v * 2 + 1] = *(lface)&sFk[v][m & 1][b][4];
+							}
+							if (fw >= 2 * m + 2 || ++spins > FLOW_SPIN_LIMIT) break;
+							__builtin_amdgcn_s_sleep(1);
+						}
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+					}
+					const float4 cA = nA;
+					const bool fl = nB != 0.f;
+					const int row = (base + s) * 64 + lane;
+					const int nrow = (s < 7) ? (base + s + 1) * 64 + lane : ((base + 8) & (ROWS_RING - 1)) * 64 + lane;
+					nA = sA[nrow];
+					nB = sB[nrow];
+					const float dj0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oj0), 0x111, 0xf, 0xf, true));
+					const float dj1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oj1), 0x111, 0xf, 0xf, true));
+					const float sk0 = __shfl_up(ok0, 8, 64), sk1 = __shfl_up(ok1, 8, 64);
+					const int hs = s >> 2, es = s & 3;
+					const float ij0 = (b == 0) ? f[0 + hs][es] : dj0, ij1 = (b == 0) ? f[2 + hs][es] : dj1;
+					const float ik0 = (c == 0) ? f[4 + hs][es] : sk0, ik1 = (c == 0) ? f[6 + hs][es] : sk1;
+					const float ii0 = oi0, ii1 = oi1;
+					const bool valid = !EDGE || ((unsigned)(xq + s) < (unsigned)X8);
+					const float a0 = cA.x, ai = cA.y, aj = cA.z, ak = cA.w;
+					float ap = 0.f;
+					if (fl) {
+						float e = a0 - ii0 - ij0 - ik0;
+						const float s3 = ii1 + ij1 + ik1;
+						// e -= tau * ( ... + 0. ): fp64 product and subtraction, conjugategrad.cpp:84-88
+						const float tau = 0.97f;
+						e = (float)((double)e - (double)tau * ((double)s3 + 0.));
+						if (e < 0.25f * a0) e = a0;
+						ap = (float)(1. / (double)sqrtf(e));
+					}
+					const float ti_ = ai * ap, tj_ = aj * ap, tk_ = ak * ap;
+					const float ap2 = ap * ap;
+					oi0 = valid ? ti_ * ti_ : 0.f;
+					oj0 = valid ? tj_ * tj_ : 0.f;
+					ok0 = valid ? tk_ * tk_ : 0.f;
+					oi1 = valid ? ai * (aj + ak) * ap2 : 0.f;
+					oj1 = valid ? aj * (ai + ak) * ap2 : 0.f;
+					ok1 = valid ? ak * (ai + aj) * ap2 : 0.f;
+					if (valid) sA[row].x = ap;
+					if (s == 3) {
+						asm volatile("" ::: "memory");
+						*(volatile __attribute__((address_space(3))) int*)&s_half = 2 * m + 1;
+					}
+				}
+				asm volatile("" ::: "memory");
+				*(volatile __attribute__((address_space(3))) int*)&s_done = m + 1;
+				*(volatile __attribute__((address_space(3))) int*)&s_half = 2 * m + 2;
+			};
+#pragma unroll 1
+			for (int m = 0; m <= nchunks + 1; m++) {
+				const bool interior = (m >= 2 && m <= nchunks - 1);
+				if (interior) block(m, std::false_type{});
+				else block(m, std::true_type{});
+			}
+		}
+		__syncthreads();
+	}
+	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+	if (threadIdx.x == 0) {
+		const int f = atomicAdd(&ctl->finished, 1);
+		if (f == (int)gridDim.x - 1) {
+			for (int q = 0; q < 8; q++) xt[q] = 0;
+			ctl->finished = 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // MIC apply, "super-bundle" form of the row-streaming sweeps (k_mic_sb): ONE workgroup owns 2 x 2 bundles of 8 x 8 x-rows.
 // What bounds k_mic_rows is the chain of face hand-offs between workgroups (62 at 256^3, each = 15 steps of structural lag +
 // a global store -> poll round trip).  Here four compute waves (one per SIMD) sweep the four sub-bundles of a 16 x 16 block of
@@ -1565,6 +1888,7 @@ struct FlowState {
 	int upack_ok_host = 0;
 	const void *up_flags = nullptr, *up_Ai = nullptr, *up_Aj = nullptr, *up_Ak = nullptr;
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
+	unsigned long long *sxj1 = nullptr, *sxk1 = nullptr;      // second hand-off value of the init sweep (k_mic_rows_init)
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
 	int* order = nullptr;
@@ -1717,10 +2041,16 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 			// scalar-path poller waves (s_load_dwordx16 glc, 0.45 us per hand-off in the micro-benchmark): bit-exact, 700+ us)
 			MF_HIP(hipMalloc((void**)&f.sxj, need));
 			MF_HIP(hipMalloc((void**)&f.sxk, need));
+			if (f.sxj1) MF_HIP(hipFree(f.sxj1));
+			if (f.sxk1) MF_HIP(hipFree(f.sxk1));
+			MF_HIP(hipMalloc((void**)&f.sxj1, need));
+			MF_HIP(hipMalloc((void**)&f.sxk1, need));
 			f.sx_cap = need;
 		}
 		MF_HIP(hipMemset(f.sxj, 0, f.sx_cap));
 		MF_HIP(hipMemset(f.sxk, 0, f.sx_cap));
+		MF_HIP(hipMemset(f.sxj1, 0, f.sx_cap));
+		MF_HIP(hipMemset(f.sxk1, 0, f.sx_cap));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 		f.sgen = 0;
 		f.nbj = nbj;
@@ -1901,6 +2231,8 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			if (f->sgen == 0) {
 				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
 				MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
+				MF_HIP(hipMemsetAsync(f->sxj1, 0, f->sx_cap, st));
+				MF_HIP(hipMemsetAsync(f->sxk1, 0, f->sx_cap, st));
 				f->sgen = 1;
 			}
 			// ---- super-bundle sweeps: the uncut system mf_mic_init registered, packed coefficients exact, every bundle swept ----
@@ -2125,7 +2457,33 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 	const Dim d = mkdim(sx, sy, sz);
 	if (!d.is3d) return fail("mICP only supports 3D grids so far");
 	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, (hipStream_t)stream));
-	MF_TRY(mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream));
+	// "rows" mode: one dataflow sweep (k_mic_rows_init); MF_MIC_INIT_LEVELS=1 or another mode: one launch per tile hyperplane
+	static const bool init_levels = getenv("MF_MIC_INIT_LEVELS") != nullptr;
+	if (mic_mode_() == 2 && !init_levels) {
+		hipStream_t st = (hipStream_t)stream;
+		FlowState* f;
+		MF_TRY(rows_prepare(d, &f, st, rows_j, cells_x));
+		f->sgen++;
+		if (f->sgen == 0) {
+			MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
+			MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
+			MF_HIP(hipMemsetAsync(f->sxj1, 0, f->sx_cap, st));
+			MF_HIP(hipMemsetAsync(f->sxk1, 0, f->sx_cap, st));
+			f->sgen = 1;
+		}
+		int dev = 0, ncu = 256;
+		(void)hipGetDevice(&dev);
+		(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+		const int grid = f->nblocks < ncu ? f->nblocks : ncu;
+		const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(Aprecond) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
+		if (vec)
+			hipLaunchKernelGGL((k_mic_rows_init<true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
+		else
+			hipLaunchKernelGGL((k_mic_rows_init<false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
+		MF_LAUNCH_CHECK();
+	} else {
+		MF_TRY(mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream));
+	}
 	if (mic_mode_() == 2) {
 		// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
 		FlowState* f;
