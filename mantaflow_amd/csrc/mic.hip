@@ -1793,15 +1793,27 @@ k_mic_sb(Dim d, int nbj, int nbk, int nsj, int nsb, int nchunks, const int* __re
 // one byte per cell: bit 0 fluid, bits 1..3 "Ai / Aj / Ak is -1"; ok[0] is cleared when a coefficient is neither +0 nor -1
 // (second-order boundaries, a caller's own matrix): the sweeps then read the four arrays themselves
 __global__ void __launch_bounds__(BLOCK)
-k_mic_pack(int64_t n, const int32_t* __restrict__ flags, const float* __restrict__ Ai, const float* __restrict__ Aj,
-           const float* __restrict__ Ak, unsigned char* __restrict__ pack, int* __restrict__ ok) {
+k_mic_pack(int64_t n, const int32_t* __restrict__ flags, const float* __restrict__ A0, const float* __restrict__ Ai,
+           const float* __restrict__ Aj, const float* __restrict__ Ak, unsigned char* __restrict__ pack, int* __restrict__ ok) {
 	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
 	if (idx >= n) return;
 	const unsigned ui = __float_as_uint(Ai[idx]), uj = __float_as_uint(Aj[idx]), uk = __float_as_uint(Ak[idx]);
 	const unsigned M1 = 0xBF800000u;   // -1.0f
 	const bool good = (ui == 0u || ui == M1) && (uj == 0u || uj == M1) && (uk == 0u || uk == M1);
 	if (!good) ok[0] = 0;
-	pack[idx] = (unsigned char)(((flags[idx] & MF_FLUID) ? 1u : 0u) | (ui == M1 ? 2u : 0u) | (uj == M1 ? 4u : 0u) | (uk == M1 ? 8u : 0u));
+	const bool fl = (flags[idx] & MF_FLUID) != 0;
+	// bits 4-7: the diagonal A0 of a fluid cell when it is a small non-negative integer (MakeLaplaceMatrix counts the non-obstacle
+	// neighbours: 0..6) -- ok[1] stays non-zero when that holds for every fluid cell, and ApplyMatrix then does not read A0 at all
+	unsigned a0code = 0u;
+	if (A0 == nullptr) {
+		if (idx == 0) ok[1] = 0;
+	} else if (fl) {
+		const float v = A0[idx];
+		const int iv = (int)v;
+		if (v == (float)iv && iv >= 0 && iv <= 15) a0code = (unsigned)iv;
+		else ok[1] = 0;
+	}
+	pack[idx] = (unsigned char)((fl ? 1u : 0u) | (ui == M1 ? 2u : 0u) | (uj == M1 ? 4u : 0u) | (uk == M1 ? 8u : 0u) | (a0code << 4));
 }
 
 // the coefficient word of k_mic_sb, one per cell: bytes {Ai == -1 ? 0xBC : 0, Aj ..., Ak ..., fluid ? 0 : 0x80} -- 0xBC00 is fp16 -1.0, so
@@ -1880,7 +1892,7 @@ struct FlowState {
 	unsigned char* pack = nullptr;
 	int* pack_ok = nullptr;
 	size_t pack_cap = 0;
-	const void *pk_flags = nullptr, *pk_Ai = nullptr, *pk_Aj = nullptr, *pk_Ak = nullptr;
+	const void *pk_flags = nullptr, *pk_Ai = nullptr, *pk_Aj = nullptr, *pk_Ak = nullptr, *pk_A0 = nullptr;
 	// a second set of packed bytes, built on request (mf_pack_matrix) for the plain mf_apply_matrix entry point
 	unsigned char* upack = nullptr;
 	int* upack_ok = nullptr;
@@ -2096,9 +2108,9 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 		MF_HIP(hipMalloc((void**)&f.upack, (size_t)d.n + 64));
 		f.upack_cap = (size_t)d.n;
 	}
-	if (!f.upack_ok) MF_HIP(hipMalloc((void**)&f.upack_ok, sizeof(int)));
-	MF_HIP(hipMemsetAsync(f.upack_ok, 1, sizeof(int), st));
-	hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, flags, Ai, Aj, Ak, f.upack, f.upack_ok);
+	if (!f.upack_ok) MF_HIP(hipMalloc((void**)&f.upack_ok, 2 * sizeof(int)));
+	MF_HIP(hipMemsetAsync(f.upack_ok, 1, 2 * sizeof(int), st));
+	hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, flags, (const float*)nullptr, Ai, Aj, Ak, f.upack, f.upack_ok);
 	MF_LAUNCH_CHECK();
 	int ok = 0;
 	MF_HIP(hipMemcpyAsync(&ok, f.upack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2404,19 +2416,22 @@ int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* 
 }
 // the packed flags/Ai/Aj/Ak bytes mf_mic_init built for exactly these grids, if every coefficient was +0 or -1 (one small
 // device-to-host read, i.e. a stream synchronisation: call it once per solve); *pack = nullptr otherwise
-int mic_pack_query(const Dim& d, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, const unsigned char** pack,
-                   hipStream_t st) {
+int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak,
+                   const unsigned char** pack, bool* a0_packed, hipStream_t st) {
 	*pack = nullptr;
+	*a0_packed = false;
 	static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
+	static const bool noa0 = getenv("MF_AM_NOA0PACK") != nullptr;
 	if (nopack || mic_mode_() != 2 || !d.is3d) return 0;
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
 	if (!f.pack || !f.pack_ok || f.pk_flags != flags || f.pk_Ai != Ai || f.pk_Aj != Aj || f.pk_Ak != Ak) return 0;
-	int ok = 0;
-	MF_HIP(hipMemcpyAsync(&ok, f.pack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+	int ok[2] = {0, 0};
+	MF_HIP(hipMemcpyAsync(ok, f.pack_ok, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
 	MF_HIP(hipStreamSynchronize(st));
-	if (ok) *pack = f.pack;
+	if (ok[0]) *pack = f.pack;
+	*a0_packed = ok[0] && ok[1] && !noa0 && f.pk_A0 == A0 && A0 != nullptr;
 	return 0;
 }
 // packed bytes built by mf_pack_matrix for exactly these grids (no synchronisation: the verdict was read when they were built)
@@ -2511,9 +2526,10 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 			MF_HIP(hipMalloc((void**)&f->pack, (size_t)d.n + 64));
 			f->pack_cap = (size_t)d.n;
 		}
-		if (!f->pack_ok) MF_HIP(hipMalloc((void**)&f->pack_ok, sizeof(int)));
-		MF_HIP(hipMemsetAsync(f->pack_ok, 1, sizeof(int), (hipStream_t)stream));     // non-zero = valid until k_mic_pack clears it
-		hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d.n, flags, Ai, Aj, Ak, f->pack, f->pack_ok);
+		if (!f->pack_ok) MF_HIP(hipMalloc((void**)&f->pack_ok, 2 * sizeof(int)));
+		MF_HIP(hipMemsetAsync(f->pack_ok, 1, 2 * sizeof(int), (hipStream_t)stream));     // non-zero = valid until k_mic_pack clears it
+		hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d.n, flags, A0, Ai, Aj, Ak, f->pack, f->pack_ok);
+		f->pk_A0 = A0;
 		MF_LAUNCH_CHECK();
 		f->pk_flags = flags;
 		f->pk_Ai = Ai;

@@ -20,9 +20,9 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                    const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st);
 // packed {fluid, Ai, Aj, Ak} bytes built by the last mf_mic_init for exactly these grids (nullptr when unavailable / not exact);
-// synchronises the stream once
-int mic_pack_query(const Dim& d, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, const unsigned char** pack,
-                   hipStream_t st);
+// synchronises the stream once.  *a0_packed: bits 4-7 of every byte hold the (small integer) diagonal A0 of these grids as well
+int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak,
+                   const unsigned char** pack, bool* a0_packed, hipStream_t st);
 // packed bytes built by mf_pack_matrix for exactly these grids, or nullptr (no synchronisation)
 const unsigned char* mic_pack_user(const int32_t* flags, const float* Ai, const float* Aj, const float* Ak);
 int mic_mode();          // 0 levels, 1 tiles, 2 rows

@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
                   const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
                   const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb,
-                  const unsigned char* __restrict__ pack, int dk0, int dk1) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
+                  const unsigned char* __restrict__ pack, int dk0, int dk1, int a0p) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
+	// a0p (PACKED only): bits 4-7 of the packed bytes hold the diagonal (k_mic_pack) -- A0 is not read at all, 9 instead of 13 B per cell
 	if (DOT && sc->done) return;
 	const int qx = d.sx >> 2;
 	const int64_t nthr = (int64_t)qx * jgroups * d.sz;
@@ -156,10 +157,11 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
 		const int64_t idx = row0 + jr * Y;
 		sv[r + 1] = *(const float4*)(src + idx);
-		a0[r] = *(const float4*)(A0 + idx);
 		unsigned pw = 0;
+		if (PACKED) pw = *(const unsigned*)(pack + idx);
+		if (PACKED && a0p) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
+		else a0[r] = *(const float4*)(A0 + idx);
 		if (PACKED) {
-			pw = *(const unsigned*)(pack + idx);
 			f[r] = unpack_flags(pw);
 			ajv[r + 1] = unpack_coef<4u>(pw);
 			ai[r] = unpack_coef<2u>(pw);
@@ -299,7 +301,7 @@ template <bool DOT>
 static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, const float* src, const float* A0,
                                const float* Ai, const float* Aj, const float* Ak, double* partials,
                                const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr,
-                               int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr) {
+                               int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr, bool a0p = false) {
 	if (ranged) *ranged = false;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
@@ -315,11 +317,11 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
 		nb = (int)((vblocks + tpb - 1) / tpb);
 #define AM5(RR)                                                                                                                                   \
 	if (d.is3d && pack)                                                                                                                           \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0); \
 	else if (d.is3d)                                                                                                                              \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0); \
 	else                                                                                                                                          \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1);
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0);
 		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
 #undef AM5
 		if (ranged) *ranged = true;
@@ -908,16 +910,17 @@ static int time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float
 	const Dim d = mkdim(sx, sy, sz);
 	hipStream_t st = (hipStream_t)stream;
 	const unsigned char* pack = nullptr;
+	bool a0p = false;
 	if (packed) {
-		MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &pack, st));
+		MF_TRY(mic_pack_query(d, flags, A0, Ai, Aj, Ak, &pack, &a0p, st));
 		if (!pack) return fail("mf_time_apply_matrix_packed: no packed coefficients for these grids (call mf_mic_init on them; the off-diagonals must all be +0 or -1)");
 	}
 	hipEvent_t e0, e1;
 	MF_HIP(hipEventCreate(&e0));
 	MF_HIP(hipEventCreate(&e1));
-	for (int i = 0; i < 3; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr, pack));
+	for (int i = 0; i < 3; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr, pack, 0, 0x7fffffff, nullptr, a0p));
 	MF_HIP(hipEventRecord(e0, st));
-	for (int i = 0; i < reps; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr, pack));
+	for (int i = 0; i < reps; i++) MF_TRY(launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, st, nullptr, pack, 0, 0x7fffffff, nullptr, a0p));
 	MF_HIP(hipEventRecord(e1, st));
 	MF_HIP(hipEventSynchronize(e1));
 	float ms = 0.f;
@@ -1103,7 +1106,8 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	MF_LAUNCH_CHECK();
 	// ApplyMatrix reads the same packed coefficient bytes as the MIC sweeps when mf_mic_init found the matrix packable
 	const unsigned char* am_pack = nullptr;
-	if (pc == MF_PC_MICP) MF_TRY(mic_pack_query(d, flags, Ai, Aj, Ak, &am_pack, st));
+	bool am_a0p = false;
+	if (pc == MF_PC_MICP) MF_TRY(mic_pack_query(d, flags, A0, Ai, Aj, Ak, &am_pack, &am_a0p, st));
 
 	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done`, one batch behind the batch it has just queued
 	// (every kernel of an iteration returns at once when `done` is already set, so running ahead costs a few empty
@@ -1127,7 +1131,7 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 		const int todo = (maxIter - issued < batch) ? (maxIter - issued) : batch;
 		for (int it = 0; it < todo; it++) {
 			int nba = 0, nsig = 0;
-			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack));
+			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
 				hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
