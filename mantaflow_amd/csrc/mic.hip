@@ -705,6 +705,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					// tags only grow: a half window (4 steps) is complete when every granule in range carries this sweep's generation.
 					// The halves are published separately: the compute wave starts a block on the first one, i.e. a consumer bundle
 					// runs 11 instead of 15 steps behind its producer (7 steps of skew + the granularity of the hand-off).
+					// (Quarter windows -- 9 steps of lag, four flag checks and four publisher rounds per block -- were built as well: bit-exact
+					// and 530 instead of 396 us per 256^3 apply.)
 					if (pub == 0 && in0) g0 = granule_load(p0);
 					if (in1) g1 = granule_load(p0 + 4 * 8);
 					const bool giveup = ++spins > FLOW_SPIN_LIMIT;
