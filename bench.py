@@ -121,28 +121,63 @@ def cpu_baseline(sample_dims, vel, dens, flags, dt):
                       "input on its first %d z-planes as a %dx%dx%d domain, %.1f s" % (sz, sx, sy, sz, el)}
 
 
-def other_configs(torch, core, plugins):
-    """BASELINE configs 3 and 5 on one GPU, a few steps each, so that the driver's record carries a number for them as well (the
-    headline `value` stays config 2).  Config 3: the S-flip step of SURVEY 8d at 128^3 (flip01_simple.py's loop, 8 particles per cell
-    in a 0.4 x 0.6 x 1.0 block).  Config 5: the up-res loop of scenes/waveletTurbulence.py with a 256^3 coarse and a 512^3 fine grid
-    (the fine-grid MacCormack advection is the HBM-bound part)."""
-    from mantaflow_amd import scene
+class OpClock(object):
+    """HIP-event timing of the operators of a step (events on torch's current stream = the solver's launch stream).  Disabled it is a
+    plain call, so the same step function serves the whole-step wall time and the per-operator pass."""
+    def __init__(self, torch):
+        self.torch, self.on, self.ev = torch, False, []
+
+    def __call__(self, name, fn, *a, **k):
+        if not self.on:
+            return fn(*a, **k)
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        self.ev.append((name, e0, e1))
+        return r
+
+    def per_op_ms(self, steps):
+        self.torch.cuda.synchronize()
+        tot = {}
+        for name, e0, e1 in self.ev:
+            tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+        self.ev = []
+        return {k: v / steps for k, v in tot.items()}
+
+
+def _timed(torch, step, steps, warm):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _op_rooflines(ops_ms, table):
+    """per-operator objects: HIP-event time, SURVEY 8d's algorithmic bytes (B per particle x particles + B per cell x cells) / time
+    against the 8 TB/s HBM peak"""
     out = {}
+    for name, (nbytes, note) in table.items():
+        if name not in ops_ms:
+            continue
+        ms = ops_ms[name]
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes": note}
+    return out
 
-    def timed(step, steps, warm):
-        for _ in range(warm):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
 
-    # ---- config 3 ----
-    n = 128
+def config3_sflip(torch, core, plugins, n=128, steps=5, warm=2, deterministic=True):
+    """BASELINE config 3: the S-flip step of SURVEY 8d at 128^3 -- scenes/flip01_simple.py's loop, 8 particles per cell in the lower
+    0.4 x 0.6 x 1.0 block of the box (flip.cpp:619-742, particle.h:458-550)."""
+    from mantaflow_amd import scene
     s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
     s.timestep = 0.5
+    plugins.setDeterministicP2G(deterministic)
     flags = core.FlagGrid(s)
     flags.initDomain(boundaryWidth=0)
     flags.updateFromLevelset(scene.Box(parent=s, p0=core.vec3(0, 0, 0), p1=core.vec3(0.4 * n, 0.6 * n, n)).computeLevelset())
@@ -151,26 +186,143 @@ def other_configs(torch, core, plugins):
     pv = pp.create(core.PdataVec3)
     pv.from_numpy(np.random.default_rng(9832).normal(0, 0.5, (pp.np, 3)).astype(np.float32))
     vel, velOld, w, pres = core.MACGrid(s), core.MACGrid(s), core.VecGrid(s), core.Grid(s)
+    clk = OpClock(torch)
 
     def flip_step():
-        pp.advectInGrid(flags, vel, 2, deleteInObstacle=False)
-        plugins.mapPartsToMAC(flags, vel, velOld, pp, pv, w)
-        plugins.extrapolateMACFromWeight(vel, w, distance=2)
-        plugins.markFluidCells(pp, flags)
-        plugins.addGravity(flags, vel, core.vec3(0, -0.002, 0))
-        plugins.setWallBcs(flags, vel)
-        plugins.solvePressure(vel, pres, flags)
-        plugins.extrapolateMACSimple(flags, vel)
-        plugins.flipVelocityUpdate(flags, vel, velOld, pp, pv, 0.97)
+        clk("advectInGrid", pp.advectInGrid, flags, vel, 2, deleteInObstacle=False)
+        clk("mapPartsToMAC", plugins.mapPartsToMAC, flags, vel, velOld, pp, pv, w)
+        clk("extrapolateMACFromWeight", plugins.extrapolateMACFromWeight, vel, w, distance=2)
+        clk("markFluidCells", plugins.markFluidCells, pp, flags)
+        clk("addGravity", plugins.addGravity, flags, vel, core.vec3(0, -0.002, 0))
+        clk("setWallBcs", plugins.setWallBcs, flags, vel)
+        clk("solvePressure", plugins.solvePressure, vel, pres, flags)
+        clk("extrapolateMACSimple", plugins.extrapolateMACSimple, flags, vel)
+        clk("flipVelocityUpdate", plugins.flipVelocityUpdate, flags, vel, velOld, pp, pv, 0.97)
         s.step()
 
-    t = timed(flip_step, 5, 2)
-    out["config3_sflip128"] = {"workload": "flip01_simple.py loop, 128^3, %d particles (ordered, bit-exact P2G)" % pp.np, "ms_per_step": round(t * 1e3, 3),
-                               "Mcells_per_s": round(n ** 3 / t / 1e6, 2), "Mparticles_per_s": round(pp.np / t / 1e6, 2),
-                               "cg_iterations_last": plugins.lastCgStats().get("iterations")}
-    del flags, pp, pv, vel, velOld, w, pres, s
-    # ---- config 5 ----
-    nc, up = 256, 2
+    t = _timed(torch, flip_step, steps, warm)
+    clk.on = True
+    for _ in range(steps):
+        flip_step()
+    ops = clk.per_op_ms(steps)
+    clk.on = False
+    npart, cells = pp.np, n ** 3
+    mode = "ordered gather, bit-exact" if deterministic else "fp32 atomics"
+    out = {"workload": "flip01_simple.py loop, %d^3, %d particles (P2G: %s)" % (n, npart, mode), "ms_per_step": round(t * 1e3, 3),
+           "Mcells_per_s": round(cells / t / 1e6, 2), "Mparticles_per_s": round(npart / t / 1e6, 2),
+           "cg_iterations_last": plugins.lastCgStats().get("iterations"),
+           "ops_ms": {k: round(v, 4) for k, v in ops.items()},
+           "solvePressure_share": round(ops.get("solvePressure", 0.0) / max(sum(ops.values()), 1e-9), 3),
+           "rooflines": _op_rooflines(ops, {
+               "mapPartsToMAC": (40 * npart + 108 * cells, "SURVEY 8d: 40 B/particle (pos/flag 28 + pvel 12) + 108 B/cell (clear 24, stomp 24, divide 36, copy 24); 48 fp32 RMWs per particle on top"),
+               "advectInGrid": (160 * npart, "SURVEY 8d: ~160 B/particle as the reference structures RK4 (4 x 28 gathers + pos 24 + scratch)"),
+               "flipVelocityUpdate": (52 * npart, "SURVEY 8d: 52 B/particle (pos/flag 28 + pvel 12 read, 12 written; 48 gathers from cache)")})}
+    if "mapPartsToMAC" in ops:
+        out["rooflines"]["mapPartsToMAC"]["rmw_per_s"] = round(48 * npart / (ops["mapPartsToMAC"] * 1e-3) / 1e9, 2)
+        out["rooflines"]["mapPartsToMAC"]["rmw_unit"] = "G fp32 accumulations/s (48 per particle; atomics in the atomic mode, ordered adds in the default mode)"
+    plugins.setDeterministicP2G(True)
+    return out
+
+
+def dam_scene(core, plugins, scene, res):
+    """Set-up of scenes/benchmark_dam.py (:33-92) at reference resolution `res` through the package API: returns the objects of its
+    main loop and `step()` = one pass of that loop (:99-135, without the GUI-only second level-set pass)."""
+    bnd, sres = 4, 2
+    dx = 1.0 / sres
+    sc = float(res)
+    gs = [round(sc * 3.2) + bnd * 2, res * 3 + bnd * 2, res + bnd * 2]
+    grav = -9.8 * sc
+    FF, FO, FE = 1, 2, 4
+    s = core.Solver(name="FLIP", gridSize=core.vec3(*gs), dim=3)
+    s.cfl, s.frameLength, s.timestepMin = 1, 1.0 / 30.0, 0
+    s.timestepMax = s.timestep = s.frameLength
+    fl, V, Vold, P = s.create(core.FlagGrid), s.create(core.MACGrid), s.create(core.MACGrid), s.create(core.RealGrid)
+    phiS, phi = s.create(core.LevelsetGrid), s.create(core.LevelsetGrid)
+    isys, idx = s.create(core.ParticleIndexSystem), s.create(core.IntGrid)
+    pp = s.create(core.BasicParticleSystem)
+    pT, pV, pX = pp.create(core.PdataInt), pp.create(core.PdataVec3), pp.create(core.PdataVec3)
+    fl.initDomain(bnd - 1)
+    outer = s.create(scene.Box, p0=core.vec3(0), p1=core.vec3(*gs))
+    inner = s.create(scene.Box, p0=core.vec3(bnd, bnd, bnd), p1=core.vec3(gs[0] - bnd, gs[1] - bnd, gs[0] - bnd))
+    phiS.join(outer.computeLevelset())
+    phiS.subtract(inner.computeLevelset())
+    obs = s.create(scene.Box, center=core.vec3(0.744 * sc + bnd, 0.161 * 0.5 * sc + bnd, 0.5 * gs[2]),
+                   size=core.vec3(0.161 * 0.5 * sc, 0.161 * 0.5 * sc, 0.403 * 0.5 * sc))
+    obs.applyToGrid(grid=fl, value=FO, respectFlags=fl)
+    phiS.join(obs.computeLevelset())
+    dam = s.create(scene.Box, center=core.vec3(2.606 * sc + bnd, 0.275 * sc + bnd, 0.5 * sc + bnd),
+                   size=core.vec3(1.228 * 0.5 * sc, 0.55 * 0.5 * sc, 0.5 * sc))
+    dam.applyToGrid(grid=fl, value=FF, respectFlags=fl)
+    scene.sampleShapeWithParticles(shape=dam, flags=fl, parts=pp, discretization=sres, randomness=0)
+    pT.setConstRange(FF, 0, pp.pySize())
+    g = core.vec3(0, grav, 0)
+    st = {"iters": []}
+
+    def step(clk=lambda name, fn, *a, **k: fn(*a, **k)):
+        clk("mapPartsToMAC", plugins.mapPartsToMAC, vel=V, flags=fl, velOld=Vold, parts=pp, partVel=pV, ptype=pT, exclude=FE)
+        s.adaptTimestep(V.getMaxAbs())
+        plugins.addGravityNoScale(flags=fl, vel=V, gravity=g)
+        clk("gridParticleIndex", plugins.gridParticleIndex, parts=pp, flags=fl, indexSys=isys, index=idx)
+        clk("unionParticleLevelset", plugins.unionParticleLevelset, parts=pp, indexSys=isys, flags=fl, index=idx, phi=phi, radiusFactor=1.0)
+        clk("extrapolateLsSimple", plugins.extrapolateLsSimple, phi=phi, distance=4, inside=True)
+        if st.get("hook"):
+            st["hook"]()
+        plugins.setWallBcs(flags=fl, vel=V)
+        clk("solvePressure", plugins.solvePressure, flags=fl, vel=V, pressure=P, cgAccuracy=1e-3, phi=phi)
+        st["iters"].append(plugins.lastCgStats()["iterations"])
+        plugins.setWallBcs(flags=fl, vel=V)
+        clk("extrapolateMACSimple", plugins.extrapolateMACSimple, flags=fl, vel=V)
+        clk("flipVelocityUpdate", plugins.flipVelocityUpdate, vel=V, velOld=Vold, flags=fl, parts=pp, partVel=pV, flipRatio=0.97, ptype=pT, exclude=FE)
+        plugins.addForcePvel(vel=pV, a=g, dt=s.timestep, ptype=pT, exclude=FF)
+        pp.getPosPdata(target=pX)
+        clk("advectInGrid", pp.advectInGrid, flags=fl, vel=V, integrationMode=2, deleteInObstacle=False, ptype=pT, exclude=FE)
+        plugins.eulerStep(parts=pp, vel=pV, ptype=pT, exclude=FF)
+        pp.projectOutOfBnd(flags=fl, bnd=bnd + dx * 0.5, plane="xXyYzZ", ptype=pT)
+        plugins.pushOutofObs(parts=pp, flags=fl, phiObs=phiS, thresh=dx * 0.5, ptype=pT)
+        plugins.updateVelocityFromDeltaPos(parts=pp, vel=pV, x_prev=pX, dt=s.timestep, ptype=pT, exclude=FF)
+        clk("markFluidCells+setPartType", lambda: (plugins.markFluidCells(parts=pp, flags=fl, ptype=pT),
+                                                   plugins.setPartType(parts=pp, ptype=pT, mark=FF, stype=FE, flags=fl, cflag=FF),
+                                                   plugins.markIsolatedFluidCell(flags=fl, mark=FE),
+                                                   plugins.setPartType(parts=pp, ptype=pT, mark=FE, stype=FF, flags=fl, cflag=FE)))
+        s.step()
+
+    return dict(s=s, gs=gs, flags=fl, vel=V, velOld=Vold, pressure=P, phi=phi, phiObs=phiS, parts=pp, ptype=pT, pvel=pV, step=step, state=st)
+
+
+DAM_RES = 116    # benchmark_dam.py's params['res'] for which its grid (3.2 res + 8) x (3 res + 8) x (res + 8) = 379 x 356 x 124 has 256^3 cells (16.73 M)
+
+
+def config4_dam(torch, core, plugins, res=DAM_RES, steps=4, warm=2):
+    """BASELINE config 4 on one GPU: the ghost-fluid FLIP dam break of scenes/benchmark_dam.py (main loop :99-135) on a grid of
+    256^3 cells (res 116: 379 x 356 x 124)."""
+    from mantaflow_amd import scene
+    sc = dam_scene(core, plugins, scene, res)
+    clk = OpClock(torch)
+    step = lambda: sc["step"](clk)
+    t = _timed(torch, step, steps, warm)
+    clk.on = True
+    for _ in range(steps):
+        step()
+    ops = clk.per_op_ms(steps)
+    clk.on = False
+    npart = sc["parts"].np
+    cells = sc["gs"][0] * sc["gs"][1] * sc["gs"][2]
+    out = {"workload": "benchmark_dam.py loop (ghost fluid, cgAccuracy 1e-3), res %d: grid %dx%dx%d = %d cells, %d particles, steps %d-%d"
+                       % (res, sc["gs"][0], sc["gs"][1], sc["gs"][2], cells, npart, warm + 1, warm + steps),
+           "ms_per_step": round(t * 1e3, 3), "Mcells_per_s": round(cells / t / 1e6, 2), "Mparticles_per_s": round(npart / t / 1e6, 2),
+           "cg_iterations": sc["state"]["iters"][warm:warm + steps], "ops_ms": {k: round(v, 4) for k, v in ops.items()},
+           "solvePressure_share": round(ops.get("solvePressure", 0.0) / max(t * 1e3, 1e-9), 3),
+           "rooflines": _op_rooflines(ops, {
+               "mapPartsToMAC": (40 * npart + 108 * cells, "SURVEY 8d: 40 B/particle + 108 B/cell"),
+               "advectInGrid": (160 * npart, "SURVEY 8d: ~160 B/particle"),
+               "flipVelocityUpdate": (52 * npart, "SURVEY 8d: 52 B/particle")})}
+    return out
+
+
+def config5_wavelet(torch, core, plugins, nc=256, up=2, steps=3, warm=2):
+    """BASELINE config 5 on one GPU: the up-res loop of scenes/waveletTurbulence.py (:105-146) with a 256^3 coarse and a 512^3 fine
+    grid; the fine-grid MacCormack advection (advection.cpp:25-42, 82-92, 242-268) is the HBM-bound part."""
+    from mantaflow_amd import scene
     gs, xgs = core.vec3(nc, nc, nc), core.vec3(nc * up, nc * up, nc * up)
     sm, xl = core.Solver(gridSize=gs, dim=3), core.Solver(gridSize=xgs, dim=3)
     sm.timestep = xl.timestep = 1.5
@@ -193,40 +345,53 @@ def other_configs(torch, core, plugins):
     xfl.initDomain(); xfl.fillGrid()
     velInflow = core.vec3(0.025, 0, 0) * float(nc)
     wlt = 0.4
-    t_fine = [0.0]
+    clk = OpClock(torch)
 
     def wavelet_step():
-        plugins.advectSemiLagrange(flags, vel, dens, order=2)
-        plugins.advectSemiLagrange(flags, vel, vel, order=2)
+        clk("coarse: advect density+vel (MacCormack)", lambda: (plugins.advectSemiLagrange(flags, vel, dens, order=2),
+                                                               plugins.advectSemiLagrange(flags, vel, vel, order=2)))
         scene.densityInflow(flags=flags, density=dens, noise=noise, shape=source, scale=1, sigma=0.5)
         sourceVel.applyToGrid(grid=vel, value=velInflow)
         plugins.setWallBcs(flags, vel)
         plugins.addBuoyancy(flags, dens, vel, core.vec3(0, -1e-3, 0))
         plugins.vorticityConfinement(vel, flags, strength=0.3)
-        plugins.solvePressure(vel, pres, flags, cgMaxIterFac=1.0, cgAccuracy=0.01)
+        clk("coarse: solvePressure", plugins.solvePressure, vel, pres, flags, cgMaxIterFac=1.0, cgAccuracy=0.01)
         plugins.setWallBcs(flags, vel)
-        plugins.computeEnergy(flags, vel, energy)
-        plugins.computeWaveletCoeffs(energy)
+        clk("coarse: computeEnergy+computeWaveletCoeffs", lambda: (plugins.computeEnergy(flags, vel, energy), plugins.computeWaveletCoeffs(energy)))
         sm.step()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        plugins.interpolateGrid(target=xw, source=energy)
-        plugins.interpolateMACGrid(source=vel, target=xvel)
-        for k in range(3):
-            plugins.applyNoiseVec3(flags=xfl, target=xvel, noise=wl[k], scale=wlt * 0.6 ** k, weight=xw)
+        clk("fine: interpolateGrid+interpolateMACGrid", lambda: (plugins.interpolateGrid(target=xw, source=energy),
+                                                                plugins.interpolateMACGrid(source=vel, target=xvel)))
+        clk("fine: applyNoiseVec3 x3", lambda: [plugins.applyNoiseVec3(flags=xfl, target=xvel, noise=wl[k], scale=wlt * 0.6 ** k, weight=xw) for k in range(3)])
         for _ in range(up):
-            plugins.advectSemiLagrange(xfl, xvel, xdens, order=2)
-        scene.densityInflow(flags=xfl, density=xdens, noise=xl_noise, shape=xl_source, scale=1, sigma=0.5)
-        e1.record()
+            clk("fine: advectSemiLagrange(density, order 2)", plugins.advectSemiLagrange, xfl, xvel, xdens, order=2)
+        clk("fine: densityInflow", scene.densityInflow, flags=xfl, density=xdens, noise=xl_noise, shape=xl_source, scale=1, sigma=0.5)
         xl.step()
-        torch.cuda.synchronize()
-        t_fine[0] = e0.elapsed_time(e1)
 
-    t = timed(wavelet_step, 3, 2)
+    t = _timed(torch, wavelet_step, steps, warm)
+    clk.on = True
+    for _ in range(steps):
+        wavelet_step()
+    ops = clk.per_op_ms(steps)
+    clk.on = False
     nf = (nc * up) ** 3
-    out["config5_wavelet512"] = {"workload": "waveletTurbulence.py loop, coarse 256^3 (MIC-CG 1e-2) + fine 512^3 (resampling, 3 noise octaves, 2 MacCormack substeps)",
-                                 "ms_per_step": round(t * 1e3, 2), "fine_part_ms": round(t_fine[0], 2), "fine_Mcells_per_s": round(nf / t / 1e6, 1),
-                                 "cg_iterations_last": plugins.lastCgStats().get("iterations")}
+    fine_ms = sum(v for k, v in ops.items() if k.startswith("fine:"))
+    mc = "fine: advectSemiLagrange(density, order 2)"
+    out = {"workload": "waveletTurbulence.py loop, coarse %d^3 (MIC-CG 1e-2) + fine %d^3 (resampling, 3 noise octaves, %d MacCormack substeps)" % (nc, nc * up, up),
+           "ms_per_step": round(t * 1e3, 2), "fine_part_ms": round(fine_ms, 2), "fine_Mcells_per_s": round(nf / t / 1e6, 1),
+           "cg_iterations_last": plugins.lastCgStats().get("iterations"), "ops_ms": {k: round(v, 4) for k, v in ops.items()},
+           "rooflines": _op_rooflines({mc: ops[mc] / up}, {mc: (92 * nf, "SURVEY 8d: MacCormack Real 92 B/cell (20 + 20 + correct 20 + clamp 32), per call at %d^3" % (nc * up))})}
+    return out
+
+
+def other_configs(torch, core, plugins):
+    """BASELINE configs 3, 4 and 5 on one GPU, a few steps each, so that the driver's record carries a number and per-operator
+    rooflines for them as well (the headline `value` stays config 2)."""
+    out = {}
+    out["config3_sflip128"] = config3_sflip(torch, core, plugins)
+    torch.cuda.empty_cache()
+    out["config4_dam256"] = config4_dam(torch, core, plugins)
+    torch.cuda.empty_cache()
+    out["config5_wavelet512"] = config5_wavelet(torch, core, plugins)
     return out
 
 
@@ -237,7 +402,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=GRID)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the short single-GPU runs of BASELINE configs 3 and 5")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short single-GPU runs of BASELINE configs 3, 4 and 5")
     ap.add_argument("--slab", action="store_true", help="N=1 only: run the z-slab code path with one rank (overhead check)")
     a = ap.parse_args()
 

@@ -1320,3 +1320,33 @@ def run_flip_step_pkg(dims, dt, flags, vel, pos, pflag, pvel):
     s.sync()
     out.update(vel=grid_to_soa(v), pvel=_pd_get(pv, pp.np), iters=plugins.lastCgStats()["iterations"])
     return out
+
+
+def run_upres_pass_pkg(nc, vel_coarse):
+    """the fine-grid part of scenes/waveletTurbulence.py:128-140 on a coarse nc^3 / fine (2 nc)^3 pair with a synthetic coarse velocity:
+    computeEnergy + computeWaveletCoeffs (coarse), interpolateGrid, interpolateMACGrid, three octaves of applyNoiseVec3, two MacCormack
+    advections of the fine density -- no pressure solve, so every field has to come out bit for bit"""
+    from mantaflow_amd import core, plugins
+    gs = (nc, nc, nc)
+    sm, xl = _mk_solver(gs, WLT_DT), _mk_solver(tuple(v * WLT_UPRES for v in gs), WLT_DT)
+    o = wavelet_objects(sm, xl, gs)
+    fl, V, E = core.FlagGrid(sm), core.MACGrid(sm), core.Grid(sm)
+    xfl, xV, xD, xW = core.FlagGrid(xl), core.MACGrid(xl), core.Grid(xl), core.Grid(xl)
+    fl.initDomain(0); fl.fillGrid(); plugins.setOpenBound(fl, 0, "Y", 16 | 4)
+    xfl.initDomain(0); xfl.fillGrid()
+    soa_to_grid(V, vel_coarse)
+    n2 = nc * WLT_UPRES
+    z = np.arange(n2, dtype=np.float32)[:, None, None]; y = np.arange(n2, dtype=np.float32)[None, :, None]; x = np.arange(n2, dtype=np.float32)[None, None, :]
+    xD.from_numpy((0.5 + 0.5 * np.sin(0.05 * x + 0.3) * np.cos(0.04 * y) * np.sin(0.03 * z + 1.0)).astype(np.float32))
+    plugins.setWallBcs(flags=fl, vel=V)
+    plugins.computeEnergy(flags=fl, vel=V, energy=E)
+    plugins.computeWaveletCoeffs(E)
+    plugins.interpolateGrid(target=xW, source=E)
+    plugins.interpolateMACGrid(source=V, target=xV)
+    plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt1"], scale=WLT_STRENGTH * 1.0, weight=xW)
+    plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt2"], scale=WLT_STRENGTH * 0.6, weight=xW)
+    plugins.applyNoiseVec3(flags=xfl, target=xV, noise=o["wlt3"], scale=WLT_STRENGTH * 0.6 * 0.6, weight=xW)
+    for _ in range(WLT_UPRES):
+        plugins.advectSemiLagrange(flags=xfl, vel=xV, grid=xD, order=2)
+    xl.sync()
+    return dict(energy=grid_to_soa(E), xl_weight=grid_to_soa(xW), xl_vel=grid_to_soa(xV), xl_dens=grid_to_soa(xD))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Focused launcher for rocprofv3: runs one hot kernel family at 256^3 so kernel-trace / PMC output stays small.
-  python3 tools/prof_kernels.py apply_matrix [reps] | apply_matrix_packed [reps] | mic [reps] | flip | dam | wavelet | advect
+  python3 tools/prof_kernels.py apply_matrix [reps] | apply_matrix_packed [reps] | mic [reps] | flip | dam | wavelet | advect | config3 | config4 | config5
 """
 import ctypes
 import os
@@ -22,6 +22,15 @@ def main():
     n = int(os.environ.get("MF_GRID", "256"))
     dims = [int(v) for v in os.environ.get("MF_DIMS", "%d,%d,%d" % (n, n, n)).split(",")]
     lib = _lib.get()
+    if what in ("config3", "config4", "config5"):
+        # exactly the workloads bench.py reports under other_configs (per-operator HIP-event times printed as JSON)
+        import json
+        fn = {"config3": bench.config3_sflip, "config4": bench.config4_dam, "config5": bench.config5_wavelet}[what]
+        kw = {"steps": reps}
+        if what == "config3":
+            kw["deterministic"] = os.environ.get("MF_P2G_DET", "1") == "1"
+        print(json.dumps(fn(torch, core, plugins, **kw), indent=1))
+        return
     s = core.Solver(gridSize=core.vec3(*dims), dim=3)
     flags = core.FlagGrid(s); flags.initDomain(); flags.fillGrid()
     A0, Ai, Aj, Ak, src, dst, ap = (core.Grid(s) for _ in range(7))
@@ -110,11 +119,12 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
         import cases
         res = int(os.environ.get("MF_RES", "160"))
-        cases.run_dam_pkg(res, 2, deterministic=False)      # warm-up (allocations, sort scratch)
+        det = os.environ.get("MF_P2G_DET", "1") == "1"
+        cases.run_dam_pkg(res, 2, deterministic=det)      # warm-up (allocations, sort scratch)
         plugins._timings.clear()
         torch.cuda.synchronize()
         t0 = time.time()
-        out = cases.run_dam_pkg(res, reps, deterministic=False)
+        out = cases.run_dam_pkg(res, reps, deterministic=det)
         torch.cuda.synchronize()
         el = time.time() - t0
         gs = out["gs"]
