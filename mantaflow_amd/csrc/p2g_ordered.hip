@@ -3,18 +3,22 @@
 // knMapLinearVec3ToMACGrid / knMapLinear<T> are KERNEL(pts, single): one thread walks the particles in index order and
 // adds w and w*val into the 8 nodes around each particle (setInterpolMAC / setInterpol, util/interpol.h:96-113, 166-213).
 // Every node is therefore an independent fp32 accumulator that receives its contributions in increasing particle index.
-// That is a gather: a node (i,j,k) is reached exactly by the particles whose base cell is (i-di, j-dj, k-dk), di,dj,dk in
-// {0,1}, through the corner (di,dj,dk).  So:
-//   1. key(p) = flat base cell of the component (skipped particles: key n), per-cell histogram, exclusive scan;
-//   2. stable radix sort of (key, p): each base cell's particles, in increasing p;
-//   3. one thread per node merges its (up to) 8 sorted lists by p and accumulates  acc_w += w ; acc_v += w*val  in
-//      exactly the reference's order.
-// Cost: every particle is visited by 8 nodes per component (position + value re-read from L2); no atomics, no order
-// dependence, same bits as the reference on every run.  In 2D the two z-corners alias the same node (strideZ = 0), the
-// per-particle order of those two adds follows the statement order of the reference (z-corners first, except for the
-// Z component).
+// That is a gather: a node (i,j,k) of component c is reached exactly by the particles whose component base cell is
+// (i-di, j-dj, k-dk), di,dj,dk in {0,1}, through the corner (di,dj,dk).
+//
+// Round 3: ONE binning pass serves all three MAC components, and it is ours (no library sort on the hot path).
+//   1. bin by the plain base cell B = BUILD_INDEX(pos) (the cell-centred base): wave-aggregated histogram, exclusive scan,
+//      placement with wave-aggregated cursors, then every cell's run is put into increasing particle index (a run is short:
+//      insertion sort per cell, a workgroup sort for the rare crowded cell).  Result: start[cell], order[slot].
+//   2. the sorted payload (per component a record {w0, w1, w2, v} and a link word to the next entries, p | e << 28) is written once; e = (ex, ey, ez) says for each axis whether the
+//      SHIFTED base of BUILD_INDEX_SHIFT is B or B + 1 (it is always one of the two).  The base cell of MAC component X is
+//      (B.x + ex, B.y, B.z), and likewise for Y, Z.
+//   3. one thread per node merges, by particle index, the 3 x 2 x 2 runs of the cells B with B.c in {n.c-2, n.c-1, n.c} (the
+//      outer two filtered by e: 12 sorted lists, 8 for a cell-centred grid) and accumulates  acc_w += w ; acc_v += w*val  in
+//      exactly the reference's order.  Heads are (p << 4 | list) words, so the minimum names the list.
+// No atomics in the sums, no order dependence, same bits as the reference on every run.  In 2D the two z-corners alias the
+// same node (strideZ = 0); the per-particle order of those two adds follows the statement order of the reference.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 #include <limits.h>
 
 using namespace mf;
@@ -22,6 +26,12 @@ using namespace mf;
 namespace {
 
 static inline unsigned nblk_n(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK > 0 ? (n + BLOCK - 1) / BLOCK : 1); }
+
+constexpr int PBITS = 28;                          // particle index bits of a payload word; e lives above
+constexpr unsigned PMASK = (1u << PBITS) - 1u;
+constexpr int SMALL_RUN = 32;                      // longest run the per-cell insertion sort takes
+constexpr int BIG_LDS = 4096;                      // longest run the workgroup sort takes in LDS
+constexpr int SCAN_ITEMS = 16;                     // per thread and scan block
 
 struct Corner {
 	int bx, by, bz;
@@ -43,81 +53,358 @@ __device__ __forceinline__ Corner corner_of(const Dim& d, float x, float y, floa
 	return c;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(BLOCK)
-k_keys(Dim d, int64_t np, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ pflag, const int32_t* __restrict__ ptype,
-       int exclude, int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ counts) {
-	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-	if (p >= np) return;
-	int key = (int)d.n;
-	if (!((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude)))) {
-		const Corner c = corner_of<MODE>(d, pos[p], pos[ps + p], pos[2 * ps + p]);
-		key = (int)((int64_t)c.bx + d.sx * ((int64_t)c.by + (int64_t)d.sy * c.bz));
-		atomicAdd(&counts[key], 1);
+// ---- binning ------------------------------------------------------------------------------------------------------------
+// keys: KEYMODE 3 = plain base cell (serves MODE 0..3); KEYMODE 10 + c = flat APIC face index of component c.
+template <int KEYMODE>
+__device__ __forceinline__ int key_of(const Dim& d, float x, float y, float z) {
+	int64_t key;
+	if (KEYMODE == 3) {
+		const Bi b = build_index(d, x, y, z);
+		key = (int64_t)b.xi + d.sx * ((int64_t)b.yi + (int64_t)d.sy * b.zi);
+	} else {
+		key = apic_face<KEYMODE - 10>(d, x, y, z).gidx;
 	}
-	keys[p] = key;
-	vals[p] = (int)p;
+	return (key >= 0 && key < d.n) ? (int)key : (int)d.n;        // a position that maps nowhere (NaN, APIC outside) is skipped
 }
 
-// one thread per node; NCOMP values per particle (1 for a MAC component / Real grid, 3 for a Vec3 grid)
-template <int MODE, int NCOMP>
+// lanes of a wave that hold the same key as their left neighbour form a run; its first lane speaks for it
+struct Run {
+	bool head;
+	int len, first;
+};
+__device__ __forceinline__ Run run_of(int key) {
+	const int lane = threadIdx.x & 63;
+	const int prev = __shfl_up(key, 1);
+	Run r;
+	r.head = lane == 0 || prev != key;
+	const unsigned long long m = __ballot(r.head);
+	const unsigned long long below = m & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+	r.first = 63 - __clzll(below);
+	const unsigned long long above = (lane == 63) ? 0ull : (m >> (lane + 1));
+	r.len = above ? (__ffsll((long long)above)) : (64 - lane);
+	return r;
+}
+
+template <int KEYMODE>
 __global__ void __launch_bounds__(BLOCK)
-k_gather(Dim d, int64_t ps, const float* __restrict__ pos, const float* __restrict__ pval, int64_t vstride, const int32_t* __restrict__ order,
-         const int32_t* __restrict__ start, float* __restrict__ ref, int64_t rstride, float* __restrict__ sum) {
-	const int64_t node = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-	if (node >= d.n) return;
-	const int i = (int)(node % d.sx), j = (int)((node / d.sx) % d.sy), k = (int)(node / ((int64_t)d.sx * d.sy));
-	const int nlist = d.is3d ? 8 : 4;
-	int cur[8], end[8], head[8];
+k_bin_keys(Dim d, int64_t np, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ pflag, const int32_t* __restrict__ ptype,
+           int exclude, int32_t* __restrict__ keys, int32_t* __restrict__ counts) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	int key = (int)d.n + 1;          // lanes past the end: a key of their own, never counted
+	if (p < np) {
+		key = (int)d.n;
+		if (!((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude)))) key = key_of<KEYMODE>(d, pos[p], pos[ps + p], pos[2 * ps + p]);
+		keys[p] = key;
+	}
+	const Run r = run_of(key);
+	if (r.head && key < d.n) atomicAdd(&counts[key], r.len);
+}
+
+// exclusive scan of counts[0..n] -> start[0..n] in three launches (block sums, their scan, the blocks)
+__global__ void __launch_bounds__(BLOCK)
+k_scan_sums(int64_t n, const int32_t* __restrict__ counts, int32_t* __restrict__ sums) {
+	const int64_t base = (int64_t)blockIdx.x * BLOCK * SCAN_ITEMS;
+	int s = 0;
+	for (int q = 0; q < SCAN_ITEMS; q++) {
+		const int64_t i = base + (int64_t)q * BLOCK + threadIdx.x;
+		if (i < n) s += counts[i];
+	}
+	__shared__ int sh[BLOCK / 64];
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) sums[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ int block_excl_scan(int v, int* total) {
+	// exclusive scan of one value per thread over the block (BLOCK = 256 = 4 waves)
+	__shared__ int shw[BLOCK / 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	int inc = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(inc, o);
+		if (lane >= o) inc += t;
+	}
+	__syncthreads();
+	if (lane == 63) shw[w] = inc;
+	__syncthreads();
+	int off = 0;
+	for (int q = 0; q < w; q++) off += shw[q];
+	*total = shw[0] + shw[1] + shw[2] + shw[3];
+	return off + inc - v;
+}
+__global__ void __launch_bounds__(BLOCK)
+k_scan_top(int nb, int32_t* __restrict__ sums) {
+	int carry = 0;
+	for (int base = 0; base < nb; base += BLOCK) {
+		const int i = base + threadIdx.x;
+		const int v = i < nb ? sums[i] : 0;
+		int tot;
+		const int ex = block_excl_scan(v, &tot);
+		if (i < nb) sums[i] = carry + ex;
+		carry += tot;
+		__syncthreads();
+	}
+}
+__global__ void __launch_bounds__(BLOCK)
+k_scan_blocks(int64_t n, const int32_t* __restrict__ counts, const int32_t* __restrict__ sums, int32_t* __restrict__ start) {
+	// thread t owns SCAN_ITEMS consecutive entries
+	const int64_t base = (int64_t)blockIdx.x * BLOCK * SCAN_ITEMS + (int64_t)threadIdx.x * SCAN_ITEMS;
+	int v[SCAN_ITEMS], s = 0;
 #pragma unroll
-	for (int q = 0; q < 8; q++) {
-		const int di = q & 1, dj = (q >> 1) & 1, dk = q >> 2;
-		const int bx = i - di, by = j - dj, bz = k - dk;
-		const bool ok = (q < nlist) && bx >= 0 && by >= 0 && bz >= 0;
-		int a = 0, e = 0;
-		if (ok) {
-			const int64_t c = (int64_t)bx + d.sx * ((int64_t)by + (int64_t)d.sy * bz);
-			a = start[c];
-			e = start[c + 1];
+	for (int q = 0; q < SCAN_ITEMS; q++) {
+		v[q] = (base + q < n) ? counts[base + q] : 0;
+		s += v[q];
+	}
+	int tot;
+	int run = sums[blockIdx.x] + block_excl_scan(s, &tot);
+#pragma unroll
+	for (int q = 0; q < SCAN_ITEMS; q++) {
+		if (base + q < n) start[base + q] = run;
+		run += v[q];
+	}
+}
+// k_scan_sums reads strided, k_scan_blocks reads blocked: both cover [blockIdx * BLOCK * SCAN_ITEMS, +BLOCK * SCAN_ITEMS)
+
+__global__ void __launch_bounds__(BLOCK)
+k_bin_place(int64_t n, int64_t np, const int32_t* __restrict__ keys, const int32_t* __restrict__ start, int32_t* __restrict__ counts,
+            int32_t* __restrict__ order) {
+	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	const int key = p < np ? keys[p] : (int)n + 1;
+	const Run r = run_of(key);
+	int old = 0;
+	if (r.head && key < n) old = atomicSub(&counts[key], r.len);       // the run takes the slots [old - len, old) of its cell
+	old = __shfl(old, r.first);
+	const int hlen = __shfl(r.len, r.first);                             // r.len is the run's length on its first lane only
+	if (key < n) order[start[key] + old - hlen + ((threadIdx.x & 63) - r.first)] = (int)p;
+}
+
+// every cell's run into increasing particle index; runs longer than SMALL_RUN go to the workgroup sort
+__global__ void __launch_bounds__(BLOCK)
+k_bin_sort_cells(int64_t n, const int32_t* __restrict__ start, int32_t* __restrict__ order, int32_t* __restrict__ nbig, int32_t* __restrict__ big) {
+	const int64_t c = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (c >= n) return;
+	const int a = start[c], e = start[c + 1];
+	if (e - a < 2) return;
+	if (e - a > SMALL_RUN) {
+		big[atomicAdd(nbig, 1)] = (int)c;
+		return;
+	}
+	for (int i = a + 1; i < e; i++) {
+		const int v = order[i];
+		int j = i - 1;
+		if (order[j] <= v) continue;
+		while (j >= a && order[j] > v) {
+			order[j + 1] = order[j];
+			j--;
 		}
-		cur[q] = a;
-		end[q] = e;
-		head[q] = a < e ? order[a] : INT_MAX;
+		order[j + 1] = v;
+	}
+}
+// one workgroup per crowded cell: bitonic sort in LDS up to BIG_LDS entries, rank counting into `tmp` beyond that
+__global__ void __launch_bounds__(BLOCK)
+k_bin_sort_big(const int32_t* __restrict__ start, int32_t* __restrict__ order, const int32_t* __restrict__ nbig, const int32_t* __restrict__ big,
+               int32_t* __restrict__ tmp) {
+	__shared__ int sh[BIG_LDS];
+	const int nb = *nbig;
+	for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+		const int c = big[b];
+		const int a = start[c], cnt = start[c + 1] - a;
+		if (cnt <= BIG_LDS) {
+			int m = 64;
+			while (m < cnt) m <<= 1;
+			for (int i = threadIdx.x; i < m; i += BLOCK) sh[i] = i < cnt ? order[a + i] : INT_MAX;
+			__syncthreads();
+			for (int k = 2; k <= m; k <<= 1)
+				for (int j = k >> 1; j > 0; j >>= 1) {
+					for (int i = threadIdx.x; i < m; i += BLOCK) {
+						const int x = i ^ j;
+						if (x > i) {
+							const int u = sh[i], v = sh[x];
+							const bool up = (i & k) == 0;
+							if ((u > v) == up) {
+								sh[i] = v;
+								sh[x] = u;
+							}
+						}
+					}
+					__syncthreads();
+				}
+			for (int i = threadIdx.x; i < cnt; i += BLOCK) order[a + i] = sh[i];
+			__syncthreads();
+		} else {
+			// particle indices are distinct: the rank of an entry is the number of smaller entries of its run
+			for (int i0 = 0; i0 < cnt; i0 += BLOCK) {
+				const int i = i0 + threadIdx.x;
+				const int v = i < cnt ? order[a + i] : INT_MAX;
+				int rank = 0;
+				for (int t0 = 0; t0 < cnt; t0 += BIG_LDS) {
+					const int tn = cnt - t0 < BIG_LDS ? cnt - t0 : BIG_LDS;
+					__syncthreads();
+					for (int q = threadIdx.x; q < tn; q += BLOCK) sh[q] = order[a + t0 + q];
+					__syncthreads();
+					for (int q = 0; q < tn; q++) rank += sh[q] < v;
+				}
+				if (i < cnt) tmp[a + rank] = v;
+			}
+			__syncthreads();
+			for (int i = threadIdx.x; i < cnt; i += BLOCK) order[a + i] = tmp[a + i];
+			__syncthreads();
+		}
+	}
+}
+
+// sorted payload, one record set per target kind T (0..2: MAC component, 3: cell-centred grid), so that a contribution costs the
+// gather two loads whose addresses follow from the slot alone:
+//   rec[T][slot]  = {w0, w1, w2, v}: the fractional weights of BUILD_INDEX (s1, t1, f1 after the clamps), the one along the
+//                   component's own axis replaced by that of the shifted half of BUILD_INDEX_SHIFT, and the value to spread.
+//                   The other weight of a pair is (float)(1. - (double)w1) in every case: that is how the reference forms it, and
+//                   the clamps set the pairs (1,0) / (0,1).
+//   link[T][slot] = {next entry of the same cell with the same e bit: p << 4 | distance (0: none, 15: 15 or more),
+//                    next entry of the same cell: p << 1 (0xffffffff: none) -- bit 0: this entry's e bit}
+// e = (ex, ey, ez): shifted base = B + e per axis.  spe[slot] = p | e << PBITS.
+template <int NV>
+__global__ void __launch_bounds__(BLOCK)
+k_bin_payload(Dim d, const int32_t* __restrict__ start, int64_t ps, const float* __restrict__ pos, const float* __restrict__ pval, int64_t vstride,
+              const int32_t* __restrict__ order, bool mac, float4* __restrict__ rec, float* __restrict__ sv, int64_t cp, uint32_t* __restrict__ spe) {
+	const int64_t slot = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (slot >= start[d.n]) return;          // the binned particles (skipped ones have no slot)
+	const int p = order[slot];
+	const float x = pos[p], y = pos[ps + p], z = pos[2 * ps + p];
+	const Bi b = build_index(d, x, y, z);
+	const Bi s = build_index_shift(d, x, y, z);
+	const unsigned e = (unsigned)(s.xi - b.xi) | ((unsigned)(s.yi - b.yi) << 1) | ((unsigned)(s.zi - b.zi) << 2);
+	if (mac) {
+		rec[slot] = make_float4(s.s1, b.t1, b.f1, pval[p]);
+		rec[cp + slot] = make_float4(b.s1, s.t1, b.f1, pval[vstride + p]);
+		rec[2 * cp + slot] = make_float4(b.s1, b.t1, s.f1, pval[2 * vstride + p]);
+	} else {
+		rec[slot] = make_float4(b.s1, b.t1, b.f1, pval[p]);
+#pragma unroll
+		for (int c = 1; c < NV; c++) sv[(c - 1) * cp + slot] = pval[c * vstride + p];
+	}
+	spe[slot] = (unsigned)p | (e << PBITS);
+}
+// link words of every slot: a look-ahead inside the slot's own cell run
+__global__ void __launch_bounds__(BLOCK)
+k_bin_links(Dim d, const int32_t* __restrict__ start, const int32_t* __restrict__ keys, const uint32_t* __restrict__ spe, bool mac, int64_t cp,
+            uint2* __restrict__ link) {
+	const int64_t slot = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (slot >= start[d.n]) return;
+	const unsigned w = spe[slot];
+	const int end = start[keys[w & PMASK] + 1];
+	const unsigned any = slot + 1 < end ? ((spe[slot + 1] & PMASK) << 1) : 0xfffffffeu;
+	if (!mac) {
+		link[slot] = make_uint2(0u, any);
+		return;
+	}
+	unsigned same[3] = {0u, 0u, 0u};
+	int found = 0;
+	for (int64_t a = slot + 1; a < end && found != 7; a++) {
+		const unsigned u = spe[a];
+		const unsigned dist = a - slot < 15 ? (unsigned)(a - slot) : 15u;
+#pragma unroll
+		for (int c = 0; c < 3; c++)
+			if (!(found & (1 << c)) && ((u ^ w) >> (PBITS + c) & 1u) == 0u) {
+				same[c] = ((u & PMASK) << 4) | dist;
+				found |= 1 << c;
+			}
+	}
+#pragma unroll
+	for (int c = 0; c < 3; c++) link[c * cp + slot] = make_uint2(same[c], any | ((w >> (PBITS + c)) & 1u));
+}
+
+// ---- the gather: one thread per node, NCOMP values per particle (1 for a MAC component / Real grid, 3 for a Vec3 grid) ----
+// All active waves are resident at once, so the kernel takes as long as one node's chain  minimum -> cursor -> next head  times
+// its contributions: list heads live in registers as (p << 4 | list) words (one v_min chain finds the next particle AND its
+// list), the cursors of the 12 lists live in LDS ([list][thread]: a dynamic list index costs one ds_read instead of a 12-way
+// select), the next head comes from the winner's link word (ONE global round trip per contribution, no filter loop), and the
+// weights / value of a contribution are consumed one iteration later, so that their load never sits on the chain.
+// where a node's merge reads its lists from: the sorted arrays in global memory
+struct SrcGlobal {
+	const float4* __restrict__ rec_;
+	const uint2* __restrict__ link_;
+	const float* __restrict__ sv_;
+	int64_t cp;
+	const uint32_t* __restrict__ spe_;
+	const int32_t* __restrict__ start;
+	int sx, sy;
+	__device__ __forceinline__ void range(int bx, int by, int bz, unsigned& a, unsigned& e) const {
+		const int64_t c = (int64_t)bx + sx * ((int64_t)by + (int64_t)sy * bz);
+		a = (unsigned)start[c];
+		e = (unsigned)start[c + 1];
+	}
+	__device__ __forceinline__ unsigned spe(unsigned a) const { return spe_[a]; }
+	__device__ __forceinline__ uint2 link(unsigned a) const { return link_[a]; }
+	__device__ __forceinline__ float4 rec(unsigned a) const { return rec_[a]; }
+	__device__ __forceinline__ float sv(int c, unsigned a) const { return sv_[c * cp + a]; }
+};
+// ---- the merge of one node: NCOMP values per particle (1 for a MAC component / Real grid, 3 for a Vec3 grid) ----
+// The kernel takes as long as one node's chain  minimum -> cursor -> next head  times its contributions: list heads live in
+// registers as (p << 4 | list) words (one v_min chain finds the next particle AND its list), the cursors of the 12 lists live
+// in LDS ([list][thread]: a dynamic list index costs one ds_read instead of a 12-way select), the next head comes from the
+// winner's link word (no filter loop), and the weights / value of a contribution are consumed one iteration later, so that
+// their load never sits on the chain.
+template <int MODE, int NCOMP, int NT, class Src>
+__device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, const Src& src, uint2 (*s_ce)[NT], float* __restrict__ ref,
+                                           int64_t rstride, float* __restrict__ sum) {
+	constexpr int NL = (MODE == 3) ? 8 : 12;
+	constexpr unsigned INF = 0xffffffffu;
+	constexpr int ESH = PBITS + (MODE == 3 ? 0 : MODE);
+	// list q: offsets (o0, o1, o2) below the node along (shifted axis, next axis, next axis) for a MAC component -- 0 / 1 / 2
+	// along the shifted axis, of which offset 2 takes the entries with e = 1, offset 0 those with e = 0, offset 1 both -- and
+	// along (x, y, z) for a cell-centred grid.  meta = o0 | o1 << 2 | o2 << 3.
+	unsigned head[NL];
+#pragma unroll
+	for (int q = 0; q < NL; q++) {
+		int o[3];
+		unsigned meta;
+		if constexpr (MODE == 3) {
+			o[0] = q & 1; o[1] = (q >> 1) & 1; o[2] = q >> 2;
+			meta = (unsigned)(o[0] | (o[1] << 2) | (o[2] << 3));
+		} else {
+			constexpr int a1 = (MODE + 1) % 3, a2 = (MODE + 2) % 3;
+			o[MODE] = q % 3; o[a1] = (q / 3) & 1; o[a2] = q / 6;
+			meta = (unsigned)(o[MODE] | (o[a1] << 2) | (o[a2] << 3));
+		}
+		const int bx = i - o[0], by = j - o[1], bz = k - o[2];
+		const bool ok = bx >= 0 && by >= 0 && bz >= 0 && (d.is3d || o[2] == 0);
+		const unsigned want = (MODE == 3) ? 2u : ((meta & 3u) == 2u ? 1u : ((meta & 3u) == 0u ? 0u : 2u));
+		unsigned a = 0, e = 0;
+		if (ok) src.range(bx, by, bz, a, e);
+		unsigned h = INF;        // first entry that passes the filter
+		while (a < e) {
+			const unsigned w = src.spe(a);
+			if (want == 2u || ((w >> ESH) & 1u) == want) {
+				h = ((w & PMASK) << 4) | (unsigned)q;
+				break;
+			}
+			a++;
+		}
+		s_ce[q][threadIdx.x] = make_uint2(a, e | (meta << PBITS));
+		head[q] = h;
 	}
 	float acc_w = 0.f, acc_v[NCOMP];
 #pragma unroll
 	for (int c = 0; c < NCOMP; c++) acc_v[c] = 0.f;
-	for (;;) {
-		int best = INT_MAX, bm = 0;
-#pragma unroll
-		for (int q = 0; q < 8; q++)
-			if (head[q] < best) {
-				best = head[q];
-				bm = q;
-			}
-		if (best == INT_MAX) break;
-#pragma unroll
-		for (int q = 0; q < 8; q++)
-			if (q == bm) {
-				cur[q]++;
-				head[q] = cur[q] < end[q] ? order[cur[q]] : INT_MAX;
-			}
-		const int p = best;
-		const Corner c = corner_of<MODE>(d, pos[p], pos[ps + p], pos[2 * ps + p]);
-		const int di = bm & 1, dj = (bm >> 1) & 1, dk = bm >> 2;
-		const float sw = di ? c.s[1] : c.s[0], tw = dj ? c.t[1] : c.t[0];
-		float v[NCOMP];
-#pragma unroll
-		for (int cc = 0; cc < NCOMP; cc++) v[cc] = pval[cc * vstride + p];
+	// the contribution whose record is still in flight
+	bool pend = false;
+	float4 prec = make_float4(0.f, 0.f, 0.f, 0.f);
+	float pv1 = 0.f, pv2 = 0.f;
+	int pd0 = 0, pd1 = 0, pd2 = 0;
+	auto accumulate = [&](const float4& r, float v1, float v2, int d0, int d1, int d2) {
+		const float sw = d0 ? r.x : (float)(1. - (double)r.x);
+		const float tw = d1 ? r.y : (float)(1. - (double)r.y);
+		const float g1 = r.z, g0 = (float)(1. - (double)r.z);
+		float v[3] = {r.w, v1, v2};
 		if (d.is3d) {
-			const float w = tw * (sw * (dk ? c.f[1] : c.f[0]));
+			const float w = tw * (sw * (d2 ? g1 : g0));
 			acc_w += w;
 #pragma unroll
 			for (int cc = 0; cc < NCOMP; cc++) acc_v[cc] += w * v[cc];
 		} else {
 			// strideZ == 0: both z-corners land on this node, in the reference's statement order
-			const float wa = tw * (sw * ((MODE == 2) ? c.f[0] : c.f[1]));
-			const float wb = tw * (sw * ((MODE == 2) ? c.f[1] : c.f[0]));
+			const float wa = tw * (sw * ((MODE == 2) ? g0 : g1));
+			const float wb = tw * (sw * ((MODE == 2) ? g1 : g0));
 			acc_w += wa;
 			acc_w += wb;
 #pragma unroll
@@ -126,33 +413,100 @@ k_gather(Dim d, int64_t ps, const float* __restrict__ pos, const float* __restri
 				acc_v[cc] += wb * v[cc];
 			}
 		}
+	};
+	for (;;) {
+		unsigned best = head[0];
+#pragma unroll
+		for (int q = 1; q < NL; q++) best = head[q] < best ? head[q] : best;
+		if (best == INF) break;
+		const unsigned bq = best & 15u;
+		const uint2 ce = s_ce[bq][threadIdx.x];
+		const unsigned slot = ce.x, e = ce.y & PMASK, meta = ce.y >> PBITS;
+		const uint2 lk = src.link(slot);
+		const float4 r = src.rec(slot);
+		float v1 = 0.f, v2 = 0.f;
+		if (NCOMP == 3) {
+			v1 = src.sv(0, slot);
+			v2 = src.sv(1, slot);
+		}
+		if (pend) accumulate(prec, pv1, pv2, pd0, pd1, pd2);
+		// advance the winner's list: the link word names the next entry (and its particle) without another load
+		const unsigned osh = meta & 3u;
+		unsigned a, h;
+		if (MODE == 3 || osh == 1u) {
+			a = slot + 1;
+			h = (a < e) ? (((lk.y >> 1) << 4) | bq) : INF;
+		} else {
+			const unsigned dist = lk.x & 15u;
+			a = slot + dist;
+			h = dist ? ((lk.x & ~15u) | bq) : INF;
+			if (dist == 15u) {
+				// the next entry with this e bit is 15 or more slots away: walk
+				const unsigned want = osh == 2u ? 1u : 0u;
+				h = INF;
+				while (a < e) {
+					const unsigned w = src.spe(a);
+					if (((w >> ESH) & 1u) == want) {
+						h = ((w & PMASK) << 4) | bq;
+						break;
+					}
+					a++;
+				}
+			}
+		}
+		s_ce[bq][threadIdx.x].x = a;
+#pragma unroll
+		for (int q = 0; q < NL; q++) head[q] = (bq == (unsigned)q) ? h : head[q];
+		// corner of this node as seen from the particle: offset - e along the shifted axis, the offset itself elsewhere
+		if constexpr (MODE == 3) {
+			pd0 = meta & 1; pd1 = (meta >> 2) & 1; pd2 = (meta >> 3) & 1;
+		} else {
+			int dd[3];
+			constexpr int a1 = (MODE + 1) % 3, a2 = (MODE + 2) % 3;
+			dd[MODE] = (int)osh - (int)(lk.y & 1u);
+			dd[a1] = (meta >> 2) & 1;
+			dd[a2] = (meta >> 3) & 1;
+			pd0 = dd[0]; pd1 = dd[1]; pd2 = dd[2];
+		}
+		prec = r;
+		pv1 = v1;
+		pv2 = v2;
+		pend = true;
 	}
+	if (pend) accumulate(prec, pv1, pv2, pd0, pd1, pd2);
+	const int64_t node = (int64_t)i + d.sx * ((int64_t)j + (int64_t)d.sy * k);
 	sum[node] = acc_w;
 #pragma unroll
 	for (int cc = 0; cc < NCOMP; cc++) ref[cc * rstride + node] = acc_v[cc];
 }
 
+// one thread per node; a wave owns a compact GX x GY x GZ tile of nodes, so that the runs its 64 merges walk (a cell's run feeds up
+// to 12 nodes of the tile) are pulled into the CU's L1 once.  (Tried and dropped, both bit-exact: a workgroup copying the runs of
+// its tile's neighbourhood into LDS first -- 79 KB per 128 nodes leave one wave per SIMD, and a lone wave needs ~2000 cycles per
+// contribution for this chain: 0.61 ms per component against 0.39 ms; and rec + link as ONE 32-byte record, one cache line per
+// contribution: the gathers go from 0.35 to 0.325 ms, the two payload kernels from 0.13 to 0.31 ms.)  Where the time goes (PMC,
+// 128^3, 3.8 M particles, one component): 1.7 M load instructions touch 67 M cache lines, 17 % of them L1 hits -- the merges of
+// the ~15 waves of a CU walk ~30 KB of runs each, far more than its 32 KB L1 -- so the kernel runs at the L2 -> L1 request rate.
+constexpr int GBLOCK = 64, GX = 4, GY = 4, GZ = 4;
+template <int MODE, int NCOMP>
+__global__ void __launch_bounds__(GBLOCK)
+k_gather(Dim d, int ntx, int nty, const float4* __restrict__ rec, const uint2* __restrict__ link, const float* __restrict__ sv, int64_t cp,
+         const uint32_t* __restrict__ spe, const int32_t* __restrict__ start, float* __restrict__ ref, int64_t rstride, float* __restrict__ sum) {
+	__shared__ uint2 s_ce[(MODE == 3) ? 8 : 12][GBLOCK];       // {cursor, end | offsets << PBITS}
+	const int tile = xcd_swizzle(blockIdx.x, gridDim.x), t = threadIdx.x;
+	const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+	// 2-D grids: the tile is GX*GZ x GY x 1
+	const int i = d.is3d ? tx * GX + (t % GX) : tx * (GX * GZ) + (t % (GX * GZ));
+	const int j = d.is3d ? ty * GY + (t / GX) % GY : ty * GY + t / (GX * GZ);
+	const int k = d.is3d ? tz * GZ + t / (GX * GY) : 0;
+	if (i >= d.sx || j >= d.sy || k >= d.sz) return;
+	const SrcGlobal src{rec, link, sv, cp, spe, start, d.sx, d.sy};
+	merge_node<MODE, NCOMP, GBLOCK>(d, i, j, k, src, s_ce, ref, rstride, sum);
+}
+
 // ---- APIC (knApicMapLinearVec3ToMACGrid, apic.cpp:19-90): same gather, other weights.  The reference addresses the 8 nodes
 // by FLAT index gidx + dX[i] + dY[j] + dZ[k] with no bounds check; the gather follows the flat arithmetic (a node n is fed by
 // the base indices n - (i + j*Y + k*Z)), faces whose base index lies outside [0, n) are skipped like in the oracle.
-template <int COMP>
-__global__ void __launch_bounds__(BLOCK)
-k_keys_apic(Dim d, int64_t np, int64_t ps, const float* __restrict__ pos, const int32_t* __restrict__ pflag, const int32_t* __restrict__ ptype,
-            int exclude, int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ counts) {
-	const int64_t p = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-	if (p >= np) return;
-	int key = (int)d.n;
-	if (!((pflag[p] & MF_PDELETE) || (ptype && (ptype[p] & exclude)))) {
-		const ApicFace a = apic_face<COMP>(d, pos[p], pos[ps + p], pos[2 * ps + p]);
-		if (a.gidx >= 0 && a.gidx < d.n) {
-			key = (int)a.gidx;
-			atomicAdd(&counts[key], 1);
-		}
-	}
-	keys[p] = key;
-	vals[p] = (int)p;
-}
-
 // one thread per node of face COMP: per particle (increasing index)  m += w ; v += w*vel_c ; v += w*dot(cp_c, node - pos)
 template <int COMP>
 __global__ void __launch_bounds__(BLOCK)
@@ -212,80 +566,81 @@ k_gather_apic(Dim d, int64_t ps, const float* __restrict__ pos, const float* __r
 }
 
 struct Scratch {
-	int32_t* keys = nullptr;    // [2 * cap_p]
-	int32_t* vals = nullptr;    // [2 * cap_p]
-	int32_t* counts = nullptr;  // [cap_n + 1]
-	int32_t* start = nullptr;   // [cap_n + 1]
-	void* tmp = nullptr;
+	int32_t* keys = nullptr;     // [cap_p]
+	int32_t* order = nullptr;    // [cap_p]
+	int32_t* tmp = nullptr;      // [cap_p]   (rank-counting sort of a crowded cell)
+	float* pay = nullptr;        // [18 * cap_p]  rec[3] (float4), link[3] (uint2) in slot order; extra value planes of a Vec3 source alias rec[1]
+	uint32_t* spe = nullptr;     // [cap_p]
+	int32_t* counts = nullptr;   // [cap_n + 1]
+	int32_t* start = nullptr;    // [cap_n + 1]
+	int32_t* big = nullptr;      // [cap_n]
+	int32_t* sums = nullptr;     // [scan blocks of cap_n + 1]
+	int32_t* nbig = nullptr;
 	int64_t cap_p = 0, cap_n = 0;
-	size_t cap_tmp = 0;
 };
 Scratch g_scratch[16];
 
-int get_scratch(int64_t np, int64_t n, size_t tmp_bytes, Scratch** out) {
+int get_scratch(int64_t np, int64_t n, Scratch** out) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	Scratch& s = g_scratch[dev];
-	if (np > s.cap_p || n > s.cap_n || tmp_bytes > s.cap_tmp) MF_HIP(hipDeviceSynchronize());
+	if (np > s.cap_p || n > s.cap_n) MF_HIP(hipDeviceSynchronize());
+	if (!s.nbig) MF_HIP(hipMalloc((void**)&s.nbig, sizeof(int32_t)));
 	if (np > s.cap_p) {
-		if (s.keys) MF_HIP(hipFree(s.keys));
-		if (s.vals) MF_HIP(hipFree(s.vals));
+		for (void* q : {(void*)s.keys, (void*)s.order, (void*)s.tmp, (void*)s.pay, (void*)s.spe})
+			if (q) MF_HIP(hipFree(q));
 		s.cap_p = np + np / 8 + 1024;
-		MF_HIP(hipMalloc((void**)&s.keys, sizeof(int32_t) * 2 * s.cap_p));
-		MF_HIP(hipMalloc((void**)&s.vals, sizeof(int32_t) * 2 * s.cap_p));
+		MF_HIP(hipMalloc((void**)&s.keys, sizeof(int32_t) * s.cap_p));
+		MF_HIP(hipMalloc((void**)&s.order, sizeof(int32_t) * s.cap_p));
+		MF_HIP(hipMalloc((void**)&s.tmp, sizeof(int32_t) * s.cap_p));
+		MF_HIP(hipMalloc((void**)&s.pay, sizeof(float) * 18 * s.cap_p));
+		MF_HIP(hipMalloc((void**)&s.spe, sizeof(uint32_t) * s.cap_p));
 	}
 	if (n > s.cap_n) {
-		if (s.counts) MF_HIP(hipFree(s.counts));
-		if (s.start) MF_HIP(hipFree(s.start));
+		for (void* q : {(void*)s.counts, (void*)s.start, (void*)s.big, (void*)s.sums})
+			if (q) MF_HIP(hipFree(q));
 		s.cap_n = n;
 		MF_HIP(hipMalloc((void**)&s.counts, sizeof(int32_t) * (s.cap_n + 1)));
 		MF_HIP(hipMalloc((void**)&s.start, sizeof(int32_t) * (s.cap_n + 1)));
-	}
-	if (tmp_bytes > s.cap_tmp) {
-		if (s.tmp) MF_HIP(hipFree(s.tmp));
-		s.cap_tmp = tmp_bytes + (tmp_bytes >> 2);
-		MF_HIP(hipMalloc(&s.tmp, s.cap_tmp));
+		MF_HIP(hipMalloc((void**)&s.big, sizeof(int32_t) * s.cap_n));
+		MF_HIP(hipMalloc((void**)&s.sums, sizeof(int32_t) * ((s.cap_n + 1) / (BLOCK * SCAN_ITEMS) + 2)));
 	}
 	*out = &s;
 	return 0;
 }
 
-template <int MODE, int NCOMP>
-int run(const Dim& d, int64_t np, int64_t ps, const float* pos, const int32_t* pflag, const int32_t* ptype, int exclude,
-        const float* pval, int64_t vstride, float* ref, int64_t rstride, float* sum, hipStream_t st) {
-	if (np >= ((int64_t)1 << 31) - 1) return fail("ordered P2G: too many particles for 32-bit indices");
-	size_t scan_bytes = 0, sort_bytes = 0;
-	int end_bit = 1;
-	while (end_bit < 31 && (((int64_t)1 << end_bit) <= d.n)) end_bit++;
-	MF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)(d.n + 1), st));
-	MF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)np, 0, end_bit, st));
-	Scratch* s;
-	MF_TRY(get_scratch(np, d.n, (scan_bytes > sort_bytes ? scan_bytes : sort_bytes) + 256, &s));
-	MF_HIP(hipMemsetAsync(s->counts, 0, sizeof(int32_t) * (d.n + 1), st));
-	hipLaunchKernelGGL((k_keys<MODE>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, np, ps, pos, pflag, ptype, exclude, s->keys, s->vals, s->counts);
-	MF_HIP(hipcub::DeviceScan::ExclusiveSum(s->tmp, scan_bytes, s->counts, s->start, (int)(d.n + 1), st));
-	MF_HIP(hipcub::DeviceRadixSort::SortPairs(s->tmp, sort_bytes, s->keys, s->keys + np, s->vals, s->vals + np, (int)np, 0, end_bit, st));
-	hipLaunchKernelGGL((k_gather<MODE, NCOMP>), dim3(nblk_n(d.n)), dim3(BLOCK), 0, st, d, ps, pos, pval, vstride, s->vals + np, s->start, ref, rstride, sum);
+// start[0..n], order[0..start[n]) : the particles of every key in increasing particle index
+template <int KEYMODE>
+int bin_particles(const Dim& d, int64_t np, int64_t ps, const float* pos, const int32_t* pflag, const int32_t* ptype, int exclude, Scratch* s,
+                  hipStream_t st) {
+	const int64_t n1 = d.n + 1;
+	const int nsb = (int)((n1 + BLOCK * SCAN_ITEMS - 1) / (BLOCK * SCAN_ITEMS));
+	MF_HIP(hipMemsetAsync(s->counts, 0, sizeof(int32_t) * n1, st));
+	MF_HIP(hipMemsetAsync(s->nbig, 0, sizeof(int32_t), st));
+	hipLaunchKernelGGL((k_bin_keys<KEYMODE>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, np, ps, pos, pflag, ptype, exclude, s->keys, s->counts);
+	hipLaunchKernelGGL(k_scan_sums, dim3(nsb), dim3(BLOCK), 0, st, n1, s->counts, s->sums);
+	hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(BLOCK), 0, st, nsb, s->sums);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(nsb), dim3(BLOCK), 0, st, n1, s->counts, s->sums, s->start);
+	hipLaunchKernelGGL(k_bin_place, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d.n, np, s->keys, s->start, s->counts, s->order);
+	hipLaunchKernelGGL(k_bin_sort_cells, dim3(nblk_n(d.n)), dim3(BLOCK), 0, st, d.n, s->start, s->order, s->nbig, s->big);
+	hipLaunchKernelGGL(k_bin_sort_big, dim3(256), dim3(BLOCK), 0, st, s->start, s->order, s->nbig, s->big, s->tmp);
 	MF_LAUNCH_CHECK();
+	return 0;
+}
+
+int check_np(int64_t np) {
+	if (np >= ((int64_t)1 << PBITS)) return fail("ordered P2G: more than 2^%d particles; use the atomic mode (setDeterministicP2G(False))", PBITS);
 	return 0;
 }
 
 template <int COMP>
 int run_apic(const Dim& d, int64_t np, int64_t ps, const float* pos, const int32_t* pflag, const int32_t* ptype, int exclude,
              const float* pvc, const float* cp, float* vel, float* mass, hipStream_t st) {
-	if (np >= ((int64_t)1 << 31) - 1) return fail("ordered P2G: too many particles for 32-bit indices");
-	size_t scan_bytes = 0, sort_bytes = 0;
-	int end_bit = 1;
-	while (end_bit < 31 && (((int64_t)1 << end_bit) <= d.n)) end_bit++;
-	MF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)(d.n + 1), st));
-	MF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)np, 0, end_bit, st));
+	MF_TRY(check_np(np));
 	Scratch* s;
-	MF_TRY(get_scratch(np, d.n, (scan_bytes > sort_bytes ? scan_bytes : sort_bytes) + 256, &s));
-	MF_HIP(hipMemsetAsync(s->counts, 0, sizeof(int32_t) * (d.n + 1), st));
-	hipLaunchKernelGGL((k_keys_apic<COMP>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, np, ps, pos, pflag, ptype, exclude, s->keys, s->vals, s->counts);
-	MF_HIP(hipcub::DeviceScan::ExclusiveSum(s->tmp, scan_bytes, s->counts, s->start, (int)(d.n + 1), st));
-	MF_HIP(hipcub::DeviceRadixSort::SortPairs(s->tmp, sort_bytes, s->keys, s->keys + np, s->vals, s->vals + np, (int)np, 0, end_bit, st));
-	hipLaunchKernelGGL((k_gather_apic<COMP>), dim3(nblk_n(d.n)), dim3(BLOCK), 0, st, d, ps, pos, pvc, cp, s->vals + np, s->start, vel, mass);
+	MF_TRY(get_scratch(np, d.n, &s));
+	MF_TRY((bin_particles<10 + COMP>(d, np, ps, pos, pflag, ptype, exclude, s, st)));
+	hipLaunchKernelGGL((k_gather_apic<COMP>), dim3(nblk_n(d.n)), dim3(BLOCK), 0, st, d, ps, pos, pvc, cp, s->order, s->start, vel, mass);
 	MF_LAUNCH_CHECK();
 	return 0;
 }
@@ -297,16 +652,49 @@ namespace mf {
 // vel / weight: SoA MAC grids (already zeroed or not: every node is written)
 int p2g_ordered_mac(const Dim& d, float* vel, float* weight, int64_t np, int64_t ps, const float* pos, const int32_t* pflag,
                     const float* pvel, const int32_t* ptype, int exclude, hipStream_t st) {
-	MF_TRY((run<0, 1>(d, np, ps, pos, pflag, ptype, exclude, pvel, ps, vel, d.n, weight, st)));
-	MF_TRY((run<1, 1>(d, np, ps, pos, pflag, ptype, exclude, pvel + ps, ps, vel + d.n, d.n, weight + d.n, st)));
-	MF_TRY((run<2, 1>(d, np, ps, pos, pflag, ptype, exclude, pvel + 2 * ps, ps, vel + 2 * d.n, d.n, weight + 2 * d.n, st)));
+	MF_TRY(check_np(np));
+	Scratch* s;
+	MF_TRY(get_scratch(np, d.n, &s));
+	MF_TRY((bin_particles<3>(d, np, ps, pos, pflag, ptype, exclude, s, st)));
+	const int64_t cp = s->cap_p;
+	float4* rec = (float4*)s->pay;
+	uint2* link = (uint2*)(s->pay + 12 * cp);
+	// the number of binned particles is start[n], known on the device only: the payload kernels are launched over np slots and
+	// bound themselves
+	hipLaunchKernelGGL((k_bin_payload<3>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, ps, pos, pvel, ps, s->order, true, rec, (float*)nullptr, cp, s->spe);
+	hipLaunchKernelGGL(k_bin_links, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, s->keys, s->spe, true, cp, link);
+	const int ntx = d.is3d ? (d.sx + GX - 1) / GX : (d.sx + GX * GZ - 1) / (GX * GZ), nty = (d.sy + GY - 1) / GY, ntz = d.is3d ? (d.sz + GZ - 1) / GZ : 1;
+	const unsigned nb = (unsigned)(ntx * nty * ntz);
+	hipLaunchKernelGGL((k_gather<0, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, (const float*)nullptr, cp, s->spe, s->start, vel, d.n, weight);
+	hipLaunchKernelGGL((k_gather<1, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + cp, link + cp, (const float*)nullptr, cp, s->spe, s->start, vel + d.n, d.n, weight + d.n);
+	hipLaunchKernelGGL((k_gather<2, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + 2 * cp, link + 2 * cp, (const float*)nullptr, cp, s->spe, s->start, vel + 2 * d.n, d.n, weight + 2 * d.n);
+	MF_LAUNCH_CHECK();
 	return 0;
 }
 // target: ncomp planes; wsum: Real grid
 int p2g_ordered_cell(const Dim& d, int ncomp, float* target, float* wsum, int64_t np, int64_t ps, const float* pos,
                      const int32_t* pflag, const float* psrc, hipStream_t st) {
-	if (ncomp == 1) return run<3, 1>(d, np, ps, pos, pflag, nullptr, 0, psrc, ps, target, d.n, wsum, st);
-	return run<3, 3>(d, np, ps, pos, pflag, nullptr, 0, psrc, ps, target, d.n, wsum, st);
+	MF_TRY(check_np(np));
+	Scratch* s;
+	MF_TRY(get_scratch(np, d.n, &s));
+	MF_TRY((bin_particles<3>(d, np, ps, pos, pflag, nullptr, 0, s, st)));
+	const int64_t cp = s->cap_p;
+	float4* rec = (float4*)s->pay;
+	float* sv = s->pay + 4 * cp;                 // the second and third value plane of a Vec3 source
+	uint2* link = (uint2*)(s->pay + 12 * cp);
+	const int ntx = d.is3d ? (d.sx + GX - 1) / GX : (d.sx + GX * GZ - 1) / (GX * GZ), nty = (d.sy + GY - 1) / GY, ntz = d.is3d ? (d.sz + GZ - 1) / GZ : 1;
+	const unsigned nb = (unsigned)(ntx * nty * ntz);
+	if (ncomp == 1)
+		hipLaunchKernelGGL((k_bin_payload<1>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, ps, pos, psrc, ps, s->order, false, rec, sv, cp, s->spe);
+	else
+		hipLaunchKernelGGL((k_bin_payload<3>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, ps, pos, psrc, ps, s->order, false, rec, sv, cp, s->spe);
+	hipLaunchKernelGGL(k_bin_links, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, s->keys, s->spe, false, cp, link);
+	if (ncomp == 1)
+		hipLaunchKernelGGL((k_gather<3, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, sv, cp, s->spe, s->start, target, d.n, wsum);
+	else
+		hipLaunchKernelGGL((k_gather<3, 3>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, sv, cp, s->spe, s->start, target, d.n, wsum);
+	MF_LAUNCH_CHECK();
+	return 0;
 }
 
 // vel / mass: SoA MAC grids; in 2-D the w face is not touched by the reference (apic.cpp:73) -> the caller's zeros stay

@@ -585,6 +585,33 @@ def test_ordered_p2g_bitexact_at_scale(hip_backend, dims, per_cell):
         assert_bitexact(a[k], a2[k], k + " (re-run)")
 
 
+def test_ordered_p2g_crowded_cells(hip_backend):
+    """the binning pass of the ordered transfer with crowded cells: a cell with 6000 particles (beyond the workgroup sort's LDS:
+    rank counting), cells with hundreds (workgroup bitonic sort) and the usual few per cell (per-cell insertion sort), particle
+    order shuffled -- bit-identical to the oracle's serial scatter"""
+    from mantaflow_amd import _lib
+    dims = (20, 16, 12)
+    flags = util.make_flags(*dims, 71, empty_top=False)
+    vel, velOld = util.rand_vel(*dims, 72), util.rand_vel(*dims, 73)
+    pos, pflag, pvel = util.make_particles(flags, 3, 74)
+    rng = np.random.default_rng(75)
+    crowds = [((7, 6, 5), 6000), ((8, 6, 5), 700), ((7, 7, 5), 300), ((12, 3, 9), 40), ((1, 1, 1), 5000)]
+    extra = [np.array(c, np.float32)[:, None] + rng.uniform(0.0, 1.0, (3, m)).astype(np.float32) for c, m in crowds]
+    pos = np.concatenate([pos] + extra, axis=1)
+    n = pos.shape[1]
+    perm = rng.permutation(n)
+    pos = np.ascontiguousarray(pos[:, perm])
+    pflag = np.concatenate([pflag, np.zeros(n - pflag.shape[0], np.int32)])[perm]
+    pvel = np.ascontiguousarray(np.concatenate([pvel, rng.normal(0, 0.5, (3, n - pvel.shape[1])).astype(np.float32)], axis=1)[:, perm])
+    keys = ("p2g_vel", "p2g_velOld", "p2g_weight", "p2g_real", "p2g_vec3")
+    a = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel)
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_flip_pkg(dims, flags, vel, velOld, pos, pflag, pvel)
+    _lib.reset()
+    for k in keys:
+        assert_bitexact(a[k], b[k], k)
+
+
 @pytest.mark.parametrize("orderSpace", [1, 2])
 @pytest.mark.parametrize("case", range(len(cases.INTERP_CASES)))
 def test_interpolate_between_grid_sizes(hip_backend, case, orderSpace):
