@@ -181,7 +181,9 @@ int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* ds
 
 /* GridCg<ApplyMatrix>::doInit + iterate loop, conjugategrad.cpp:210-307, driven like
  * solvePressureSystem's loop (plugin/pressure.cpp:438-441).
- *   dst(pressure), residual, search, tmp : work grids, overwritten (dst = solution)
+ *   dst(pressure), residual, search, tmp : work grids, overwritten (dst = solution; the contents of residual / search / tmp /
+ *   Aprecond after the call are unspecified: with the MIC preconditioner and a row length that is not a multiple of 8 the loop
+ *   runs on an internal copy of the system whose rows are padded with obstacle cells -- same iterates, 16-byte rows)
  *   pc = MF_PC_NONE | MF_PC_MICP; Aprecond: grid for the MIC factor (pca0), unused for PC_NONE
  *   out_host[0] = iterations done, out_host[1] = final residual norm (mResNorm), out_host[2] = mSigma
  * returns non-zero with message "The CG solver diverged" when resNorm !< 1e35 (conjugategrad.cpp:288-295). */
