@@ -29,6 +29,11 @@ APPLY_MATRIX_BYTES_PER_CELL = 28  # flags 4 + src 4 + A0,Ai,Aj,Ak 16 
 MIC_BYTES_PER_CELL = 56           # (flags 4, var1 4, Aprecond 4, Ai, Aj, Ak 12 read; dst 4 written) x 2 sweeps
 CG_ITERATION_BYTES_PER_CELL = 144  # 96 (unpreconditioned, as structured by the reference) - 8 (copy) + 56 (MIC apply)
 STEP_FIXED_BYTES_PER_CELL = 92 + 188 + 20 + 24 + 28 + 20 + 20 + 28 + 32   # once per step, SURVEY 8d table (see roofline_step below)
+# what the kernels as built stream per cell: per PCG iteration ApplyMatrix on the packed byte (src 4, dst 4, byte 1),
+# k_cg_axpy_r (residual r/w 8, tmp 4), forward sweep (var1 4, Aprecond 4, byte 1, dst 4), backward sweep with the fused dot (dst r/w 8,
+# Aprecond 4, byte 1, residual 4), k_cg_update_search_x (search r/w 8, tmp 4, pressure r/w 8)
+MOVED_ITERATION_BYTES_PER_CELL = 9 + 12 + 13 + 17 + 20
+MOVED_FIXED_BYTES_PER_CELL = 76 + 160 + 24 + 28 + 20 + 20 + 21 + 28 + 36 + 32
 
 
 def synthetic_velocity(sx, sy, sz, seed=7, vmax=2.0):
@@ -72,12 +77,13 @@ def domain_flags(sx, sy, sz):
     return f
 
 
-def cpu_baseline(sample_dims, vel, dens, flags, dt):
-    """The reference CPU path timed on this host: one step of the same workload on a bounded sample (a z-slab of the
-    256^3 input re-walled as its own domain).  kind 'reference' = the reference's own C++/OpenMP (oracle/_ref)."""
+def cpu_baseline(dims, vel, dens, dt, gpu_iterations):
+    """The reference CPU path timed on this host: ONE step of the same workload at full size (256^3: about half a minute on the GPU
+    box's host cores -- the MIC sweeps and nothing else are serial in the reference).  kind 'reference' = the reference's own
+    C++/OpenMP (oracle/_ref), 'port' = the plain-C oracle where the compiled reference did not travel."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util
-    sx, sy, sz = sample_dims
+    sx, sy, sz = dims
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -85,13 +91,15 @@ def cpu_baseline(sample_dims, vel, dens, flags, dt):
         pass
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     os.environ.setdefault("OMP_PROC_BIND", "close")
-    v = np.ascontiguousarray(vel[:, :sz])
-    d = np.ascontiguousarray(dens[:sz])
+    v = np.ascontiguousarray(vel)
+    d = np.ascontiguousarray(dens)
     f = domain_flags(sx, sy, sz)
     cf = ctypes.c_float
+    iters = None
     if util.have_ref():
         import cases  # noqa: F401
         kind = "reference"
+        util.refcall("ref_set_wall_bcs", sx, sy, sz, f, v, None)
         t0 = time.time()
         util.refcall("ref_advect_semi_lagrange", sx, sy, sz, cf(dt), f, v, d, 0, 2, cf(1.0), 1, 2, 1)
         v2 = v.copy()
@@ -100,25 +108,31 @@ def cpu_baseline(sample_dims, vel, dens, flags, dt):
         p = np.zeros((sz, sy, sx), np.float32)
         util.refcall("ref_solve_pressure", sx, sy, sz, v2, p, f, cf(1e-3), None, None, None, None, cf(1e-4), cf(1.5), 1, 1, 0, 0, 0, None, cf(0.0), None)
         el = time.time() - t0
+        it_note = ("%s CG iterations: the GPU's count on this input; the reference's own solvePressure does not return its count, the oracle's is "
+                   "identical to the reference's (tests/test_oracle_vs_reference.py) and to the GPU's at this size (tests/test_gpu_fullsize.py config 2)"
+                   % gpu_iterations)
     else:
         import cases
         from mantaflow_amd import _lib, core, plugins
         kind = "port"
         _lib.use_library(util.build_oracle(), "cpu")
-        s = cases._mk_solver(sample_dims, dt)
+        s = cases._mk_solver(dims, dt)
         fl, vg, dg, pg = core.FlagGrid(s), core.MACGrid(s), core.Grid(s), core.Grid(s)
         cases.soa_to_grid(fl, f); cases.soa_to_grid(vg, v); cases.soa_to_grid(dg, d)
+        plugins.setWallBcs(fl, vg)
         t0 = time.time()
         plugins.advectSemiLagrange(fl, vg, dg, order=2)
         plugins.advectSemiLagrange(fl, vg, vg, order=2)
         plugins.setWallBcs(fl, vg)
         plugins.solvePressure(vg, pg, fl)
         el = time.time() - t0
+        iters = plugins.lastCgStats().get("iterations")
+        it_note = "%s CG iterations (counted)" % iters
         _lib.reset()
     cells = sx * sy * sz
     return {"value": round(cells / el / 1e6, 4), "unit": "Mcells/s", "cores": cores, "kind": kind,
-            "sample": "1 step (advect density+vel order 2, setWallBcs, solvePressure MIC-CG 1e-3) of the same synthetic "
-                      "input on its first %d z-planes as a %dx%dx%d domain, %.1f s" % (sz, sx, sy, sz, el)}
+            "sample": "1 full step (advect density+vel order 2, setWallBcs, solvePressure MIC-CG 1e-3) of the same synthetic "
+                      "%dx%dx%d input, %.1f s, %s" % (sx, sy, sz, el, it_note)}
 
 
 class OpClock(object):
@@ -523,7 +537,12 @@ def main():
                                   "bound": "dependency chain (serial sweep in the reference), hbm if it were free",
                                   "achieved": round(mic_bytes / (mic_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(mic_bytes / (mic_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_apply_us": round(mic_us, 1),
-                                  "algorithmic_bytes_per_apply": mic_bytes, "traffic": mic_traffic, "traffic_source": mic_traffic_src}
+                                  "algorithmic_bytes_per_apply": mic_bytes, "traffic": mic_traffic, "traffic_source": mic_traffic_src,
+                                  "achieved_on_measured_traffic": None if not mic_traffic else round(mic_traffic / (mic_us * 1e-6) / 1e9, 1),
+                                  "frac_on_measured_traffic": None if not mic_traffic else round(mic_traffic / (mic_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "note": "achieved / frac price the reference's unfused structure (SURVEY 8d: 56 B per cell and apply) at the measured "
+                                          "time -- a speed against the reference-structure roofline; the packed sweeps move fewer bytes (traffic), "
+                                          "and *_on_measured_traffic is the bandwidth they really draw"}
         # ---- the whole step against the HBM roofline: SURVEY 8d's algorithmic bytes of every operator of the step / ms_per_step
         its = float(np.mean(result["cg_iterations"])) if result["cg_iterations"] else 0.0
         step_bytes = (STEP_FIXED_BYTES_PER_CELL + its * CG_ITERATION_BYTES_PER_CELL) * n ** 3
@@ -533,14 +552,23 @@ def main():
                                    "bytes_per_cell": {"fixed (MacCormack Real 92 + MAC 188 + outflow sweeps 20 + velocity restore 24 + setWallBcs 28 "
                                                       "+ MakeRhs 20 + MakeLaplaceMatrix 20 + MIC init 28 + correctVelocity 32)": STEP_FIXED_BYTES_PER_CELL,
                                                       "per CG iteration (ApplyMatrix 28 + 2 dot 16 + 2 axpy 24 + max-norm 8 + search update 12 + MIC apply 56)": CG_ITERATION_BYTES_PER_CELL,
-                                                      "mean CG iterations": round(its, 1)}}
+                                                      "mean CG iterations": round(its, 1)},
+                                   "moved_bytes_per_step": int((MOVED_FIXED_BYTES_PER_CELL + its * MOVED_ITERATION_BYTES_PER_CELL) * n ** 3),
+                                   "moved_bytes_per_cell": {"per CG iteration as built (ApplyMatrix on packed bytes 9 + residual update and max-norm 12 + forward sweep 13 "
+                                                            "+ backward sweep with dot 17 + search / pressure update 20)": MOVED_ITERATION_BYTES_PER_CELL,
+                                                            "fixed as built (MacCormack Real 76 + MAC 160 + restore 24 + setWallBcs 28 + MakeRhs 20 + MakeLaplaceMatrix 20 "
+                                                            "+ pack 21 + MIC init 28 + doInit copies 36 + correctVelocity 32)": MOVED_FIXED_BYTES_PER_CELL},
+                                   "frac_on_moved_bytes": round((MOVED_FIXED_BYTES_PER_CELL + its * MOVED_ITERATION_BYTES_PER_CELL) * n ** 3
+                                                                / (el / max(a.steps, 1)) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "achieved / frac price the reference's structure (SURVEY 8d) at the measured step time; frac_on_moved_bytes uses the "
+                                           "bytes the fused / packed kernels stream (own model, DESIGN.md section 3)"}
         del A0, Ai, Aj, Ak, src, dst, ap
         if not a.no_other_configs and n == GRID:
             del flags, vel, vel0, dens, pres, s
             torch.cuda.empty_cache()
             result["other_configs"] = other_configs(torch, core, plugins)
         if not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline((n, n, max(16, n // 4)), v_np, d_np, None, dt)
+            result["cpu_baseline"] = cpu_baseline((n, n, n), v_np, d_np, dt, result["cg_iterations"][-1] if result["cg_iterations"] else None)
 
     if world > 1:
         t = torch.tensor([result["elapsed"]], dtype=torch.float64, device="cuda")
@@ -557,7 +585,8 @@ def main():
             "config": {"workload": "%d^3 smoke step on %d x MI355X: advectSemiLagrange(density, order 2) + "
                                    "advectSemiLagrange(vel, order 2) + setWallBcs + solvePressure (MIC-CG, cgAccuracy 1e-3)" % (n, a.gpus),
                        "grid": [n, n, n], "cg_iterations_per_step": result.get("cg_iterations"),
-                       "parallelism": "single GPU" if a.gpus == 1 else "z-slab x%d, 1-plane halo p2p + RCCL all-reduce of CG scalars" % a.gpus},
+                       "parallelism": "single GPU" if a.gpus == 1 else ("z-slab x%d, 1-plane halo p2p per PCG iteration + one RCCL all-gather per reduction point "
+                                                                          "(16-byte rows, summed in rank order); N = 1 of this code path is `bench.py --slab`" % a.gpus)},
         }
         if "roofline" in result:
             line["roofline"] = result["roofline"]

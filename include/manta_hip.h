@@ -47,6 +47,15 @@ enum { MF_PC_NONE = 0, MF_PC_ICP = 1, MF_PC_MICP = 2, MF_PC_MGP = 3 };
 const char* mf_last_error(void);
 /* "hip" | "oracle" | "reference" -- which implementation answered (tests assert on this) */
 const char* mf_backend(void);
+/* ABI revision of this header.  It changes whenever an existing entry point changes its arguments (a binding built against another
+ * revision would pass, e.g., the stream pointer where an int is now expected): a loader compares mf_abi_version() of the library
+ * it opened with the MF_ABI_VERSION it was built against and refuses a mismatch (mantaflow_amd/_lib.py does).
+ *   1  round 1
+ *   2  round 2: mf_semi_lagrange_{real,vec3,mac}, mf_interpolate_grid, mf_interpolate_mac_grid take `int orderSpace` before `stream`;
+ *      mf_apply_noise_vec3 takes four uv arguments; mf_set_mic_blocking / mf_set_mic_blocking_x replaced by mf_mic_init_blocked
+ *   3  round 3: mf_abi_version itself; mf_set_mic_mode knows "rows" and "levels" only */
+#define MF_ABI_VERSION 3
+int mf_abi_version(void);
 
 /* z-slab window (multi-GPU, no reference counterpart): subsequent calls on this thread treat every grid as the
  * planes [zoff, zoff+sz) of a global grid with gsz planes -- positions handed to the interpolators are global
@@ -56,12 +65,11 @@ int mf_set_slab_window(int zoff, int gsz);
  * the weight grid of mf_apply_noise_vec3): in a two-resolution scene each solver's slab has its own window */
 int mf_set_slab_window_source(int zoff, int gsz);
 
-/* How the MIC(0) substitution sweeps are parallelised on the GPU (no reference counterpart; every mode gives the same
- * bits as the serial sweep of ApplyPreconditionModifiedIncompCholesky2, conjugategrad.cpp:88-128):
- * "rows" (default for 3D: row-streaming sweeps, one 8 x 8 bundle of x-rows per workgroup), "rows-sb" (2 x 2 bundles per workgroup
- * with the inner faces through LDS, where the system allows it -- measured slower, kept selectable: DESIGN.md), "tiles", "levels";
- * NULL or "" = back to the default / MF_MIC_MODE.  Set it before mf_mic_init.  Returns 0, or -1 for an unknown name.  The oracle
- * accepts and ignores it. */
+/* How the MIC(0) sweeps are parallelised on the GPU (no reference counterpart; every mode gives the same bits as the serial sweeps of
+ * conjugategrad.cpp:66-97, 135-159): "rows" (default for 3D: row-streaming dataflow sweeps, one 8 x 8 bundle of x-rows per workgroup,
+ * one launch per sweep) or "levels" (one launch per hyperplane of 8^3 tiles: no waiting between workgroups); NULL or "" = back to the
+ * default / MF_MIC_MODE.  The mode is taken by the next mf_mic_init* and stays with the system it registers.  Returns 0, or -1 for an
+ * unknown name.  The oracle accepts and ignores it. */
 int mf_set_mic_mode(const char* name);
 /* Synchronises the stream and reports whether any MIC sweep since the last check gave up waiting for a neighbouring
  * workgroup (a deadlock guard of the single-launch sweeps; never seen in practice).  mf_cg_solve checks by itself; callers

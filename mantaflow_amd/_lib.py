@@ -73,12 +73,15 @@ class Library:
         if missing:
             raise RuntimeError("mantaflow_amd: %s lacks ABI symbols: %s" % (path, ", ".join(missing)))
         self.backend = self.cdll.mf_backend().decode()
+        want = int(re.search(r"#define\s+MF_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+        got = int(self.cdll.mf_abi_version())
+        if got != want:
+            raise RuntimeError("mantaflow_amd: %s implements ABI revision %d, include/manta_hip.h declares %d -- rebuild the library"
+                               % (path, got, want))
         # the z-slab window is thread-local state of the shared object (which stays loaded across Library instances): start
         # from "the grid is the whole domain"; solvers carry their own window and set it per call (core.SolverLib)
         self.cdll.mf_set_slab_window(0, 0)
         self.cdll.mf_set_slab_window_source(0, 0)
-        self._window = (0, 0)
-        self._window_src = (0, 0)
 
     def call(self, name, *args):
         fn = getattr(self.cdll, name)

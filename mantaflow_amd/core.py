@@ -161,18 +161,16 @@ class SolverLib(object):
         self.backend, self.device, self.cdll, self.path = lib.backend, lib.device, lib.cdll, lib.path
 
     def call(self, name, *args):
+        # set on every call: the window is thread-local state of the shared object, so a cache per Library object would go
+        # stale under a second host thread or a second Library on the same .so (two thread-local stores per call)
         lib, w = self._lib, self._solver._slab_window
-        if lib._window != w:
-            lib.call("mf_set_slab_window", w[0], w[1])
-            lib._window = w
+        lib.cdll.mf_set_slab_window(w[0], w[1])
         return lib.call(name, *args)
 
     def call2(self, src_solver, name, *args):
         """a call that reads a grid of another solver (interpolateGrid & co.): that grid's window goes in as the source window"""
         lib, w = self._lib, src_solver._slab_window
-        if lib._window_src != w:
-            lib.call("mf_set_slab_window_source", w[0], w[1])
-            lib._window_src = w
+        lib.cdll.mf_set_slab_window_source(w[0], w[1])
         return self.call(name, *args)
 
 

@@ -1,7 +1,7 @@
 // mic.hip -- the MIC(0) preconditioner of the pressure solve on gfx950: InitPreconditionModifiedIncompCholesky2 and the two
 // substitution sweeps of ApplyPreconditionModifiedIncompCholesky2 (source/conjugategrad.cpp:66-97, 135-159), which the
-// reference runs as single-threaded lexicographic sweeps.  Three parallelisations with identical results:
-// "levels" (k_mic_tiles), "tiles" (k_mic_flow), "rows" (k_mic_rows, default for the apply sweeps).
+// reference runs as single-threaded lexicographic sweeps.  Two parallelisations with identical results: "rows" (k_mic_rows /
+// k_mic_rows_init, one dataflow launch per sweep, the default) and "levels" (k_mic_tiles, one launch per tile hyperplane).
 #include "common.h"
 #include "pressure.h"
 #include <float.h>
@@ -266,12 +266,12 @@ k_mic_tiles(Dim d, int level, int nti, int ntj, int ntk, const int32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// MIC apply as ONE launch per sweep ("dataflow"): one wave per tile, tiles are handed out in hyperplane order by an
-// atomic ticket (a ticketed tile's predecessors hold smaller tickets, i.e. they are already running or finished, so the
-// wait below always ends whatever the dispatch order), and the three faces a tile hands to its +i/+j/+k successors
-// travel as 8-byte {value, tag} granules written with ONE agent-scope (sc1, write-through) store each and polled with
-// agent-scope (sc1, L1-bypassing) loads: no flag, no fence (MI355X_MICROARCH.md, "handoff-1to1").  tag = launch
-// generation, so the exchange buffer never needs clearing.  Per-cell arithmetic is identical to k_mic_tiles.
+// Single-launch ("dataflow") sweeps: work items are handed out in dependency order by an atomic ticket (a ticketed item's
+// predecessors hold smaller tickets, i.e. they are already running or finished, so a wait always ends whatever the dispatch
+// order -- ONE queue: that argument needs nothing about which workgroups are resident), and the faces an item hands to its
+// successors travel as 8-byte {value, tag} granules written with ONE agent-scope (sc1, write-through) store each and polled
+// with agent-scope (sc1, L1-bypassing) loads: no flag, no fence (MI355X_MICROARCH.md, "handoff-1to1").  tag = launch
+// generation, so the exchange buffers never need clearing.
 // ---------------------------------------------------------------------------------------------------------
 struct FlowCtl {
 	int ticket, finished, err, pad;
@@ -283,222 +283,7 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, float v, un
 	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// same-XCD hand-off: a plain store reaches that XCD's L2, where an agent-scope (sc1) load of another CU of the same XCD
-// finds it (0.26 us one way vs 0.72 us for sc1 -> sc1 across XCDs, tools/micro/pingpong.hip); NOT visible to other XCDs
-__device__ __forceinline__ void granule_store_local(unsigned long long* p, float v, unsigned tag) {
-	const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-	__hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
 constexpr int FLOW_SPIN_LIMIT = 1 << 21;
-
-template <int MODE, bool VEC>
-__global__ void __launch_bounds__(64)
-k_mic_flow(Dim d, int nti, int ntj, int ntk, int ntiles, const int* __restrict__ order, FlowCtl* ctl,
-           unsigned long long* xch, unsigned gen, const int32_t* __restrict__ flags, float* __restrict__ dst,
-           const float* __restrict__ var1, const float* __restrict__ Ap, const float* __restrict__ Ai,
-           const float* __restrict__ Aj, const float* __restrict__ Ak, const CgScalars* __restrict__ sc) {
-	static_assert(MODE == 1 || MODE == 2, "dataflow kernel implements the apply sweeps");
-	constexpr bool REV = (MODE == 2);
-	if (sc && sc->done) return;
-	const int lane = threadIdx.x, b = lane & 7, c = lane >> 3;
-	// double-buffered tile operands: while tile n runs its 22 steps out of one buffer, the operands of the tile this
-	// wave will run next are already in flight (its ticket was drawn one tile earlier), so ticket, tile lookup and the
-	// HBM round trip of the operands are off the dependency chain between tiles
-	__shared__ float4 sA[2][512];   // {V, Ai, Aj, Ak}
-	__shared__ float4 sB[2][512];   // {Aprecond, dst, fluid, -}
-	__shared__ float sHj[64], sHk[64];
-	const unsigned long long fresh0 = (unsigned long long)gen << 32;
-
-	struct TileRegs {
-		int F[8];
-		float V[8], Ai[8], Aj[8], Ak[8], P[8], D[8];
-	};
-	auto tile_geom = [&](int packed, int& x0, int64_t& rowbase, int& nv) {
-		const int til = packed & 1023, tjl = (packed >> 10) & 1023, tkl = (packed >> 20) & 1023;
-		const int ti = REV ? nti - 1 - til : til, tj = REV ? ntj - 1 - tjl : tjl, tk = REV ? ntk - 1 - tkl : tkl;
-		const int lj = REV ? 7 - b : b, lk = REV ? 7 - c : c;
-		x0 = ti * 8;
-		const int j = tj * 8 + lj, k = tk * 8 + lk;
-		const bool row_in = (j < d.sy) && (k < d.sz);
-		rowbase = (int64_t)x0 + d.Y * j + d.Z * k;
-		const int nvx = d.sx - x0 < 8 ? d.sx - x0 : 8;
-		nv = row_in ? nvx : 0;
-	};
-	auto issue = [&](TileRegs& r, int packed) {
-		int x0, nv;
-		int64_t rowbase;
-		tile_geom(packed, x0, rowbase, nv);
-		load_row8i<VEC, REV>(flags, rowbase, nv, r.F);
-		load_row8<VEC, REV>(var1, rowbase, nv, r.V);
-		load_row8<VEC, REV>(Ai, rowbase, nv, r.Ai);
-		load_row8<VEC, REV>(Aj, rowbase, nv, r.Aj);
-		load_row8<VEC, REV>(Ak, rowbase, nv, r.Ak);
-		load_row8<VEC, REV>(Ap, rowbase, nv, r.P);
-		load_row8<VEC, REV>(dst, rowbase, nv, r.D);
-	};
-	auto commit = [&](const TileRegs& r, int packed, int buf) {
-		int x0, nv;
-		int64_t rowbase;
-		tile_geom(packed, x0, rowbase, nv);
-#pragma unroll
-		for (int a = 0; a < 8; a++) {
-			const bool in = ((REV ? 7 - a : a) < nv);
-			const bool fl = in && (r.F[a] & MF_FLUID);
-			sA[buf][a * 64 + lane] = make_float4(fl ? r.V[a] : 0.f, r.Ai[a], r.Aj[a], r.Ak[a]);
-			sB[buf][a * 64 + lane] = make_float4(r.P[a], r.D[a], fl ? 1.f : 0.f, 0.f);
-		}
-	};
-	auto draw = [&]() {
-		int t = 0;
-		if (lane == 0) t = atomicAdd(&ctl->ticket, 1);
-		return __builtin_amdgcn_readfirstlane(t);
-	};
-
-	int t_cur = draw();
-	int t_nxt = draw();
-	int pk_cur = (t_cur < ntiles) ? order[t_cur] : 0;
-	int pk_nxt = (t_nxt < ntiles) ? order[t_nxt] : 0;
-	TileRegs R;
-	if (t_cur < ntiles) {
-		issue(R, pk_cur);
-		commit(R, pk_cur, 0);
-	}
-	int buf = 0, spins = 0;
-	while (t_cur < ntiles) {
-		int tnn_raw = 0;           // ticket of the tile after next: drawn now, looked at when this tile is done
-		if (lane == 0) tnn_raw = atomicAdd(&ctl->ticket, 1);
-		// ---- geometry of the current tile ----
-		const int til = pk_cur & 1023, tjl = (pk_cur >> 10) & 1023, tkl = (pk_cur >> 20) & 1023;
-		const int64_t tid = ((int64_t)tkl * ntj + tjl) * nti + til;
-		const bool has_pi = til > 0, has_pj = (tjl > 0) && (b == 0), has_pk = (tkl > 0) && (c == 0);
-		const bool has_si = til + 1 < nti, has_sj = (tjl + 1 < ntj) && (b == 7), has_sk = (tkl + 1 < ntk) && (c == 7);
-		unsigned long long* out_i = xch + ((tid * 3 + 0) << 6) + lane;
-		unsigned long long* out_j = xch + ((tid * 3 + 1) << 6) + c * 8;
-		unsigned long long* out_k = xch + ((tid * 3 + 2) << 6) + b * 8;
-		const unsigned long long* in_i = xch + (((tid - 1) * 3 + 0) << 6) + lane;
-		const unsigned long long* in_j = xch + (((tid - nti) * 3 + 1) << 6) + c * 8;
-		const unsigned long long* in_k = xch + (((tid - (int64_t)nti * ntj) * 3 + 2) << 6) + b * 8;
-		// ---- first look at the predecessors' faces, then the next tile's operands (both stay in flight) ----
-		unsigned long long gi = has_pi ? granule_load(in_i) : fresh0;
-		unsigned long long gj[8], gk[8];
-#pragma unroll
-		for (int a = 0; a < 8; a++) gj[a] = has_pj ? granule_load(in_j + a) : fresh0;
-#pragma unroll
-		for (int a = 0; a < 8; a++) gk[a] = has_pk ? granule_load(in_k + a) : fresh0;
-		if (t_nxt < ntiles) issue(R, pk_nxt);
-		// ---- wait until every face value is there ----
-		for (;;) {
-			bool ok = ((unsigned)(gi >> 32) == gen);
-#pragma unroll
-			for (int a = 0; a < 8; a++) ok = ok && ((unsigned)(gj[a] >> 32) == gen) && ((unsigned)(gk[a] >> 32) == gen);
-			if (ok || ++spins > FLOW_SPIN_LIMIT) break;
-			__builtin_amdgcn_s_sleep(1);
-			if ((unsigned)(gi >> 32) != gen) gi = granule_load(in_i);
-#pragma unroll
-			for (int a = 0; a < 8; a++) {
-				if ((unsigned)(gj[a] >> 32) != gen) gj[a] = granule_load(in_j + a);
-				if ((unsigned)(gk[a] >> 32) != gen) gk[a] = granule_load(in_k + a);
-			}
-		}
-		if (b == 0) {
-#pragma unroll
-			for (int a = 0; a < 8; a++) sHj[c * 8 + a] = __uint_as_float((unsigned)gj[a]);
-		}
-		if (c == 0) {
-#pragma unroll
-			for (int a = 0; a < 8; a++) sHk[b * 8 + a] = __uint_as_float((unsigned)gk[a]);
-		}
-		const float hi0 = __uint_as_float((unsigned)gi);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-		// ---- 22 cell hyperplanes (no global loads inside) ----
-		float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
-		int a = -b - c;
-		int ac = 0;
-		float4 nA = sA[buf][lane], nB = sB[buf][lane];
-		float nHj = sHj[c * 8], nHk = sHk[b * 8];
-#pragma unroll 2
-		for (int h = 0; h < 22; h++) {
-			const float4 cA = nA, cB = nB;
-			const float hj = nHj, hk = nHk;
-			const int cc = ac;
-			{
-				const int a1 = a + 1;
-				ac = a1 < 0 ? 0 : (a1 > 7 ? 7 : a1);
-				nA = sA[buf][ac * 64 + lane];
-				nB = sB[buf][ac * 64 + lane];
-				nHj = sHj[c * 8 + ac];
-				nHk = sHk[b * 8 + ac];
-			}
-			const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
-			const float sk = __shfl_up(ok0, 8, 64);
-			const float ij0 = (b == 0) ? hj : dj;
-			const float ik0 = (c == 0) ? hk : sk;
-			const float ii0 = (a == 0) ? hi0 : oi0;
-			const bool valid = (unsigned)a < 8u;
-			const float ai = cA.y, aj = cA.z, ak = cA.w, p = cB.x;
-			const bool fl = valid && (cB.z != 0.f);
-			float val = cB.y;
-			if (MODE == 1) {
-				const float nv = p * (cA.x - ii0 - ij0 - ik0);
-				val = fl ? nv : val;
-				oi0 = (val * ai) * p;
-				oj0 = (val * aj) * p;
-				ok0 = (val * ak) * p;
-			} else {
-				const float nv = p * (val - ii0 * ai * p - ij0 * aj * p - ik0 * ak * p);
-				val = fl ? nv : val;
-				oi0 = oj0 = ok0 = val;
-			}
-			if (valid) {
-				sB[buf][cc * 64 + lane].y = val;
-				if (has_si && a == 7) granule_store(out_i, oi0, gen);
-				if (has_sj) granule_store(out_j + a, oj0, gen);
-				if (has_sk) granule_store(out_k + a, ok0, gen);
-			}
-			a++;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// ---- write back the finished tile ----
-		{
-			int x0, nv;
-			int64_t rowbase;
-			tile_geom(pk_cur, x0, rowbase, nv);
-			float w[8];
-#pragma unroll
-			for (int e = 0; e < 8; e++) w[REV ? 7 - e : e] = sB[buf][e * 64 + lane].y;
-			if (VEC) {
-				if (nv > 0) *(float4*)(dst + rowbase) = make_float4(w[0], w[1], w[2], w[3]);
-				if (nv > 4) *(float4*)(dst + rowbase + 4) = make_float4(w[4], w[5], w[6], w[7]);
-			} else {
-#pragma unroll
-				for (int e = 0; e < 8; e++)
-					if (e < nv) dst[rowbase + e] = w[e];
-			}
-		}
-		// ---- land the next tile's operands in the other buffer, rotate ----
-		if (t_nxt < ntiles) commit(R, pk_nxt, buf ^ 1);
-		const int t_nn = __builtin_amdgcn_readfirstlane(tnn_raw);
-		buf ^= 1;
-		t_cur = t_nxt;
-		pk_cur = pk_nxt;
-		t_nxt = t_nn;
-		pk_nxt = (t_nn < ntiles) ? order[t_nn] : 0;
-	}
-	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
-	// the last workgroup to leave re-arms the ticket for the next sweep (visible at the kernel boundary)
-	if (lane == 0) {
-		const int f = atomicAdd(&ctl->finished, 1);
-		if (f == (int)gridDim.x - 1) {
-			ctl->ticket = 0;
-			ctl->finished = 0;
-		}
-	}
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // MIC apply, row-streaming form ("rows"): a workgroup of TWO waves owns an 8x8 bundle of x-rows (tj,tk) and streams
@@ -539,8 +324,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
            const CgScalars* __restrict__ sc, double* __restrict__ dotpart, const int* __restrict__ bempty,
-           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok, long long* trace, int trace_ticket,
-           int trace_ticket2) {
+           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok) {
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
 	// write-back wave, one partial per bundle (and x-block) at dotpart[sid] -- the sum the PCG needs right after this sweep
@@ -579,17 +363,11 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 
 	for (;;) {
 		if (threadIdx.x == 0) {
-			// xt[0..7] tickets, xt[8..16] bounds of the per-XCD queues inside `order`, xt[17] = number of queues (1: one
-			// global queue; 8: bundles are queued per XCD by k-slab, so that most faces are handed over inside one XCD's L2)
-			const int nq = xt[17] & 0xff;
-			const int q = nq > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;   // HW_REG_XCC_ID
-			const int lo = xt[8 + q], hi = xt[9 + q];
-			int tk = nstreams;
-			if (lo < hi) {
-				const int tl = atomicAdd(&xt[q], 1);
-				if (lo + tl < hi) tk = lo + tl;
-			}
-			s_ticket = tk;
+			// ONE ticket queue in dependency order (xt[0]): whoever holds the lowest unfinished ticket finds all its predecessors
+			// drawn by workgroups that are already running, so the sweep ends whichever workgroups are resident (a second rank on
+			// the device, a CU mask).  Per-XCD queues (round 2: 1 % at 256^3) gave that guarantee up and are gone.
+			const int tl = atomicAdd(&xt[0], 1);
+			s_ticket = tl < nstreams ? tl : nstreams;
 			s_ready[0] = s_ready[1] = s_ready[2] = 0;
 			s_done = 0;
 			s_flushed = 0;
@@ -650,12 +428,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			const int skewL = (L & 7) + (L >> 3);
 			const bool live = fsel == 0 ? sj_live : sk_live;
 			unsigned long long* outp = (fsel == 0 ? xj : xk) + sid * XP * 8 + idx;
-			// plain (XCD-local) face stores only when every consumer of this bundle's faces runs on this XCD
-			// (k-slab queues, MF_ROWS_XCD=1: both faces unless the k-successor belongs to the next slab; queues interleaved in k,
-			// MF_ROWS_XCD=2: the j face always -- same tkl, same XCD --, the k face never)
-			const int nq_ = xt[17] & 0xff;
-			const bool inter_ = (xt[17] >> 8) != 0;
-			const bool local_faces = nq_ > 1 && (inter_ ? (fsel == 0) : ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk)));
 			const int nhalf = 2 * (nchunks + 2);
 #pragma unroll 1
 			for (int n = 0; n < nhalf; n++) {
@@ -674,8 +446,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 						const float t = cA.x * (fsel == 0 ? cA.z : cA.w);
 						fv = packed ? t : t * p;
 					}
-					if (local_faces) granule_store_local(outp + (int64_t)h2 * 8, fv, gen);
-					else granule_store(outp + (int64_t)h2 * 8, fv, gen);
+					granule_store(outp + (int64_t)h2 * 8, fv, gen);
 				}
 				// the ring rows may be overwritten now (LDS-only release: the granule stores need not have been acknowledged)
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -869,18 +640,10 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
 			float4 nA = sA[lane];                  // ring row of h = -2 (never valid)
 			float2 nB = sB[lane];
-			const bool tr = trace && (t == trace_ticket || t == trace_ticket2);      // wave-uniform: one scalar branch per stamp
-			long long* trb = trace + (t == trace_ticket2 ? 8 * 4096 : 0);
-			if (trace && lane == 0 && t < 4096) {
-				trace[4 * 4096 + 2 * t] = wall_clock64();
-				trace[6 * 4096 + t] = ((long long)blockIdx.x << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
-			}
-#define ROWS_TRACE(i) if (__builtin_expect(tr, 0)) { if (lane == 0) trb[m * 4 + (i)] = wall_clock64(); }
 			auto block = [&](int m, auto edge_tag, auto pre_tag) {
 				constexpr bool EDGE = decltype(edge_tag)::value;
 				constexpr bool PRE = decltype(pre_tag)::value;      // the ring holds A * Aprecond (packed operands)
 				const int xq = 8 * m - 2 - skew;                       // this lane's x' at the first step of the block
-				ROWS_TRACE(0)
 				// flags and face values in one batch of LDS reads: the LDS serves a wave's requests in order, and the poller
 				// publishes the values before the flag -- a flag read that shows block m is followed by reads that see its values
 				typedef int rows_i4 __attribute__((ext_vector_type(4)));
@@ -903,11 +666,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					__builtin_amdgcn_s_sleep(1);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-				ROWS_TRACE(1)
 				float gj[8], gk[8];
 				gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
 				gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
-				ROWS_TRACE(2)
 				const int base = (8 * m) & (ROWS_RING - 1);
 #pragma unroll
 				for (int s = 0; s < 8; s++) {
@@ -962,7 +723,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 				asm volatile("" ::: "memory");
 				*(volatile __attribute__((address_space(3))) int*)&s_done = m + 1;
 				*(volatile __attribute__((address_space(3))) int*)&s_half = 2 * m + 2;
-				ROWS_TRACE(3)
 			};
 #pragma unroll 1
 			for (int m = 0; m <= nchunks + 1; m++) {
@@ -976,8 +736,6 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					else block(m, std::true_type{}, std::false_type{});
 				}
 			}
-			if (trace && lane == 0 && t < 4096) trace[4 * 4096 + 2 * t + 1] = wall_clock64();
-#undef ROWS_TRACE
 		}
 		__syncthreads();
 	}
@@ -985,7 +743,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 	if (threadIdx.x == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
 		if (f == (int)gridDim.x - 1) {
-			for (int q = 0; q < 8; q++) xt[q] = 0;
+			xt[0] = 0;
 			ctl->finished = 0;
 		}
 	}
@@ -1022,15 +780,9 @@ k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, cons
 
 	for (;;) {
 		if (threadIdx.x == 0) {
-			const int nq = xt[17] & 0xff;
-			const int q = nq > 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;   // HW_REG_XCC_ID
-			const int lo = xt[8 + q], hi = xt[9 + q];
-			int tk = nstreams;
-			if (lo < hi) {
-				const int tl = atomicAdd(&xt[q], 1);
-				if (lo + tl < hi) tk = lo + tl;
-			}
-			s_ticket = tk;
+			// one ticket queue in dependency order, as in k_mic_rows
+			const int tl = atomicAdd(&xt[0], 1);
+			s_ticket = tl < nstreams ? tl : nstreams;
 			s_ready[0] = s_ready[1] = s_ready[2] = 0;
 			s_done = 0;
 			s_flushed = 0;
@@ -1063,9 +815,6 @@ k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, cons
 			const bool live = fsel == 0 ? sj_live : sk_live;
 			unsigned long long* out0 = (fsel == 0 ? xj : xk) + sid * XP * 8 + idx;
 			unsigned long long* out1 = (fsel == 0 ? xj1 : xk1) + sid * XP * 8 + idx;
-			const int nq_ = xt[17] & 0xff;
-			const bool inter_ = (xt[17] >> 8) != 0;
-			const bool local_faces = nq_ > 1 && (inter_ ? (fsel == 0) : ((tkl + 1 >= nbk) || ((tkl * nq_) / nbk == ((tkl + 1) * nq_) / nbk)));
 			const int nhalf = 2 * (nchunks + 2);
 #pragma unroll 1
 			for (int n = 0; n < nhalf; n++) {
@@ -1085,13 +834,8 @@ k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, cons
 					const float ap2 = ap * ap;
 					const float h0 = t_ * t_;
 					const float h1 = adir * osum * ap2;
-					if (local_faces) {
-						granule_store_local(out0 + (int64_t)h2 * 8, h0, gen);
-						granule_store_local(out1 + (int64_t)h2 * 8, h1, gen);
-					} else {
-						granule_store(out0 + (int64_t)h2 * 8, h0, gen);
-						granule_store(out1 + (int64_t)h2 * 8, h1, gen);
-					}
+					granule_store(out0 + (int64_t)h2 * 8, h0, gen);
+					granule_store(out1 + (int64_t)h2 * 8, h1, gen);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 				__hip_atomic_store(&s_pub, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1308,485 +1052,7 @@ k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, cons
 	if (threadIdx.x == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
 		if (f == (int)gridDim.x - 1) {
-			for (int q = 0; q < 8; q++) xt[q] = 0;
-			ctl->finished = 0;
-		}
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// MIC apply, "super-bundle" form of the row-streaming sweeps (k_mic_sb): ONE workgroup owns 2 x 2 bundles of 8 x 8 x-rows.
-// What bounds k_mic_rows is the chain of face hand-offs between workgroups (62 at 256^3, each = 15 steps of structural lag +
-// a global store -> poll round trip).  Here four compute waves (one per SIMD) sweep the four sub-bundles of a 16 x 16 block of
-// rows and hand their inner faces to each other through LDS; only the outer faces of the block cross workgroups (30 hand-offs
-// at 256^3).  The helper waves are shared: wave 4+w loads for sub-bundle w (software-pipelined three chunks ahead), one wave
-// writes all four back, one wave polls the (up to) four outer input faces, each 8-lane group at its own pace.
-//   sub-bundle w = sj + 2 sk;  j face in : sj == 0 global (polled), sj == 1 from w-1 through LDS;   out: sj == 1 global, else LDS
-//                              k face in : sk == 0 global,          sk == 1 from w-2;                out: sk == 1 global, else LDS
-// Operands reach the compute waves as ONE 16-byte LDS slot per cell: {value, Aprecond (sign bit set = not a fluid cell),
-// (Ai, Aj) and (Ak, -) as fp16 pairs}.  This needs every coefficient to be exactly +0 or -1 (the packed bytes of k_mic_pack)
-// and Aprecond >= +0 (what mf_mic_init writes); the products (val * A) * p are formed exactly as in the reference:
-// v_fma_mix_f32(val, A as fp16, -0) is the fp32 product val * A without rounding (A is 0 or -1, x + (-0) == x for every x), then
-// one fp32 multiply by |p|.  Global faces use the granule arrays of k_mic_rows (per 8 x 8 bundle), so both kernels share them.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int SB_THREADS = 640;
-constexpr int SB_FR = 64;          // slots of a face ring
-constexpr int SB_AHEAD = SB_FR / 8 - 1;   // blocks a face producer may run ahead of its consumer
-constexpr int SB_PW = 3;           // windows (blocks) the poller fetches per round trip
-struct SbShared {
-	float4 ring[4][32 * 64];      // operand / result ring of each sub-bundle, index = ((h + 2) & 31) * 64 + lane
-	// input faces of the four sub-bundles, one ring per face: [ring][face lane][slot], slot = (producer row - 7) & (SB_FR - 1), so that a
-	// consumer block m reads the eight slots 8m .. 8m+7.  Rings 0-3 are the OUTER faces, filled by the poller from the granule arrays
-	// (0 j of w0, 1 j of w2, 2 k of w0, 3 k of w1); rings 4-7 the INNER faces, written by the producing compute wave itself
-	// (4 j w0->w1, 5 j w2->w3, 6 k w0->w2, 7 k w1->w3).  SB_FR slots = 8 blocks of slack between producer and consumer: the hand-off
-	// latency jitters by a few blocks, and a ring that is too short turns that jitter into a stall of the whole chain.
-	float FR[8][8][SB_FR];
-	float dump[64 + 8];
-	int ready[4], done[4], flushed[4], faces[4], ticket, pad[3];
-};
-__device__ __forceinline__ float sb_mulh(float v, float packed, bool hi, float negzero) {
-	float r;   // negzero is uniform: it stays in an SGPR (one constant-bus operand)
-	if (hi) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(packed), "s"(negzero));
-	else asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(v), "v"(packed), "s"(negzero));
-	return r;
-}
-typedef float sbf4 __attribute__((ext_vector_type(4)));
-typedef unsigned sbu4 __attribute__((ext_vector_type(4)));
-struct SbChunk {      // one 8-cell chunk of a row in flight (physical order; no arrays, so that it lives in registers)
-	sbu4 C0, C1;     // coefficient words of k_mic_sbcoef
-	sbf4 P0, P1, V0, V1, D0, D1;
-};
-__device__ __forceinline__ unsigned sb_picku(const sbu4& lo, const sbu4& hi, int e) {
-	return e == 0 ? lo.x : e == 1 ? lo.y : e == 2 ? lo.z : e == 3 ? lo.w : e == 4 ? hi.x : e == 5 ? hi.y : e == 6 ? hi.z : hi.w;
-}
-__device__ __forceinline__ float sb_pick(const sbf4& lo, const sbf4& hi, int e) {
-	return e == 0 ? lo.x : e == 1 ? lo.y : e == 2 ? lo.z : e == 3 ? lo.w : e == 4 ? hi.x : e == 5 ? hi.y : e == 6 ? hi.z : hi.w;
-}
-// loader wave of one sub-bundle: three chunks in flight (register sets rotate statically), slot assembly, commit to the ring.
-// A function of its own, NOT inlined: the kernel's other roles would otherwise share one register allocation with it, and the
-// three chunk sets in flight end up spilled to scratch right behind their loads (which serialises the loads).
-template <int MODE>
-__device__ __attribute__((noinline)) int sb_loader(float4* ring_, int* ready_, int* flushed_, int nchunks, bool row_in, int64_t rowbase,
-                                                   const unsigned* __restrict__ coef, const float* __restrict__ Ap, const float* dst,
-                                                   const float* __restrict__ var1, long long* tr) {
-	constexpr bool REV = (MODE == 2);
-	const int lane = threadIdx.x & 63, b = lane & 7, c = lane >> 3, skew = b + c;
-	// LDS address space for the ring and the counters: ds_ instructions, and acquire / release that wait for LDS only (through a
-	// generic pointer every poll of a counter would wait for the global loads in flight as well)
-	typedef __attribute__((address_space(3))) sbf4* lf4;
-	typedef __attribute__((address_space(3))) int* li;
-	lf4 ring = (lf4)ring_;
-	li ready = (li)ready_, flushed = (li)flushed_;
-	int spins = 0;
-	auto issue = [&](SbChunk& r, int m) {
-		const int x0 = (REV ? nchunks - 1 - m : m) * 8;
-		const int64_t i0 = row_in ? rowbase + x0 : 0;      // sx % 8 == 0: a chunk is inside the row, or the row is outside the grid
-		typedef const __attribute__((address_space(1))) sbu4* gu4;      // global address space: global_load, counted by vmcnt alone
-		typedef const __attribute__((address_space(1))) sbf4* gf4;
-		r.C0 = *(gu4)(coef + i0);
-		r.C1 = *(gu4)(coef + i0 + 4);
-		r.P0 = *(gf4)(Ap + i0);
-		r.P1 = *(gf4)(Ap + i0 + 4);
-		r.D0 = *(gf4)(dst + i0);
-		r.D1 = *(gf4)(dst + i0 + 4);
-		if (MODE == 1) {
-			r.V0 = *(gf4)(var1 + i0);
-			r.V1 = *(gf4)(var1 + i0 + 4);
-		}
-	};
-	// The slot is assembled with five VALU instructions per cell (the coefficient word was laid out for it by k_mic_sbcoef):
-	// this wave shares its SIMD with a compute wave, every instruction here is taken from the sweep.
-	auto commit = [&](const SbChunk& r, int m) {
-		const int p0 = 8 * m + skew + 2;
-#pragma unroll
-		for (int a = 0; a < 8; a++) {
-			const int e = REV ? 7 - a : a;              // physical cell of the logical position a
-			const unsigned q = row_in ? sb_picku(r.C0, r.C1, e) : 0x80000000u;
-			// bytes of q: [Ai ? 0xBC : 0, Aj ? 0xBC : 0, Ak ? 0xBC : 0, not fluid ? 0x80 : 0]; fp16 -1.0 = 0xBC00
-			const unsigned zi = __builtin_amdgcn_perm(0u, q, 0x010c000cu);   // bytes {0, q.b0, 0, q.b1}
-			const unsigned zk = __builtin_amdgcn_perm(0u, q, 0x0c0c020cu);   // bytes {0, q.b2, 0, 0}
-			const float p = row_in ? sb_pick(r.P0, r.P1, e) : 0.f;
-			const float pm = __uint_as_float((q & 0x80000000u) | __float_as_uint(p));   // Aprecond >= +0 (mf_mic_init); sign bit = not fluid
-			float v = (MODE == 1 && (int)q >= 0) ? sb_pick(r.V0, r.V1, e) : sb_pick(r.D0, r.D1, e);
-			if (!row_in) v = 0.f;
-			sbf4 slot;
-			slot.x = v;
-			slot.y = pm;
-			slot.z = __uint_as_float(zi);
-			slot.w = __uint_as_float(zk);
-			ring[((p0 + a) & 31) * 64 + lane] = slot;
-		}
-	};
-	SbChunk R0, R1, R2;
-	if (0 < nchunks) issue(R0, 0);
-	if (1 < nchunks) issue(R1, 1);
-	if (2 < nchunks) issue(R2, 2);
-#pragma unroll 1
-	for (int n = 0; n < nchunks; n += 3) {
-#define SB_LOAD_STEP(R, q)                                                                                     \
-	if (n + (q) < nchunks) {                                                                               \
-		if (n + (q) >= 4) {                                                                                \
-			while (__hip_atomic_load(flushed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + (q) - 3) { \
-				if (++spins > FLOW_SPIN_LIMIT) break;                                                      \
-				__builtin_amdgcn_s_sleep(2);                                                               \
-			}                                                                                              \
-		}                                                                                                  \
-		commit(R, n + (q));                                                                                \
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                    \
-		__hip_atomic_store(ready, n + (q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);            \
-		if (tr && lane == 0 && n + (q) < 64) tr[n + (q)] = wall_clock64();                                 \
-		if (n + (q) + 3 < nchunks) issue(R, n + (q) + 3);                                                  \
-	}
-		SB_LOAD_STEP(R0, 0)
-		SB_LOAD_STEP(R1, 1)
-		SB_LOAD_STEP(R2, 2)
-#undef SB_LOAD_STEP
-	}
-	return spins > FLOW_SPIN_LIMIT ? FLOW_SPIN_LIMIT + 1 : 0;
-}
-template <int MODE>
-__global__ void __launch_bounds__(SB_THREADS)
-k_mic_sb(Dim d, int nbj, int nbk, int nsj, int nsb, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* tick,
-         unsigned long long* xj, unsigned long long* xk, unsigned gen, float* __restrict__ dst, const float* __restrict__ var1,
-         const float* __restrict__ Ap, const CgScalars* __restrict__ sc, const unsigned* __restrict__ coef, float negzero,
-         long long* trace, int trace_ticket, int dbg) {
-	static_assert(MODE == 1 || MODE == 2, "apply sweeps only");
-	constexpr bool REV = (MODE == 2);
-	if (sc && sc->done) return;
-	extern __shared__ __attribute__((aligned(16))) unsigned char sb_raw[];
-	SbShared& S = *reinterpret_cast<SbShared*>(sb_raw);
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
-	const int skew = b + c;
-	// compute waves run above the poller / write-back waves; the loaders sit on the critical ring cycle (a chunk is committed one block
-	// before it is needed) and run at the top
-	if (wave < 4) __builtin_amdgcn_s_setprio(2);
-	else if (wave < 8) { if (dbg & 8) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
-	else __builtin_amdgcn_s_setprio(1);
-	const int X8 = nchunks * 8;
-	const int nblocks = nchunks + 2;
-	const int64_t XP = X8 + 2 * ROWS_PAD;
-	int spins = 0;
-	// nap == 1: a compute wave.  It shares its SIMD with the very helper waves it waits for, so it must not spin at high priority:
-	// it steps down while it waits (otherwise the wait starves the loader that would end it)
-	auto wait_ge = [&](int* flag, int need, int nap) {
-		if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return;
-		if (nap == 1) __builtin_amdgcn_s_setprio(0);
-		while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-			if (++spins > FLOW_SPIN_LIMIT) break;
-			if (nap == 1) __builtin_amdgcn_s_sleep(2);
-			else __builtin_amdgcn_s_sleep(4);
-		}
-		if (nap == 1) __builtin_amdgcn_s_setprio(2);
-	};
-
-	for (;;) {
-		if (threadIdx.x == 0) {
-			const int t = atomicAdd(tick, 1);
-			S.ticket = t < nsb ? t : nsb;
-			for (int q = 0; q < 4; q++) S.ready[q] = S.done[q] = S.flushed[q] = S.faces[q] = 0;
-		}
-		__syncthreads();
-		const int t = S.ticket;
-		if (t >= nsb) break;
-		if ((dbg & 128) && t > 0) break;
-		const int pk = order[t];
-		const int SJ = pk & 0xfff, SK = pk >> 12;      // logical (sweep-direction) super-bundle coordinates
-		// ---- geometry of sub-bundle `w` (uniform) ----
-		auto sub_tjl = [&](int w) { return 2 * SJ + (w & 1); };
-		auto sub_tkl = [&](int w) { return 2 * SK + (w >> 1); };
-		auto sub_alive = [&](int w) { return sub_tjl(w) < nbj && sub_tkl(w) < nbk && !((dbg & 16) && w > 0) && !((dbg & 32) && w > 1); };
-
-		if (wave < 4) {
-			// ===================================== compute wave of sub-bundle w =====================================
-			// the role (which faces are inner / outer) is a compile-time property of w: four copies of the step loop
-			auto compute = [&](auto wtag) {
-				constexpr int w = decltype(wtag)::value, sj = w & 1, sk = w >> 1;
-				constexpr bool JIN_INT = (sj == 1), KIN_INT = (sk == 1);      // else: outer face (polled) or none
-				constexpr bool JOUT_GLOB = (sj == 1), KOUT_GLOB = (sk == 1);  // else: inner face through LDS
-				constexpr bool BOTH_GLOB = JOUT_GLOB && KOUT_GLOB;
-				constexpr int gJ = sk ? 1 : 0, gK = sj ? 3 : 2;                     // outer input rings / poller groups
-				constexpr int rJ_in = JIN_INT ? 4 + (sk ? 1 : 0) : gJ, rK_in = KIN_INT ? 6 + sj : gK;
-				constexpr int rJ_out = 4 + (sk ? 1 : 0), rK_out = 6 + sj;
-				const int tjl = sub_tjl(w), tkl = sub_tkl(w);
-				if (!sub_alive(w)) {
-					if (lane == 0) __hip_atomic_store(&S.done[w], 1 << 28, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-					return;
-				}
-				const int64_t sid = (int64_t)tkl * nbj + tjl;
-				const bool jin_glob = !JIN_INT && (tjl > 0), kin_glob = !KIN_INT && (tkl > 0);
-				// an outer face without a predecessor bundle reads zeros: the buffers are cleared once, nobody else writes them
-				if (!JIN_INT && !jin_glob)
-					for (int q = lane; q < 8 * SB_FR; q += 64) (&S.FR[gJ][0][0])[q] = 0.f;
-				if (!KIN_INT && !kin_glob)
-					for (int q = lane; q < 8 * SB_FR; q += 64) (&S.FR[gK][0][0])[q] = 0.f;
-				const bool jout_glob = JOUT_GLOB && (tjl + 1 < nbj), kout_glob = KOUT_GLOB && (tkl + 1 < nbk);
-				// outer face lanes: b == 7 publish the j face, c == 7 the k face; when both are outer (w == 3) lane 0 stands in for
-				// lane 63's k value (lane 63 is busy with its j value; lane 0's own x' runs 14 ahead of lane 63's)
-				const bool corner_proxy = BOTH_GLOB && kout_glob && (lane == 0);
-				const bool gl_j = jout_glob && (b == 7), gl_k = kout_glob && (c == 7) && !(BOTH_GLOB && lane == 63);
-				const bool face_lane = gl_j || gl_k || corner_proxy;
-				const int fskew = corner_proxy ? -14 : 0;
-				unsigned long long* out_f = gl_j ? xj + sid * XP * 8 + c : (corner_proxy ? xk + sid * XP * 8 + 7 : xk + sid * XP * 8 + b);
-				// inner face lanes write LDS every step; all other lanes write to a dump slot (no exec juggling in the step)
-				const bool lj_real = !JOUT_GLOB && (b == 7) && sub_alive(w + 1), lk_real = !KOUT_GLOB && (c == 7) && sub_alive(w + 2);
-				float* lds_j = lj_real ? &S.FR[rJ_out][c][0] : &S.dump[lane];
-				float* lds_k = lk_real ? &S.FR[rK_out][b][0] : &S.dump[lane];
-				float4* ring = S.ring[w];
-				float oi0 = 0.f, oj0 = 0.f, ok0 = 0.f;
-				float4 nxt = ring[lane];                 // ring row of h = -2 (never valid)
-				const bool tr = trace && (t == trace_ticket) && lane == 0;
-				long long* trb = trace + (int64_t)w * 4 * 64;
-#define SB_TRACE(i) if (tr && m < 64) trb[m * 4 + (i)] = wall_clock64();
-				if (trace && lane == 0 && w == 0 && t < 2048) trace[1024 + 2 * t] = wall_clock64();
-				auto block = [&](int m, auto edge_tag) {
-					constexpr bool EDGE = decltype(edge_tag)::value;
-					const int xq = 8 * m - 2 - skew;
-					SB_TRACE(0)
-					if (m < nchunks) wait_ge(&S.ready[w], m + 1, 1);
-					SB_TRACE(1)
-					const int need_int = (m + 2 < nblocks) ? m + 2 : nblocks;
-					if (JIN_INT) wait_ge(&S.done[JIN_INT ? w - 1 : 0], need_int, 1);
-					else if (jin_glob) wait_ge(&S.faces[gJ], m + 1, 1);
-					if (KIN_INT) wait_ge(&S.done[KIN_INT ? w - 2 : 0], need_int, 1);
-					else if (kin_glob) wait_ge(&S.faces[gK], m + 1, 1);
-					// never run more than SB_AHEAD blocks ahead of the consumer of an inner face (a consumer that does not exist has
-					// done = 2^28)
-					if (!JOUT_GLOB) wait_ge(&S.done[JOUT_GLOB ? 0 : w + 1], m - SB_AHEAD, 1);
-					if (!KOUT_GLOB) wait_ge(&S.done[KOUT_GLOB ? 0 : w + 2], m - SB_AHEAD, 1);
-					SB_TRACE(2)
-					float gj[8], gk[8];
-					{
-						const int r0 = (8 * m) & (SB_FR - 1);
-						const float* pj = &S.FR[rJ_in][c][r0];
-						const float* pk_ = &S.FR[rK_in][b][r0];
-						const float4 j0 = *(const float4*)pj, j1 = *(const float4*)(pj + 4);
-						const float4 k0 = *(const float4*)pk_, k1 = *(const float4*)(pk_ + 4);
-						gj[0] = j0.x; gj[1] = j0.y; gj[2] = j0.z; gj[3] = j0.w; gj[4] = j1.x; gj[5] = j1.y; gj[6] = j1.z; gj[7] = j1.w;
-						gk[0] = k0.x; gk[1] = k0.y; gk[2] = k0.z; gk[3] = k0.w; gk[4] = k1.x; gk[5] = k1.y; gk[6] = k1.z; gk[7] = k1.w;
-					}
-					const int base = (8 * m) & 31;
-					unsigned long long* pf = out_f + (int64_t)(8 * m) * 8;
-					// inner face slots of this block: producer row 8m + s -> slot (8m + s - 7) & (SB_FR - 1)
-					float* wjA = lds_j + (lj_real ? ((8 * m - 8) & (SB_FR - 1)) : 0);   // + s + 1 for s < 7
-					float* wjB = lds_j + (lj_real ? ((8 * m) & (SB_FR - 1)) : 0);       // s == 7
-					float* wkA = lds_k + (lk_real ? ((8 * m - 8) & (SB_FR - 1)) : 0);
-					float* wkB = lds_k + (lk_real ? ((8 * m) & (SB_FR - 1)) : 0);
-#pragma unroll
-					for (int s = 0; s < 8; s++) {
-						const float4 cur = nxt;
-						const int row = ((base + s) & 31) * 64 + lane;
-						const int nrow = ((base + s + 1) & 31) * 64 + lane;
-						nxt = ring[nrow];
-						const float dj = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(oj0), 0x111, 0xf, 0xf, false));
-						const float sk_ = (dbg & 4) ? dj : __shfl_up(ok0, 8, 64);
-						const float ij0 = (b == 0) ? gj[s] : dj;
-						const float ik0 = (c == 0) ? gk[s] : sk_;
-						const float ii0 = oi0;
-						const bool valid = !EDGE || ((unsigned)(xq + s) < (unsigned)X8);
-						const float pa = __builtin_fabsf(cur.y);
-						const bool fl = __float_as_int(cur.y) >= 0;
-						float val = cur.x;
-						if (MODE == 1) {
-							const float nv = pa * (val - ii0 - ij0 - ik0);
-							val = fl ? nv : val;
-							const float ti = sb_mulh(val, cur.z, false, negzero), tj_ = sb_mulh(val, cur.z, true, negzero), tk_ = sb_mulh(val, cur.w, false, negzero);
-							oi0 = valid ? ti * pa : 0.f;
-							oj0 = valid ? tj_ * pa : 0.f;
-							ok0 = valid ? tk_ * pa : 0.f;
-						} else {
-							const float ti = sb_mulh(ii0, cur.z, false, negzero), tj_ = sb_mulh(ij0, cur.z, true, negzero), tk_ = sb_mulh(ik0, cur.w, false, negzero);
-							const float nv = pa * (val - ti * pa - tj_ * pa - tk_ * pa);
-							val = fl ? nv : val;
-							oi0 = oj0 = ok0 = valid ? val : 0.f;
-						}
-						if (valid && !(dbg & 1)) ring[row].x = val;
-						if (!JOUT_GLOB && !(dbg & 2)) {
-							if (s < 7) wjA[s + 1] = oj0;
-							else wjB[0] = oj0;
-						}
-						if (!KOUT_GLOB && !(dbg & 2)) {
-							if (s < 7) wkA[s + 1] = ok0;
-							else wkB[0] = ok0;
-						}
-						if (JOUT_GLOB || KOUT_GLOB) {
-							float fv = (JOUT_GLOB && !KOUT_GLOB) ? oj0 : ((KOUT_GLOB && !JOUT_GLOB) ? ok0 : ((b == 7) ? oj0 : ok0));
-							if (BOTH_GLOB) {
-								const float corner = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ok0), 63));
-								fv = (lane == 0) ? corner : fv;
-							}
-							if (face_lane) {
-								const bool fvalid = !EDGE || ((unsigned)(xq + s + fskew) < (unsigned)X8);
-								if (fvalid) granule_store(pf + s * 8, fv, gen);
-							}
-						}
-					}
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-					__hip_atomic_store(&S.done[w], m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					SB_TRACE(3)
-				};
-#pragma unroll 1
-				for (int m = 0; m < nblocks; m++) {
-					const bool interior = (m >= 2 && m <= nchunks - 1);
-					if (interior) block(m, std::false_type{});
-					else block(m, std::true_type{});
-				}
-				if (trace && lane == 0 && w == 0 && t < 2048) trace[1024 + 2 * t + 1] = wall_clock64();
-#undef SB_TRACE
-			};
-			if (wave == 0) compute(std::integral_constant<int, 0>{});
-			else if (wave == 1) compute(std::integral_constant<int, 1>{});
-			else if (wave == 2) compute(std::integral_constant<int, 2>{});
-			else compute(std::integral_constant<int, 3>{});
-		} else if (wave < 8) {
-			// ===================================== loader wave of sub-bundle w (own function: own register allocation) =====================================
-			const int w = wave - 4;
-			if (sub_alive(w)) {
-				const int tjl = sub_tjl(w), tkl = sub_tkl(w);
-				const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
-				const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
-				const bool row_in = (j < d.sy) && (k < d.sz);
-				const int sp = sb_loader<MODE>(S.ring[w], &S.ready[w], &S.flushed[w], nchunks, row_in, d.Y * j + d.Z * k, coef, Ap, dst, var1,
-				                               (trace && t == trace_ticket) ? trace + 5120 + w * 64 : nullptr);
-				spins += sp;
-			}
-		} else if (wave == 8) {
-			// ===================================== write-back wave (all four sub-bundles, each at its own pace) =====================================
-			int q[4] = {0, 0, 0, 0};
-			int64_t rowbase[4];
-			bool rin[4], live[4];
-#pragma unroll
-			for (int w = 0; w < 4; w++) {
-				live[w] = sub_alive(w);
-				const int tjl = sub_tjl(w), tkl = sub_tkl(w);
-				const int tj = REV ? nbj - 1 - tjl : tjl, tk = REV ? nbk - 1 - tkl : tkl;
-				const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
-				rin[w] = live[w] && (j < d.sy) && (k < d.sz);
-				rowbase[w] = d.Y * j + d.Z * k;
-				if (!live[w]) q[w] = nchunks;
-			}
-			for (;;) {
-				bool all = true, any = false;
-#pragma unroll
-				for (int w = 0; w < 4; w++) {
-					if (q[w] >= nchunks) continue;
-					all = false;
-					if (__hip_atomic_load(&S.done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < q[w] + 3) continue;   // chunk q is complete once block q+2 is finished
-					any = true;
-					const int p0 = 8 * q[w] + skew + 2;
-					float r[8];
-#pragma unroll
-					for (int e = 0; e < 8; e++) r[REV ? 7 - e : e] = S.ring[w][((p0 + e) & 31) * 64 + lane].x;
-					__hip_atomic_store(&S.flushed[w], q[w] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-					if (trace && t == trace_ticket && lane == 0 && q[w] < 64) trace[5376 + w * 64 + q[w]] = wall_clock64();
-					const int x0 = (REV ? nchunks - 1 - q[w] : q[w]) * 8;
-					if (rin[w]) {
-						*(float4*)(dst + rowbase[w] + x0) = make_float4(r[0], r[1], r[2], r[3]);
-						*(float4*)(dst + rowbase[w] + x0 + 4) = make_float4(r[4], r[5], r[6], r[7]);
-					}
-					q[w]++;
-				}
-				if (all) break;
-				if (!any) {
-					if (++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(4);
-				}
-			}
-		} else {
-			// ===================================== face poller: four 8-lane groups, each follows its own consumer =====================================
-			// group g = lane >> 3 (lanes 0..31): 0 j face of w0, 1 j face of w2, 2 k face of w0, 3 k face of w1; f = lane & 7 = face lane.
-			// A round trip to the granule arrays costs more than a block of the compute waves, so every round fetches the windows of
-			// SB_PW consecutive blocks and publishes as many leading ones as are complete (the face rings hold SB_FR / 8 blocks).
-			const int g = lane >> 3, f = lane & 7;
-			const int cw = (g == 0 || g == 2) ? 0 : (g == 1 ? 2 : 1);       // consumer sub-bundle
-			const bool isj = g < 2;
-			bool live = (lane < 32) && sub_alive(cw);
-			const int tjl = sub_tjl(cw), tkl = sub_tkl(cw);
-			if (live) live = isj ? (tjl > 0) : (tkl > 0);
-			const int64_t sid = (int64_t)tkl * nbj + tjl;
-			const unsigned long long* in = isj ? xj + (sid - 1) * XP * 8 + f : xk + (sid - nbj) * XP * 8 + f;
-			float* ringf = &S.FR[g & 3][f][0];
-			int m = live ? 0 : nblocks;
-			bool hot = false;      // per group: has a recent round published?  A cold group only probes the last row of its next window
-			int empty = 0;         // consecutive rounds without a publish: a group goes cold after SB_COLD_AFTER of them
-			for (;;) {
-				if (__all(m >= nblocks)) break;
-				unsigned long long gv[SB_PW][8];
-				int nok = 0;
-				if (m < nblocks && !hot) {
-					// probe: one granule per lane = one 64-byte line per group.  A producer stores its rows in order, so a fresh last row
-					// says the window is (nearly) there; the full fetch below verifies every tag.
-					const int xl = 8 * m - 2 - f + 7;
-					const unsigned long long pv = granule_load(in + (int64_t)(8 * m + 14) * 8);
-					const bool fresh = ((unsigned)(pv >> 32) == gen) || !((unsigned)xl < (unsigned)X8);
-					const unsigned long long fm = __ballot(fresh);
-					hot = ((fm >> (8 * g)) & 0xffull) != 0ull;
-				}
-				if (m < nblocks && hot) {
-#pragma unroll
-					for (int q = 0; q < SB_PW; q++) {
-						const int mq = (m + q < nblocks) ? m + q : nblocks - 1;
-#pragma unroll
-						for (int a = 0; a < 8; a++) gv[q][a] = granule_load(in + (int64_t)(8 * mq + 7 + a) * 8);
-					}
-					const int cdone = __hip_atomic_load(&S.done[cw], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-					bool run = true;
-#pragma unroll
-					for (int q = 0; q < SB_PW; q++) {
-						const int mq = m + q;
-						const int xq = 8 * mq - 2 - f;          // consumer lane (0, f) / (f, 0): skew f
-						unsigned tmin = gen;
-#pragma unroll
-						for (int a = 0; a < 8; a++) {
-							const bool inr = (unsigned)(xq + a) < (unsigned)X8;
-							const unsigned tg = (unsigned)(gv[q][a] >> 32);
-							tmin = min(tmin, inr ? tg : gen);
-						}
-						// complete, inside the sweep, and its ring slots were read (the consumer has finished block mq - SB_FR / 8)
-						run = run && (mq < nblocks) && (tmin == gen) && (cdone >= mq - SB_AHEAD);
-						nok += run ? 1 : 0;
-					}
-				}
-				// a group publishes the leading windows that are complete in all of its eight lanes
-				int gn = 0;
-				bool chain = true;
-#pragma unroll
-				for (int q = 0; q < SB_PW; q++) {
-					const unsigned long long okm = __ballot(nok > q);
-					chain = chain && (((okm >> (8 * g)) & 0xffull) == 0xffull);
-					gn += chain ? 1 : 0;
-				}
-				if (m >= nblocks) gn = 0;
-#pragma unroll
-				for (int q = 0; q < SB_PW; q++) {
-					if (q < gn) {
-						const int r0 = (8 * (m + q)) & (SB_FR - 1);
-						*(float4*)(ringf + r0) = make_float4(__uint_as_float((unsigned)gv[q][0]), __uint_as_float((unsigned)gv[q][1]), __uint_as_float((unsigned)gv[q][2]), __uint_as_float((unsigned)gv[q][3]));
-						*(float4*)(ringf + r0 + 4) = make_float4(__uint_as_float((unsigned)gv[q][4]), __uint_as_float((unsigned)gv[q][5]), __uint_as_float((unsigned)gv[q][6]), __uint_as_float((unsigned)gv[q][7]));
-					}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-				if (m < nblocks) {
-					empty = gn > 0 ? 0 : empty + 1;
-					hot = empty < 8;
-				}
-				if (gn > 0) {
-					if (trace && t == trace_ticket && f == 0 && lane < 32)
-						for (int q = 0; q < gn; q++) if (m + q < 64) trace[5632 + (g & 3) * 64 + m + q] = wall_clock64();
-					if (f == 0) __hip_atomic_store(&S.faces[g & 3], m + gn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					m += gn;
-				} else {
-					if (++spins > FLOW_SPIN_LIMIT) break;
-					__builtin_amdgcn_s_sleep(4);
-				}
-			}
-		}
-		__syncthreads();
-	}
-	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
-	if (threadIdx.x == 0) {
-		const int fin = atomicAdd(&ctl->finished, 1);
-		if (fin == (int)gridDim.x - 1) {
-			tick[0] = 0;
+			xt[0] = 0;
 			ctl->finished = 0;
 		}
 	}
@@ -1812,23 +1078,10 @@ k_mic_pack(int64_t n, const int32_t* __restrict__ flags, const float* __restrict
 	} else if (fl) {
 		const float v = A0[idx];
 		const int iv = (int)v;
-		if (v == (float)iv && iv >= 0 && iv <= 15) a0code = (unsigned)iv;
+		if (__float_as_uint(v) == __float_as_uint((float)iv) && iv >= 0 && iv <= 15) a0code = (unsigned)iv;   // bit pattern: -0.0f is not the +0 the nibble rebuilds
 		else ok[1] = 0;
 	}
 	pack[idx] = (unsigned char)((fl ? 1u : 0u) | (ui == M1 ? 2u : 0u) | (uj == M1 ? 4u : 0u) | (uk == M1 ? 8u : 0u) | (a0code << 4));
-}
-
-// the coefficient word of k_mic_sb, one per cell: bytes {Ai == -1 ? 0xBC : 0, Aj ..., Ak ..., fluid ? 0 : 0x80} -- 0xBC00 is fp16 -1.0, so
-// a byte permute turns the word into the two fp16 pairs of the LDS slot, and bit 31 is the "not a fluid cell" mark that goes onto
-// the sign of Aprecond.  Valid under the same condition as the packed bytes (every coefficient exactly +0 or -1: ok[0] of k_mic_pack).
-__global__ void __launch_bounds__(BLOCK)
-k_mic_sbcoef(int64_t n, const int32_t* __restrict__ flags, const float* __restrict__ Ai, const float* __restrict__ Aj,
-             const float* __restrict__ Ak, unsigned* __restrict__ coef) {
-	const int64_t idx = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
-	if (idx >= n) return;
-	const unsigned M1 = 0xBF800000u;   // -1.0f
-	const unsigned ui = __float_as_uint(Ai[idx]), uj = __float_as_uint(Aj[idx]), uk = __float_as_uint(Ak[idx]);
-	coef[idx] = (ui == M1 ? 0xBCu : 0u) | (uj == M1 ? 0xBC00u : 0u) | (uk == M1 ? 0xBC0000u : 0u) | ((flags[idx] & MF_FLUID) ? 0u : 0x80000000u);
 }
 
 // bempty[tk * nbj + tj] = 1 when the 8x8 bundle of x-rows (tj, tk) needs no sweep: it has no fluid cell, and nothing couples
@@ -1862,15 +1115,15 @@ k_bundle_empty(Dim d, int nbj, const int32_t* __restrict__ flags, const float* _
 	}
 }
 
-// host-side state of the dataflow sweeps (per device): tile order for the current grid, exchange buffer, generation
+// The system handle of the sweeps (per device; built by mf_mic_init_blocked / mf_pack_matrix, used by the apply sweeps of the
+// grids it was built for): sweep mode, preconditioner blocks, bundle order, hand-off buffers, packed operands, empty-bundle map.
 struct FlowState {
-	int nti = 0, ntj = 0, ntk = 0, ntiles = 0;
-	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;   // streaming form
+	int mode = 2;                // sweep mode this system was initialised under: 2 "rows", 0 "levels" (mf_set_mic_mode / MF_MIC_MODE)
+	int nbj = 0, nbk = 0, nblocks = 0, nchunks = 0;
 	int* border = nullptr;       // ticket order of the forward sweep, then of the backward sweep (nblocks entries each)
 	int jb = 0;                  // bundles per j-block the order was built for
 	int nxb = 0;                 // x-blocks per row (1 = whole rows)
-	int nq = 0;                  // ticket queues (1 or 8)
-	int* rows_xt = nullptr;      // [2][18]: tickets, queue bounds, queue count -- forward sweep, backward sweep
+	int* rows_xt = nullptr;      // [2]: ticket counter of the forward / backward sweep
 	// bundles without a fluid cell (and without coupling into them) need no sweep at all: built by mf_mic_init for the grids
 	// it was given, used by the apply sweeps only when they are given the same grids
 	int* bempty = nullptr;
@@ -1879,17 +1132,6 @@ struct FlowState {
 	// preconditioner blocks of the system mf_mic_init_blocked was given (0 = uncut): the apply sweeps use them only when they
 	// are called with the same flags / Aprecond / Aj / Ak (be_*), any other system is swept as the uncut reference algorithm
 	int blk_rows = 0, blk_cells = 0;
-	// what the host knows about the system mf_mic_init registered (read back once per system, one stream synchronisation):
-	// are the packed bytes exact, and does any row bundle sit out the sweeps?  The super-bundle sweeps need yes / no.
-	bool sys_known = false;
-	int pack_ok_host = 0, nempty_host = 0;
-	// super-bundle sweeps (k_mic_sb): ticket order of the 16 x 16-row blocks, ticket counter
-	int sb_nsj = 0, sb_nsk = 0;
-	int* sb_order = nullptr;
-	int* sb_tick = nullptr;
-	unsigned* sb_coef = nullptr;      // k_mic_sbcoef words of the registered system (nullptr: not built, e.g. sx % 8 != 0)
-	size_t sb_coef_cap = 0;
-	bool sb_coef_valid = false;
 	// packed operands of the apply sweeps (k_mic_pack), valid for the grids mf_mic_init was given
 	unsigned char* pack = nullptr;
 	int* pack_ok = nullptr;
@@ -1905,142 +1147,45 @@ struct FlowState {
 	unsigned long long *sxj1 = nullptr, *sxk1 = nullptr;      // second hand-off value of the init sweep (k_mic_rows_init)
 	size_t sx_cap = 0;
 	unsigned sgen = 0;
-	int* order = nullptr;
-	int level_count[3072];
-	unsigned long long* xch = nullptr;
-	size_t xch_cap = 0;
 	FlowCtl* ctl = nullptr;
-	unsigned gen = 0;
 };
 static FlowState g_flow[16];
 
-static int flow_prepare(const Dim& d, FlowState** out, hipStream_t st, bool need_xch = false) {
-	int dev = 0;
-	MF_HIP(hipGetDevice(&dev));
-	FlowState& f = g_flow[dev];
-	const int nti = (d.sx + 7) / 8, ntj = (d.sy + 7) / 8, ntk = (d.sz + 7) / 8;
-	if (nti > 1023 || ntj > 1023 || ntk > 1023) return fail("grid too large for the MIC tile order table");
-	if (!f.ctl) {
-		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
-		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
-	}
-	if (f.nti != nti || f.ntj != ntj || f.ntk != ntk) {
-		MF_HIP(hipStreamSynchronize(st));
-		const int nt = nti * ntj * ntk;
-		int* h = (int*)malloc(sizeof(int) * nt);
-		int q = 0;
-		for (int L = 0; L <= nti + ntj + ntk - 3; L++) {
-			const int q0 = q;
-			for (int tk = 0; tk < ntk; tk++)
-				for (int tj = 0; tj < ntj; tj++) {
-					const int ti = L - tj - tk;
-					if (ti >= 0 && ti < nti) h[q++] = ti | (tj << 10) | (tk << 20);
-				}
-			f.level_count[L] = q - q0;
-		}
-		if (f.order) MF_HIP(hipFree(f.order));
-		MF_HIP(hipMalloc((void**)&f.order, sizeof(int) * nt));
-		MF_HIP(hipMemcpy(f.order, h, sizeof(int) * nt, hipMemcpyHostToDevice));
-		free(h);
-		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
-		f.gen = 0;
-		f.nti = nti;
-		f.ntj = ntj;
-		f.ntk = ntk;
-		f.ntiles = nt;
-		if (f.xch) MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
-	}
-	if (need_xch) {
-		const size_t need = (size_t)f.ntiles * 3 * 64 * sizeof(unsigned long long);
-		if (need > f.xch_cap) {
-			MF_HIP(hipStreamSynchronize(st));
-			if (f.xch) MF_HIP(hipFree(f.xch));
-			MF_HIP(hipMalloc((void**)&f.xch, need));
-			f.xch_cap = need;
-			MF_HIP(hipMemset(f.xch, 0, f.xch_cap));
-			f.gen = 0;
-		}
-	}
-	*out = &f;
-	return 0;
-}
-// per-XCD ticket queues rely on workgroup b running on XCD b % 8 (round-robin dispatch, verified once per process)
-__global__ void k_probe_xcc(int* out) {
-	if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
-}
-static bool xcd_round_robin_ok() {
-	static int state = -1;
-	if (state < 0) {
-		state = 0;
-		int* dbuf = nullptr;
-		int hbuf[64];
-		if (hipMalloc((void**)&dbuf, sizeof hbuf) == hipSuccess) {
-			hipLaunchKernelGGL(k_probe_xcc, dim3(64), dim3(64), 0, 0, dbuf);
-			if (hipMemcpy(hbuf, dbuf, sizeof hbuf, hipMemcpyDeviceToHost) == hipSuccess) {
-				state = 1;
-				for (int b = 0; b < 64; b++)
-					if (hbuf[b] != (b & 7)) state = 0;
-			}
-			(void)hipFree(dbuf);
-		}
-	}
-	return state == 1;
-}
 static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jblock_rows, int xblock_cells) {
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
 	const int nbj = (d.sy + 7) / 8, nbk = (d.sz + 7) / 8;
-	// x-blocks of g_mic_xblock_cells cells (independent systems, the caller has cut Ai) -- or the whole row
+	// x-blocks of xblock_cells cells (independent systems, the caller has cut Ai) -- or the whole row
 	const int xcells = (xblock_cells > 0 && xblock_cells < d.sx) ? xblock_cells : ((d.sx + 7) / 8) * 8;
 	const int nchunks = xcells / 8, nxb = (d.sx + xcells - 1) / xcells;
 	if (nbj > 4095 || nbk > 4095 || nxb > 127) return fail("grid too large for the MIC bundle order table");
 	int jb = jblock_rows > 0 ? jblock_rows / 8 : nbj;
 	if (jb < 1 || jb > nbj) jb = nbj;
-	// MF_ROWS_XCD=1: one ticket queue per XCD = k-slab of bundles (256^3: 549 us per apply, 32 workgroups cannot cover a 4-bundle-wide band);
-	// =2: queues interleaved in k (tkl % 8: balanced; j faces stay inside an XCD's L2, k faces cross): 409 vs 416 us at 256^3, 192 vs 194 at
-	// 128^3, 2023 vs 1963 at 512^3 (mid-round figures)
-	// default: interleaved queues where the sweep is bound by its chain of hand-offs (up to ~4 bundles per workgroup: 397 vs 402 us at 256^3,
-	// 269 vs 276 at 192^3; 320^3 already prefers one queue, 645 vs 666),
-	// one global queue where it is bound by the number of workgroups (512^3: 1920 vs 2034 us) or too small to matter
-	static const int env_xcd = getenv("MF_ROWS_XCD") ? atoi(getenv("MF_ROWS_XCD")) : -1;
-	const int nb_all = nbj * nbk * nxb;
-	const int use_xcd = env_xcd >= 0 ? env_xcd : ((nb_all >= 512 && nb_all <= 1280) ? 2 : 0);
-	const int nq = (use_xcd && nbk >= 8 && xcd_round_robin_ok()) ? 8 : 1;
 	if (!f.ctl) {
 		MF_HIP(hipMalloc((void**)&f.ctl, sizeof(FlowCtl)));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 	}
-	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nq != (nq | (use_xcd << 8)) || f.nxb != nxb) {
+	if (f.nbj != nbj || f.nbk != nbk || f.nchunks != nchunks || f.jb != jb || f.nxb != nxb) {
 		MF_HIP(hipStreamSynchronize(st));
 		const int nb = nbj * nbk * nxb;
 		int* h = (int*)malloc(sizeof(int) * 2 * nb);
-		int xt[2][18];
-		memset(xt, 0, sizeof xt);
 		// tickets in topological order of each sweep: key = position of the bundle inside its j-block along the sweep
-		// direction + tkl (anti-diagonals of the block-local dependency graph); one queue per XCD = k-slab of bundles
+		// direction + tkl (anti-diagonals of the block-local dependency graph); ONE queue per sweep (see k_mic_rows)
 		for (int rev = 0; rev < 2; rev++) {
 			int q = 0;
-			for (int x = 0; x < 8; x++) {
-				xt[rev][8 + x] = q;
-				if (x < nq)
-					for (int L = 0; L <= nbj + nbk - 2; L++)
-						for (int bk = 0; bk < nbk; bk++) {
-							if (use_xcd == 2 ? (bk % nq != x) : ((bk * nq) / nbk != x)) continue;
-							for (int bjl = 0; bjl < nbj; bjl++) {
-								const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
-								const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
-								const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
-								if (posj + bk == L)
-									for (int xb = 0; xb < nxb; xb++) h[rev * nb + q++] = bjl | (bk << 12) | (xb << 24);
-							}
-						}
-			}
-			xt[rev][16] = q;
-			xt[rev][17] = nq | ((nq > 1 && use_xcd == 2) ? 0x100 : 0);      // bit 8: queues interleaved in k (tkl % 8) instead of k-slabs
+			for (int L = 0; L <= nbj + nbk - 2; L++)
+				for (int bk = 0; bk < nbk; bk++)
+					for (int bjl = 0; bjl < nbj; bjl++) {
+						const int tj = rev ? nbj - 1 - bjl : bjl;   // physical bundle row
+						const int b0 = (tj / jb) * jb, b1 = (b0 + jb < nbj ? b0 + jb : nbj);
+						const int posj = rev ? (b1 - 1 - tj) : (tj - b0);
+						if (posj + bk == L)
+							for (int xb = 0; xb < nxb; xb++) h[rev * nb + q++] = bjl | (bk << 12) | (xb << 24);
+					}
 		}
-		if (!f.rows_xt) MF_HIP(hipMalloc((void**)&f.rows_xt, sizeof(xt)));
-		MF_HIP(hipMemcpy(f.rows_xt, xt, sizeof(xt), hipMemcpyHostToDevice));
+		if (!f.rows_xt) MF_HIP(hipMalloc((void**)&f.rows_xt, 2 * sizeof(int)));
+		MF_HIP(hipMemset(f.rows_xt, 0, 2 * sizeof(int)));
 		if (f.border) MF_HIP(hipFree(f.border));
 		MF_HIP(hipMalloc((void**)&f.border, sizeof(int) * 2 * nb));
 		MF_HIP(hipMemcpy(f.border, h, sizeof(int) * 2 * nb, hipMemcpyHostToDevice));
@@ -2048,23 +1193,16 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 		// one granule per (bundle, x', face lane) and face
 		const size_t need = (size_t)nb * 8 * (8 * (size_t)nchunks + 2 * ROWS_PAD) * sizeof(unsigned long long);
 		if (need > f.sx_cap) {
-			if (f.sxj) MF_HIP(hipFree(f.sxj));
-			if (f.sxk) MF_HIP(hipFree(f.sxk));
 			// (fine-grained memory, hipExtMallocWithFlags, was tried for these: 0.45 instead of 0.71 us per idle hand-off in
 			// tools/micro/pingpong_scalar.hip, but no change of the sweep time -- 575.0 vs 576.4 us per apply at 256^3; so were four
 			// scalar-path poller waves (s_load_dwordx16 glc, 0.45 us per hand-off in the micro-benchmark): bit-exact, 700+ us)
-			MF_HIP(hipMalloc((void**)&f.sxj, need));
-			MF_HIP(hipMalloc((void**)&f.sxk, need));
-			if (f.sxj1) MF_HIP(hipFree(f.sxj1));
-			if (f.sxk1) MF_HIP(hipFree(f.sxk1));
-			MF_HIP(hipMalloc((void**)&f.sxj1, need));
-			MF_HIP(hipMalloc((void**)&f.sxk1, need));
+			for (unsigned long long** q : {&f.sxj, &f.sxk, &f.sxj1, &f.sxk1}) {
+				if (*q) MF_HIP(hipFree(*q));
+				MF_HIP(hipMalloc((void**)q, need));
+			}
 			f.sx_cap = need;
 		}
-		MF_HIP(hipMemset(f.sxj, 0, f.sx_cap));
-		MF_HIP(hipMemset(f.sxk, 0, f.sx_cap));
-		MF_HIP(hipMemset(f.sxj1, 0, f.sx_cap));
-		MF_HIP(hipMemset(f.sxk1, 0, f.sx_cap));
+		for (unsigned long long* q : {f.sxj, f.sxk, f.sxj1, f.sxk1}) MF_HIP(hipMemset(q, 0, f.sx_cap));
 		MF_HIP(hipMemset(f.ctl, 0, sizeof(FlowCtl)));
 		f.sgen = 0;
 		f.nbj = nbj;
@@ -2072,27 +1210,42 @@ static int rows_prepare(const Dim& d, FlowState** out, hipStream_t st, int jbloc
 		f.nblocks = nb;
 		f.nchunks = nchunks;
 		f.jb = jb;
-		f.nq = nq | (use_xcd << 8);
 		f.nxb = nxb;
 	}
 	*out = &f;
 	return 0;
 }
-// MF_MIC_MODE selects how the two apply sweeps are parallelised (all three give bit-identical results):
-// 2 "rows"  : one launch per sweep, a 6-wave workgroup per 8x8 bundle of x-rows streaming along x (default for 3D grids:
-//              256^3 apply 0.83 ms; 2D grids fall through to "tiles")
-// 1 "tiles" : one launch per sweep, ticketed 8^3 tiles + tagged sc1 granules, operands of the next tile prefetched
-//              (256^3 apply 1.32 ms)
-// 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback, 2.2 ms)
-static int g_mic_mode = -1;     // 0 levels, 1 tiles, 2 rows, 3 rows-sb (super-bundles where they apply, else rows)
+// next launch generation of the hand-off granules (tag = generation: the buffers are cleared only when the 32-bit counter wraps)
+static int rows_next_gen(FlowState* f, hipStream_t st) {
+	f->sgen++;
+	if (f->sgen == 0) {
+		for (unsigned long long* q : {f->sxj, f->sxk, f->sxj1, f->sxk1}) MF_HIP(hipMemsetAsync(q, 0, f->sx_cap, st));
+		f->sgen = 1;
+	}
+	return 0;
+}
+
+// How the sweeps are parallelised (both give the bits of the serial sweep):
+// 2 "rows"  : one launch per sweep, a 7-wave workgroup per 8x8 bundle of x-rows streaming along x (default for 3D grids)
+// 0 "levels": one launch per tile hyperplane (no inter-workgroup waiting at all; the conservative fallback, 2.2 ms per 256^3 apply)
+// mf_set_mic_mode / MF_MIC_MODE choose the mode the NEXT mf_mic_init registers its system under; the apply sweeps of that system
+// follow the handle, a system the handle does not know is swept in the requested mode.
+// (Round 2 also carried "tiles", single-wave 8^3 tiles in one launch -- 1.32 ms -- and "rows-sb", 2 x 2 bundles per workgroup --
+// 1.05 ms; both bit-exact, both slower than "rows", deleted in round 3.)
+static int g_mic_mode = -1;     // requested mode: 0 levels, 2 rows
 extern "C" int mf_set_mic_mode(const char* name) {
 	if (!name || !*name) g_mic_mode = -1;
 	else if (!strcmp(name, "levels")) g_mic_mode = 0;
-	else if (!strcmp(name, "tiles")) g_mic_mode = 1;
 	else if (!strcmp(name, "rows")) g_mic_mode = 2;
-	else if (!strcmp(name, "rows-sb")) g_mic_mode = 3;      // "rows" with the super-bundle form (2 x 2 bundles per workgroup) where it applies
-	else return fail("mf_set_mic_mode: unknown mode (rows | rows-sb | tiles | levels)");
+	else return fail("mf_set_mic_mode: unknown mode (rows | levels)");
 	return 0;
+}
+static int mic_mode_() {
+	if (g_mic_mode < 0) {
+		const char* e = getenv("MF_MIC_MODE");
+		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : 2;
+	}
+	return g_mic_mode;
 }
 extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
@@ -2102,8 +1255,7 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 	FlowState& f = g_flow[dev];
 	hipStream_t st = (hipStream_t)stream;
 	f.upack_ok_host = 0;
-	static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
-	if (nopack || !d.is3d || (d.sx % 4) != 0) return 0;
+	if (!d.is3d || (d.sx % 4) != 0) return 0;
 	if ((size_t)d.n > f.upack_cap) {
 		MF_HIP(hipStreamSynchronize(st));
 		if (f.upack) MF_HIP(hipFree(f.upack));
@@ -2124,106 +1276,7 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 	f.up_Ak = Ak;
 	return 0;
 }
-static int mic_mode_() {
-	if (g_mic_mode < 0) {
-		const char* e = getenv("MF_MIC_MODE");
-		g_mic_mode = (e && !strcmp(e, "levels")) ? 0 : ((e && !strcmp(e, "tiles")) ? 1 : ((e && !strcmp(e, "rows-sb")) ? 3 : 2));
-	}
-	return g_mic_mode >= 2 ? 2 : g_mic_mode;
-}
-static bool mic_sb_() { (void)mic_mode_(); return g_mic_mode == 3; }
 
-// host side of k_mic_sb: ticket order (anti-diagonals of the super-bundle grid, logical coordinates: the same table serves both
-// sweeps), ticket counter, dynamic LDS size
-template <int MODE>
-static int sb_launch(const Dim& d, FlowState* f, float* dst, const float* var1, const float* Ap, const CgScalars* sc, hipStream_t st) {
-	const int nsj = (f->nbj + 1) / 2, nsk = (f->nbk + 1) / 2, nsb = nsj * nsk;
-	if (f->sb_nsj != nsj || f->sb_nsk != nsk) {
-		MF_HIP(hipStreamSynchronize(st));
-		int* h = (int*)malloc(sizeof(int) * nsb);
-		int q = 0;
-		for (int L = 0; L <= nsj + nsk - 2; L++)
-			for (int SK = 0; SK < nsk; SK++) {
-				const int SJ = L - SK;
-				if (SJ >= 0 && SJ < nsj) h[q++] = SJ | (SK << 12);
-			}
-		if (f->sb_order) MF_HIP(hipFree(f->sb_order));
-		MF_HIP(hipMalloc((void**)&f->sb_order, sizeof(int) * nsb));
-		MF_HIP(hipMemcpy(f->sb_order, h, sizeof(int) * nsb, hipMemcpyHostToDevice));
-		free(h);
-		if (!f->sb_tick) MF_HIP(hipMalloc((void**)&f->sb_tick, sizeof(int)));
-		MF_HIP(hipMemset(f->sb_tick, 0, sizeof(int)));
-		f->sb_nsj = nsj;
-		f->sb_nsk = nsk;
-	}
-	static bool attr_set = false;
-	if (!attr_set) {
-		MF_HIP(hipFuncSetAttribute((const void*)k_mic_sb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbShared)));
-		MF_HIP(hipFuncSetAttribute((const void*)k_mic_sb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbShared)));
-		attr_set = true;
-	}
-	static int ncu = -1;
-	if (ncu < 0) {
-		int dev = 0;
-		(void)hipGetDevice(&dev);
-		ncu = 256;
-		(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-		const char* e = getenv("MF_SB_WGS");
-		if (e) ncu = atoi(e);
-		if (ncu < 1) ncu = 1;
-	}
-	const int grid = nsb < ncu ? nsb : ncu;
-	union { unsigned u; float fl; } nz;
-	nz.u = 0x80000000u;
-	// MF_SB_TRACE=<ticket>: wall-clock stamps (100 MHz) of that super-bundle's four compute waves per block, and start / end of every
-	// super-bundle's wave 0, printed for the first launches
-	static const int dbg = getenv("MF_SB_DBG") ? atoi(getenv("MF_SB_DBG")) : 0;     // timing experiments only (wrong results)
-	static long long* trace = nullptr;
-	static int trace_ticket = -2;
-	if (trace_ticket == -2) {
-		const char* e = getenv("MF_SB_TRACE");
-		trace_ticket = e ? atoi(e) : -1;
-		if (trace_ticket >= 0) {
-			MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 8192));
-			MF_HIP(hipMemset(trace, 0, sizeof(long long) * 8192));
-		}
-	}
-	hipLaunchKernelGGL((k_mic_sb<MODE>), dim3(grid), dim3(SB_THREADS), sizeof(SbShared), st, d, f->nbj, f->nbk, nsj, nsb, f->nchunks, f->sb_order, f->ctl,
-	                   f->sb_tick, f->sxj, f->sxk, f->sgen, dst, var1, Ap, sc, f->sb_coef, nz.fl, trace, trace_ticket, dbg);
-	MF_LAUNCH_CHECK();
-	if (trace) {
-		static int printed = 0;
-		MF_HIP(hipStreamSynchronize(st));
-		if (printed++ < 2) {
-			long long* h = (long long*)malloc(sizeof(long long) * 8192);
-			MF_HIP(hipMemcpy(h, trace, sizeof(long long) * 8192, hipMemcpyDeviceToHost));
-			const int nb = f->nchunks + 2 < 64 ? f->nchunks + 2 : 64;
-			long long t0 = h[0];
-			fprintf(stderr, "[sb trace] mode %d ticket %d: per wave and block: gap | wait ready | wait faces | steps (us), end time\n", MODE, trace_ticket);
-			for (int w = 0; w < 4; w++) {
-				const long long* b = h + w * 256;
-				for (int m = 0; m < nb; m++)
-					fprintf(stderr, "  w%d m=%2d  %6.2f %6.2f %6.2f %6.2f   t=%8.2f\n", w, m, m ? (b[m * 4] - b[m * 4 - 1]) * 0.01 : (b[0] - t0) * 0.01, (b[m * 4 + 1] - b[m * 4]) * 0.01,
-					        (b[m * 4 + 2] - b[m * 4 + 1]) * 0.01, (b[m * 4 + 3] - b[m * 4 + 2]) * 0.01, (b[m * 4 + 3] - t0) * 0.01);
-			}
-			fprintf(stderr, "[sb trace] helper stamps (us since the super-bundle's start): block | commit w0..w3 | flush w0..w3 | publish g0..g3\n");
-			for (int m = 0; m < nb; m++) {
-				fprintf(stderr, "  m=%2d |", m);
-				for (int q = 0; q < 12; q++) {
-					const long long v = h[5120 + q * 64 + m];
-					fprintf(stderr, " %7.2f%s", v ? (v - t0) * 0.01 : -1.0, (q % 4 == 3) ? " |" : "");
-				}
-				fprintf(stderr, "\n");
-			}
-			long long g0 = h[1024];
-			for (int i = 0; i < nsb && i < 2048; i++) if (h[1024 + 2 * i] && h[1024 + 2 * i] < g0) g0 = h[1024 + 2 * i];
-			fprintf(stderr, "[sb trace] super-bundles (ticket: start end, us since the first start)\n");
-			for (int i = 0; i < nsb && i < 2048; i += (nsb > 64 ? 7 : 1)) fprintf(stderr, "  t=%4d  %8.2f %8.2f\n", i, (h[1024 + 2 * i] - g0) * 0.01, (h[1024 + 2 * i + 1] - g0) * 0.01);
-			free(h);
-		}
-	}
-	return 0;
-}
 // set by mic_launch_dot for the duration of one backward-sweep launch
 static thread_local double* g_dot_request = nullptr;
 static thread_local int g_dot_count = 0;
@@ -2234,154 +1287,38 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 	const int levels = nti + ntj + ntk - 2;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(var1) && al16(Ai) && al16(Aj) && al16(Ak) && (MODE == 0 || al16(Ap));
 	if constexpr (MODE != 0) {
-		if (mic_mode_() == 2 && d.is3d) {
-			int dev_ = 0;
-			MF_HIP(hipGetDevice(&dev_));
-			const FlowState& f0 = g_flow[dev_];
-			const bool same_system = f0.be_flags == flags && f0.be_Ap == Ap && f0.be_Aj == Aj && f0.be_Ak == Ak;
+		int dev_ = 0;
+		MF_HIP(hipGetDevice(&dev_));
+		const FlowState& f0 = g_flow[dev_];
+		// the system mf_mic_init registered: its mode and its preconditioner blocks; any other system: requested mode, uncut
+		const bool same_system = f0.be_flags == flags && f0.be_Ap == Ap && f0.be_Aj == Aj && f0.be_Ak == Ak;
+		const int mode = same_system ? f0.mode : mic_mode_();
+		if (mode == 2 && d.is3d) {
 			FlowState* f;
 			MF_TRY(rows_prepare(d, &f, st, same_system ? f0.blk_rows : 0, same_system ? f0.blk_cells : 0));
-			f->sgen++;
-			if (f->sgen == 0) {
-				MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
-				MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
-				MF_HIP(hipMemsetAsync(f->sxj1, 0, f->sx_cap, st));
-				MF_HIP(hipMemsetAsync(f->sxk1, 0, f->sx_cap, st));
-				f->sgen = 1;
-			}
-			// ---- super-bundle sweeps: the uncut system mf_mic_init registered, packed coefficients exact, every bundle swept ----
-			static const bool nosb = getenv("MF_MIC_NOSB") != nullptr;
-			static const bool nopack_sb = getenv("MF_MIC_NOPACK") != nullptr;
-			if (!nosb && mic_sb_() && !nopack_sb && vec && (d.sx % 8) == 0 && same_system && f->blk_rows == 0 && f->blk_cells == 0 && f->pack &&
-			    f->pk_flags == flags && f->pk_Ai == Ai && f->pk_Aj == Aj && f->pk_Ak == Ak && d.sx >= 32 && f->sb_coef_valid) {
-				if (!f->sys_known) {
-					int h[2] = {0, 0};
-					MF_HIP(hipMemcpyAsync(&h[0], f->pack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
-					MF_HIP(hipMemcpyAsync(&h[1], f->bempty + f->nbj * f->nbk, sizeof(int), hipMemcpyDeviceToHost, st));
-					MF_HIP(hipStreamSynchronize(st));
-					f->pack_ok_host = h[0] != 0;
-					f->nempty_host = h[1];
-					f->sys_known = true;
-				}
-				if (f->pack_ok_host && f->nempty_host == 0) {
-					MF_TRY(sb_launch<MODE>(d, f, dst, var1, Ap, sc, st));
-					g_dot_count = 0;      // no fused dot in this form: the caller runs its own dot kernel
-					return 0;
-				}
-			}
-			static int rwgs = -1;
-			if (rwgs < 0) {
-				const char* e = getenv("MF_ROWS_WGS");
-				int dev = 0, ncu = 256;
+			MF_TRY(rows_next_gen(f, st));
+			static int ncu = 0;
+			if (!ncu) {
+				// one bundle per CU measured best (round 1: 834 us per apply with 256 workgroups, 1040 us with 512; round 2, with a
+				// packed-only <= 128-VGPR variant and a 32- / 48-step ring for two workgroups per CU: 445 vs 412 us, 217 vs 204 us per
+				// sweep -- mid-sweep the 256 bundles already stream ~4 TB/s, the rest of the sweep is the dependency chain)
+				int dev = 0;
+				ncu = 256;
 				(void)hipGetDevice(&dev);
 				(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-				// one bundle per CU measured best (round 1: 834 us per apply with 256 workgroups, 1040 us with 512).  Round 2, with a
-				// packed-only variant of the kernel (<= 128 VGPRs, 32-step ring = 56 KB of LDS, two workgroups per CU): 445 vs 412 us --
-				// the 32-step ring costs 28 us and the second workgroup per CU gains nothing: mid-sweep the 256 bundles already
-				// stream ~4 TB/s, the rest of the sweep is the dependency chain
-				// (third try, final kernel, forward sweep only with a 48-step ring = 72 KB: both workgroups resident -- bundles past
-				// ticket 256 start at once -- and every hop takes 2.8 instead of 2.3 us: 217 vs 204 us per sweep)
-				rwgs = e ? atoi(e) : ncu;
-				if (rwgs < 1) rwgs = 1;
+				if (ncu < 1) ncu = 1;
 			}
-			const int grid = f->nblocks < rwgs ? f->nblocks : rwgs;
-			// MF_ROWS_TRACE=<ticket>: per-block wall-clock stamps (100 MHz) of that bundle's compute wave, printed per launch
-			static long long* trace = nullptr;
-			static int trace_ticket = -2;
-			static int trace_ticket2 = getenv("MF_ROWS_TRACE2") ? atoi(getenv("MF_ROWS_TRACE2")) : -1;
-			if (trace_ticket == -2) {
-				const char* e = getenv("MF_ROWS_TRACE");
-				trace_ticket = e ? atoi(e) : -1;
-				if (trace_ticket >= 0) {
-					MF_HIP(hipMalloc((void**)&trace, sizeof(long long) * 12 * 4096));
-					MF_HIP(hipMemset(trace, 0, sizeof(long long) * 12 * 4096));
-					if (trace_ticket2 < 0 && trace_ticket < f->nblocks) {
-						// second traced bundle = the j-successor of the first (the consumer of its j face); MF_ROWS_TRACEK: its k-successor
-						int* ho = (int*)malloc(sizeof(int) * f->nblocks);
-						MF_HIP(hipMemcpy(ho, f->border, sizeof(int) * f->nblocks, hipMemcpyDeviceToHost));
-						const int want = ho[trace_ticket] + (getenv("MF_ROWS_TRACEK") ? (1 << 12) : 1);
-						for (int i = 0; i < f->nblocks; i++)
-							if (ho[i] == want) trace_ticket2 = i;
-						free(ho);
-					}
-				}
-			}
-			static const bool noskip = getenv("MF_MIC_NOSKIP") != nullptr;
-			const int* be = (!noskip && f->bempty && f->be_flags == flags && f->be_Ap == Ap && f->be_Aj == Aj && f->be_Ak == Ak) ? f->bempty : nullptr;
-			static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
+			const int grid = f->nblocks < ncu ? f->nblocks : ncu;
+			const int* be = (f->bempty && same_system) ? f->bempty : nullptr;
+			static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;       // debugging: sweeps on the four coefficient arrays
 			const bool use_pack = !nopack && f->pack && (d.sx % 8 == 0) && f->pk_flags == flags && f->pk_Ai == Ai && f->pk_Aj == Aj && f->pk_Ak == Ak;
 			const unsigned char* pk = use_pack ? f->pack : nullptr;
 			double* dotp = (MODE == 2 && al16(var1) && f->nblocks <= MAX_BLOCKS) ? g_dot_request : nullptr;
 			g_dot_count = dotp ? f->nblocks : 0;
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, trace, trace_ticket, trace_ticket2);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 18 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, trace, trace_ticket, trace_ticket2);
-			MF_LAUNCH_CHECK();
-			if (trace) {
-				static int printed = 0;
-				MF_HIP(hipStreamSynchronize(st));
-				if (printed++ < 4) {
-					const int nb = f->nchunks + 2;
-					long long* h = (long long*)malloc(sizeof(long long) * 4 * nb);
-					MF_HIP(hipMemcpy(h, trace, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
-					fprintf(stderr, "[rows trace] mode %d ticket %d: block: gap ready poll steps (us)\n", MODE, trace_ticket);
-					for (int m = 0; m < nb; m++)
-						fprintf(stderr, "  m=%2d  %6.2f %6.2f %6.2f %6.2f   t=%.2f\n", m, m ? (h[m * 4] - h[m * 4 - 1]) * 0.01 : 0.0, (h[m * 4 + 1] - h[m * 4]) * 0.01,
-						        (h[m * 4 + 2] - h[m * 4 + 1]) * 0.01, (h[m * 4 + 3] - h[m * 4 + 2]) * 0.01, (h[m * 4 + 3] - h[0]) * 0.01);
-					if (trace_ticket2 >= 0) {
-						// producer (ticket) vs consumer (ticket2): consumer block m needs the producer's step 8m+12 (its block m+1)
-						long long* h2 = (long long*)malloc(sizeof(long long) * 4 * nb);
-						MF_HIP(hipMemcpy(h2, trace + 8 * 4096, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
-						fprintf(stderr, "[rows trace] hand-off %d -> %d: m  producer_end(m+1)  consumer_faces_ready(m)  delta   consumer_block_start(m)\n", trace_ticket, trace_ticket2);
-						for (int m = 0; m + 1 < nb; m++)
-							fprintf(stderr, "  m=%2d  %8.2f  %8.2f  %6.2f   %8.2f\n", m, (h[(m + 1) * 4 + 3] - h[0]) * 0.01, (h2[m * 4 + 2] - h[0]) * 0.01,
-							        (h2[m * 4 + 2] - h[(m + 1) * 4 + 3]) * 0.01, (h2[m * 4] - h[0]) * 0.01);
-						free(h2);
-					}
-					free(h);
-					const int ns = f->nblocks < 4096 ? f->nblocks : 4096;
-					long long* g = (long long*)malloc(sizeof(long long) * 2 * ns);
-					MF_HIP(hipMemcpy(g, trace + 4 * 4096, sizeof(long long) * 2 * ns, hipMemcpyDeviceToHost));
-					long long t0 = g[0];
-					for (int i = 0; i < ns; i++) if (g[2 * i] < t0) t0 = g[2 * i];
-					fprintf(stderr, "[rows trace] bundles: ticket start end (us since first start)\n");
-					for (int i = 0, L = 0; i < ns; L++, i += (L < f->nbj ? L : 1) + 0) {
-						fprintf(stderr, "  t=%4d  %8.2f %8.2f\n", i, (g[2 * i] - t0) * 0.01, (g[2 * i + 1] - t0) * 0.01);
-						if (L > 200) break;
-					}
-					free(g);
-					long long* hw = (long long*)malloc(sizeof(long long) * ns);
-					MF_HIP(hipMemcpy(hw, trace + 6 * 4096, sizeof(long long) * ns, hipMemcpyDeviceToHost));
-					fprintf(stderr, "[rows trace] compute wave placement: ticket block simd cu sh se\n");
-					for (int i = 0; i < ns && i < 1024; i += 37) {
-						const unsigned v = (unsigned)hw[i];
-						fprintf(stderr, "  t=%4d blk=%4d simd=%u cu=%u sh=%u se=%u wave=%u\n", i, (int)(hw[i] >> 32), (v >> 4) & 3, (v >> 8) & 15, (v >> 12) & 1, (v >> 13) & 7, v & 15);
-					}
-					free(hw);
-				}
-			}
-			return 0;
-		}
-		if (mic_mode_() >= 1) {
-			FlowState* f;
-			MF_TRY(flow_prepare(d, &f, st, true));
-			f->gen++;
-			if (f->gen == 0) {  // 32-bit wrap: stale tags could alias -> clear once
-				MF_HIP(hipMemsetAsync(f->xch, 0, f->xch_cap, st));
-				f->gen = 1;
-			}
-			static int wgs = -1;
-			if (wgs < 0) {
-				const char* e = getenv("MF_FLOW_WGS");
-				wgs = e ? atoi(e) : 512;   // two single-wave workgroups per CU measured best (256: too few, 1024: contention)
-				if (wgs < 1) wgs = 1;
-			}
-			const int grid = f->ntiles < wgs ? f->ntiles : wgs;
-			if (vec)
-				hipLaunchKernelGGL((k_mic_flow<MODE, true>), dim3(grid), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
-			else
-				hipLaunchKernelGGL((k_mic_flow<MODE, false>), dim3(grid), dim3(64), 0, st, d, nti, ntj, ntk, f->ntiles, f->order, f->ctl, f->xch, f->gen, flags, dst, var1, Ap, Ai, Aj, Ak, sc);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
@@ -2408,8 +1345,7 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 // this mode -- the caller runs its own dot kernel)
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                    const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st) {
-	static const bool off = getenv("MF_MIC_NODOT") != nullptr;
-	g_dot_request = off ? nullptr : dotpart;
+	g_dot_request = dotpart;
 	g_dot_count = 0;
 	const int rc = launch_mic<2>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
 	g_dot_request = nullptr;
@@ -2423,17 +1359,16 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const fl
 	*pack = nullptr;
 	*a0_packed = false;
 	static const bool nopack = getenv("MF_MIC_NOPACK") != nullptr;
-	static const bool noa0 = getenv("MF_AM_NOA0PACK") != nullptr;
-	if (nopack || mic_mode_() != 2 || !d.is3d) return 0;
+	if (nopack || !d.is3d) return 0;
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	FlowState& f = g_flow[dev];
-	if (!f.pack || !f.pack_ok || f.pk_flags != flags || f.pk_Ai != Ai || f.pk_Aj != Aj || f.pk_Ak != Ak) return 0;
+	if (f.mode != 2 || !f.pack || !f.pack_ok || f.pk_flags != flags || f.pk_Ai != Ai || f.pk_Aj != Aj || f.pk_Ak != Ak) return 0;
 	int ok[2] = {0, 0};
 	MF_HIP(hipMemcpyAsync(ok, f.pack_ok, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
 	MF_HIP(hipStreamSynchronize(st));
 	if (ok[0]) *pack = f.pack;
-	*a0_packed = ok[0] && ok[1] && !noa0 && f.pk_A0 == A0 && A0 != nullptr;
+	*a0_packed = ok[0] && ok[1] && f.pk_A0 == A0 && A0 != nullptr;
 	return 0;
 }
 // packed bytes built by mf_pack_matrix for exactly these grids (no synchronisation: the verdict was read when they were built)
@@ -2445,7 +1380,6 @@ const unsigned char* mic_pack_user(const int32_t* flags, const float* Ai, const 
 	return f.upack;
 }
 int mic_flow_error() {
-	if (mic_mode_() < 1) return 0;
 	int dev = 0;
 	MF_HIP(hipGetDevice(&dev));
 	if (!g_flow[dev].ctl) return 0;
@@ -2457,7 +1391,7 @@ int mic_flow_error() {
 	}
 	return 0;
 }
-int mic_mode() { return mic_mode_(); }
+int mic_mode() { return mic_mode_(); }      // the requested mode (0 levels, 2 rows)
 }  // namespace mf
 
 extern "C" {
@@ -2473,85 +1407,59 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 	if (cells_x < 0 || (cells_x % 8) != 0) return fail("mf_mic_init_blocked: cells_x must be a non-negative multiple of 8");
 	const Dim d = mkdim(sx, sy, sz);
 	if (!d.is3d) return fail("mICP only supports 3D grids so far");
-	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, (hipStream_t)stream));
-	// "rows" mode: one dataflow sweep (k_mic_rows_init); MF_MIC_INIT_LEVELS=1 or another mode: one launch per tile hyperplane
-	static const bool init_levels = getenv("MF_MIC_INIT_LEVELS") != nullptr;
-	if (mic_mode_() == 2 && !init_levels) {
-		hipStream_t st = (hipStream_t)stream;
-		FlowState* f;
-		MF_TRY(rows_prepare(d, &f, st, rows_j, cells_x));
-		f->sgen++;
-		if (f->sgen == 0) {
-			MF_HIP(hipMemsetAsync(f->sxj, 0, f->sx_cap, st));
-			MF_HIP(hipMemsetAsync(f->sxk, 0, f->sx_cap, st));
-			MF_HIP(hipMemsetAsync(f->sxj1, 0, f->sx_cap, st));
-			MF_HIP(hipMemsetAsync(f->sxk1, 0, f->sx_cap, st));
-			f->sgen = 1;
-		}
-		int dev = 0, ncu = 256;
-		(void)hipGetDevice(&dev);
-		(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-		const int grid = f->nblocks < ncu ? f->nblocks : ncu;
-		const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(Aprecond) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
-		if (vec)
-			hipLaunchKernelGGL((k_mic_rows_init<true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
-		else
-			hipLaunchKernelGGL((k_mic_rows_init<false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
-		MF_LAUNCH_CHECK();
-	} else {
-		MF_TRY(mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, (hipStream_t)stream));
+	hipStream_t st = (hipStream_t)stream;
+	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, st));
+	const int mode = mic_mode_();
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	g_flow[dev].mode = mode;
+	g_flow[dev].be_flags = nullptr;        // no registered system until this call has built one
+	if (mode != 2) return mic_launch(0, d, flags, Aprecond, A0, nullptr, Ai, Aj, Ak, nullptr, st);   // one launch per tile hyperplane
+	// "rows": one dataflow sweep (k_mic_rows_init)
+	FlowState* f;
+	MF_TRY(rows_prepare(d, &f, st, rows_j, cells_x));
+	MF_TRY(rows_next_gen(f, st));
+	int ncu = 256;
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+	const int grid = f->nblocks < ncu ? f->nblocks : ncu;
+	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(Aprecond) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
+	if (vec)
+		hipLaunchKernelGGL((k_mic_rows_init<true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
+	else
+		hipLaunchKernelGGL((k_mic_rows_init<false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
+	MF_LAUNCH_CHECK();
+	// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
+	f->blk_rows = rows_j;
+	f->blk_cells = cells_x;
+	if (f->nblocks + 1 > f->bempty_cap) {
+		MF_HIP(hipStreamSynchronize(st));
+		if (f->bempty) MF_HIP(hipFree(f->bempty));
+		MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * (f->nblocks + 1)));
+		f->bempty_cap = f->nblocks + 1;
 	}
-	if (mic_mode_() == 2) {
-		// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
-		FlowState* f;
-		MF_TRY(rows_prepare(d, &f, (hipStream_t)stream, rows_j, cells_x));
-		f->blk_rows = rows_j;
-		f->blk_cells = cells_x;
-		f->sys_known = false;
-		if (f->nblocks + 1 > f->bempty_cap) {
-			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
-			if (f->bempty) MF_HIP(hipFree(f->bempty));
-			MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * (f->nblocks + 1)));
-			f->bempty_cap = f->nblocks + 1;
-		}
-		MF_HIP(hipMemsetAsync(f->bempty + f->nbj * f->nbk, 0, sizeof(int), (hipStream_t)stream));
-		hipLaunchKernelGGL(k_bundle_empty, dim3(f->nbj * f->nbk), dim3(BLOCK), 0, (hipStream_t)stream, d, f->nbj, flags, Aj, Ak, f->bempty);
-		MF_LAUNCH_CHECK();
-		f->be_flags = flags;
-		f->be_Ap = Aprecond;
-		f->be_Aj = Aj;
-		f->be_Ak = Ak;
-		// packed operands for the apply sweeps
-		if ((size_t)d.n > f->pack_cap) {
-			MF_HIP(hipStreamSynchronize((hipStream_t)stream));
-			if (f->pack) MF_HIP(hipFree(f->pack));
-			MF_HIP(hipMalloc((void**)&f->pack, (size_t)d.n + 64));
-			f->pack_cap = (size_t)d.n;
-		}
-		if (!f->pack_ok) MF_HIP(hipMalloc((void**)&f->pack_ok, 2 * sizeof(int)));
-		MF_HIP(hipMemsetAsync(f->pack_ok, 1, 2 * sizeof(int), (hipStream_t)stream));     // non-zero = valid until k_mic_pack clears it
-		hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d.n, flags, A0, Ai, Aj, Ak, f->pack, f->pack_ok);
-		f->pk_A0 = A0;
-		MF_LAUNCH_CHECK();
-		f->pk_flags = flags;
-		f->pk_Ai = Ai;
-		f->pk_Aj = Aj;
-		f->pk_Ak = Ak;
-		// coefficient words of the super-bundle sweeps (uncut systems with sx % 8 == 0)
-		f->sb_coef_valid = false;
-		static const bool nosb_init = getenv("MF_MIC_NOSB") != nullptr;
-		if (!nosb_init && mic_sb_() && rows_j == 0 && cells_x == 0 && (d.sx % 8) == 0 && d.sx >= 32) {
-			if ((size_t)d.n > f->sb_coef_cap) {
-				MF_HIP(hipStreamSynchronize((hipStream_t)stream));
-				if (f->sb_coef) MF_HIP(hipFree(f->sb_coef));
-				MF_HIP(hipMalloc((void**)&f->sb_coef, sizeof(unsigned) * ((size_t)d.n + 64)));
-				f->sb_coef_cap = (size_t)d.n;
-			}
-			hipLaunchKernelGGL(k_mic_sbcoef, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream, d.n, flags, Ai, Aj, Ak, f->sb_coef);
-			MF_LAUNCH_CHECK();
-			f->sb_coef_valid = true;
-		}
+	MF_HIP(hipMemsetAsync(f->bempty + f->nbj * f->nbk, 0, sizeof(int), st));
+	hipLaunchKernelGGL(k_bundle_empty, dim3(f->nbj * f->nbk), dim3(BLOCK), 0, st, d, f->nbj, flags, Aj, Ak, f->bempty);
+	MF_LAUNCH_CHECK();
+	f->be_flags = flags;
+	f->be_Ap = Aprecond;
+	f->be_Aj = Aj;
+	f->be_Ak = Ak;
+	// packed operands for the apply sweeps
+	if ((size_t)d.n > f->pack_cap) {
+		MF_HIP(hipStreamSynchronize(st));
+		if (f->pack) MF_HIP(hipFree(f->pack));
+		MF_HIP(hipMalloc((void**)&f->pack, (size_t)d.n + 64));
+		f->pack_cap = (size_t)d.n;
 	}
+	if (!f->pack_ok) MF_HIP(hipMalloc((void**)&f->pack_ok, 2 * sizeof(int)));
+	MF_HIP(hipMemsetAsync(f->pack_ok, 1, 2 * sizeof(int), st));     // non-zero = valid until k_mic_pack clears it
+	hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, flags, A0, Ai, Aj, Ak, f->pack, f->pack_ok);
+	MF_LAUNCH_CHECK();
+	f->pk_A0 = A0;
+	f->pk_flags = flags;
+	f->pk_Ai = Ai;
+	f->pk_Aj = Aj;
+	f->pk_Ak = Ak;
 	return 0;
 }
 int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,

@@ -294,6 +294,7 @@ extern "C" {
 
 const char* mf_last_error(void) { return mf::g_err; }
 const char* mf_backend(void) { return "hip"; }
+int mf_abi_version(void) { return MF_ABI_VERSION; }
 int mf_set_slab_window(int zoff, int gsz) {
 	if (gsz < 0 || zoff < 0 || (gsz > 0 && zoff >= gsz)) return fail("invalid slab window %d / %d", zoff, gsz);
 	mf::g_slab_zoff = zoff;

@@ -31,6 +31,7 @@ static int fail(const char* msg) {
 }
 const char* mf_last_error(void) { return g_err; }
 const char* mf_backend(void) { return "oracle"; }
+int mf_abi_version(void) { return MF_ABI_VERSION; }
 
 typedef struct {
 	int sx, sy, sz;

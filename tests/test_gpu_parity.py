@@ -133,13 +133,14 @@ def test_mic_apply_signed_zeros_negative_and_huge_operands(hip, oracle, dims):
         (got[~nan_w].view(np.uint32) != want[~nan_w].view(np.uint32)).sum())
 
 
-@pytest.mark.parametrize("mode", ["rows", "rows-sb", "tiles", "levels"])
+@pytest.mark.parametrize("mode", ["rows", "levels"])
 @pytest.mark.parametrize("dims", [(32, 24, 40), (37, 21, 19), (64, 64, 64), (24, 40, 9), (16, 8, 136), (40, 33, 27), (128, 40, 24), (32, 8, 8),
                                   (96, 72, 17)])
 def test_mic_every_sweep_mode(hip, oracle, dims, mode):
     """the ways the MIC sweeps are parallelised (mf_set_mic_mode) give the serial sweep's bits, and a CG solve takes the same
-    number of iterations in each.  "rows-sb" runs the super-bundle form (2 x 2 bundles of rows per workgroup, inner faces through
-    LDS) where sx % 8 == 0 and sx >= 32: odd bundle counts, rows outside the grid and a single bundle are among the sizes."""
+    number of iterations in each: odd bundle counts, rows outside the grid and a single bundle are among the sizes.  The mode is
+    taken at mf_mic_init and stays with the system it registers (an unknown name is refused)."""
+    assert hip.lib.cdll.mf_set_mic_mode(b"tiles") != 0
     flags, A, src = cases.system_inputs(dims, 3)
     rhs = cases.cg_rhs(dims, flags, 3)
     ap_o, dst_o = cases.run_mic_impl(oracle, dims, flags, A, src)
@@ -154,6 +155,36 @@ def test_mic_every_sweep_mode(hip, oracle, dims, mode):
     assert_bitexact(dst, dst_o, "mic apply " + mode)
     assert st[0] == sto[0], (mode, st, sto)
     _close(x, xo, "cg solution " + mode)
+
+
+@pytest.mark.parametrize("a0", [15.0, 16.0, 2.5, -0.0, 0.0])
+def test_apply_matrix_packed_diagonal_nibble(hip, oracle, a0):
+    """ApplyMatrix inside the PCG reads the diagonal from bits 4-7 of the packed byte when every fluid cell's A0 is a small
+    non-negative integer (k_mic_pack's ok[1], bit patterns compared).  Systems whose A0 holds 15 (largest code), 16, 2.5 or -0.0 in
+    some fluid cells: whichever form is taken (nibble, or the A0 array where the nibble would not be exact), the result has the
+    bits of the reference expression -- signed zeros included."""
+    dims = (32, 24, 16)
+    sx, sy, sz = dims
+    flags, A, src = cases.system_inputs(dims, 9)
+    A = [a.copy() for a in A]
+    fluid = np.argwhere((flags & util.FLUID) != 0)
+    rng = np.random.default_rng(31)
+    for k, j, i in fluid[rng.choice(len(fluid), 40, replace=False)]:
+        A[0][k, j, i] = np.float32(a0)
+    src = src.copy()
+    src[rng.random(src.shape) < 0.3] = 0.0          # zero sums, so that the sign of a rebuilt zero diagonal would show
+    src[rng.random(src.shape) < 0.2] = -0.0
+    want = cases.run_apply_matrix_impl(oracle, dims, flags, A, src)
+    f, s_, dA = hip.dev(flags), hip.dev(src), [hip.dev(a) for a in A]
+    ap = hip.dev(np.zeros((sz, sy, sx), np.float32))
+    dst = hip.dev(np.full((sz, sy, sx), 7.0, np.float32))
+    hip.call("mf_mic_init", sx, sy, sz, f, ap, *dA, None)
+    us = ctypes.c_double()
+    hip.call("mf_time_apply_matrix_packed", sx, sy, sz, f, dst, s_, *dA, 1, ctypes.byref(us), None)
+    hip.sync()
+    got = hip.host(dst)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "packed ApplyMatrix differs in %d cells (A0 = %r)" % (
+        (got.view(np.uint32) != want.view(np.uint32)).sum(), a0)
 
 
 @pytest.mark.parametrize("dims", [(32, 24, 40), (64, 48, 24), (36, 20, 17)])
