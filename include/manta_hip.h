@@ -53,7 +53,8 @@ const char* mf_backend(void);
  *   1  round 1
  *   2  round 2: mf_semi_lagrange_{real,vec3,mac}, mf_interpolate_grid, mf_interpolate_mac_grid take `int orderSpace` before `stream`;
  *      mf_apply_noise_vec3 takes four uv arguments; mf_set_mic_blocking / mf_set_mic_blocking_x replaced by mf_mic_init_blocked
- *   3  round 3: mf_abi_version itself; mf_set_mic_mode knows "rows" and "levels" only */
+ *   3  round 3: mf_abi_version itself; mf_set_mic_mode knows "rows" and "levels" only; mf_cg_slab_after_dp / _after_zr: the pressure
+ *      update moved from the former to the latter (arguments changed) */
 #define MF_ABI_VERSION 3
 int mf_abi_version(void);
 
@@ -469,16 +470,20 @@ int mf_grid_scaled_add_dev(int64_t n, float* me, const float* other, const float
 int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const float* factor_dev, void* stream);
 /* The z-slab PCG iteration has three stretches of device work between its communication points (halo exchange of `search`, gather of
  * dot(A search, search), gather of {max|r|, dot(z, r)}).  These two entry points queue the second and the third stretch with ONE
- * call each instead of three and two -- same kernels, same order; the host loop of a rank is per-iteration latency at N > 1:
- *   mf_cg_slab_after_dp  : mf_cg_slab_alpha ; mf_cg_slab_axpy2 over the owned cells ; mf_mic_apply_dot_dev  (tmp = M^-1 residual)
- *   mf_cg_slab_after_zr  : mf_cg_slab_beta ; mf_update_search_vec_dev over the owned cells
+ * call each; the host loop of a rank is per-iteration latency at N > 1.  As in mf_cg_solve, `x += alpha * search` rides on the search
+ * update (`search` is read once for both; revision 3 of the ABI -- before, mf_cg_slab_after_dp updated x):
+ *   mf_cg_slab_after_dp  : alpha from the gathered rows (0 once the stop state is set) ; residual += nalpha * tmp over the owned cells
+ *                          with maxabs_dev[0] = max |residual| ; mf_mic_apply_dot_dev (tmp = M^-1 residual, dot_dev[0] = dot(tmp, residual))
+ *   mf_cg_slab_after_zr  : beta and the stopping test from the gathered rows ; x += alpha * search over the owned cells (this iteration's
+ *                          update, also when the iteration is the one that converged) ; unless stopped, search = tmp + beta * search
+ * `scalars`: the block described above plus int32 xpending at word 12 (16 words, zero-initialised by the caller).
  * `own_off` / `n_own`: first owned cell and number of owned cells of the slab's grids (ghost planes excluded). */
 int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
-                        float* x, const float* search, float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
+                        float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
                         const int32_t* flags, const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
                         void* stream);
 int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float accuracy, int iter, int32_t* state_dev, int64_t own_off,
-                        int64_t n_own, float* search, const float* tmp, void* stream);
+                        int64_t n_own, float* x, float* search, const float* tmp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HIP-only helpers (return an error in the CPU libraries)

@@ -859,7 +859,78 @@ k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restr
 	}
 }
 
+// the same for views that do not start on a 16-byte boundary
+__global__ void __launch_bounds__(BLOCK)
+k_cg_update_search_x_scalar(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp) {
+	if (!sc->xpending) return;
+	const bool upd = !sc->done;
+	const float alpha = sc->alpha, beta = sc->beta;
+	for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+		const float s = search[i];
+		dst[i] = dst[i] + alpha * s;
+		if (upd) search[i] = tmp[i] + beta * s;
+	}
+}
+// z-slab PCG scalar steps on the gathered per-rank reductions g[world][2] = {max|residual|, dot} (rows combined in rank order: the
+// same bits on every rank; conjugategrad.cpp:250-291), on a CgScalars block: `done` mirrors the stop state, `xpending` says that this
+// iteration's x += alpha * search is still to be done by the search update
+__global__ void k_slab_alpha_x(const double* __restrict__ g, int world, CgScalars* __restrict__ sc, const int32_t* __restrict__ state) {
+	if (state && state[0]) {
+		sc->alpha = 0.f;
+		sc->nalpha = -0.f;
+		sc->xpending = 0;
+		sc->done = 1;
+		return;
+	}
+	double acc = 0.0;
+	for (int r = 0; r < world; r++) acc += g[2 * r + 1];
+	const float dp = (float)acc;
+	const float a = (fabs((double)dp) > 0.) ? sc->sigma / dp : 0.f;
+	sc->alpha = a;
+	sc->nalpha = -a;
+	sc->xpending = 1;
+	sc->done = 0;
+}
+__global__ void k_slab_beta_x(const double* __restrict__ g, int world, CgScalars* __restrict__ sc, float accuracy, int iter, int32_t* __restrict__ state) {
+	if (state && state[0]) return;
+	double acc = 0.0, mx = 0.0;
+	for (int r = 0; r < world; r++) {
+		acc += g[2 * r + 1];
+		mx = g[2 * r] > mx ? g[2 * r] : mx;
+	}
+	const float sigmaNew = (float)acc;
+	const float rn = (float)mx;
+	sc->resNorm = rn;
+	sc->beta = sigmaNew / sc->sigma;
+	sc->sigma = sigmaNew;
+	if (state) {
+		if (rn < accuracy) {
+			state[0] = 1;
+			state[1] = iter;
+			sc->done = 1;
+		} else if (!(rn < 1e35f)) {
+			state[0] = 2;
+			state[1] = iter;
+			sc->done = 1;
+		}
+	}
+}
+
 // one-block finishers of the slab entry points
+__global__ void __launch_bounds__(BLOCK) k_fin_maxabs_live(int nb, const float* __restrict__ fpart, double* __restrict__ out, const CgScalars* __restrict__ sc) {
+	if (sc->done) return;
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+		lo = fminf(lo, fpart[2 * i]);
+		hi = fmaxf(hi, fpart[2 * i + 1]);
+	}
+	block_minmax(lo, hi);
+	if (threadIdx.x == 0) {
+		lo = fabsf(lo);
+		hi = fabsf(hi);
+		out[0] = (double)(lo > hi ? lo : hi);
+	}
+}
 __global__ void __launch_bounds__(BLOCK) k_fin_sum(int nb, const double* __restrict__ partials, double* __restrict__ out) {
 	double acc = strided_sum(partials, nb);
 	acc = block_sum(acc);
@@ -1240,21 +1311,49 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 
 
 // the stretches of a z-slab PCG iteration between two communication points, queued with one call each (CgScalars layout: sigma,
-// alpha, nalpha, beta, resNorm at floats 0, 1, 2, 3, 4)
+// alpha, nalpha, beta, resNorm at floats 0, 1, 2, 3, 4); x += alpha * search rides on the search update as in mf_cg_solve
 int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
-                        float* x, const float* search, float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
+                        float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
                         const int32_t* flags, const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
                         void* stream) {
-	float* sc = (float*)scalars;
-	MF_TRY(mf_cg_slab_alpha(gathered, world, sc + 0, sc + 1, state_dev, stream));
-	MF_TRY(mf_cg_slab_axpy2(n_own, scalars, x + own_off, search + own_off, residual + own_off, tmp + own_off, maxabs_dev, stream));
+	hipStream_t st = (hipStream_t)stream;
+	CgScalars* sc = (CgScalars*)scalars;
+	hipLaunchKernelGGL(k_slab_alpha_x, dim3(1), dim3(1), 0, st, gathered, world, sc, state_dev);
+	float* r = residual + own_off;
+	float* t = tmp + own_off;
+	if (n_own > 0) {
+		if (al16(r) && al16(t)) {
+			Workspace* ws;
+			MF_TRY(get_workspace(&ws));
+			const int nb = blocks_for(n_own >> 2, BLOCK, 2048);
+			hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nb), dim3(BLOCK), 0, st, n_own, sc, r, t, ws->fpartials, ws->partials + MAX_BLOCKS);
+			hipLaunchKernelGGL(k_fin_maxabs_live, dim3(1), dim3(BLOCK), 0, st, nb, ws->fpartials, maxabs_dev, sc);
+			MF_LAUNCH_CHECK();
+		} else {
+			// views that do not start on a 16-byte boundary (odd plane sizes): the unfused sequence (alpha is 0 once stopped)
+			MF_TRY(mf_grid_scaled_add_dev(n_own, r, t, &sc->alpha, -1.f, stream));
+			MF_TRY(mf_grid_max_abs_dev_f64(n_own, r, maxabs_dev, stream));
+		}
+	}
 	return mf_mic_apply_dot_dev(sx, sy, sz, flags, tmp, residual, Aprecond, Ai, Aj, Ak, dot_dev, stream);
 }
 int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float accuracy, int iter, int32_t* state_dev, int64_t own_off,
-                        int64_t n_own, float* search, const float* tmp, void* stream) {
-	float* sc = (float*)scalars;
-	MF_TRY(mf_cg_slab_beta(gathered, world, sc + 0, sc + 3, sc + 4, accuracy, iter, state_dev, stream));
-	return mf_update_search_vec_dev(n_own, search + own_off, tmp + own_off, sc + 3, stream);
+                        int64_t n_own, float* x, float* search, const float* tmp, void* stream) {
+	hipStream_t st = (hipStream_t)stream;
+	CgScalars* sc = (CgScalars*)scalars;
+	hipLaunchKernelGGL(k_slab_beta_x, dim3(1), dim3(1), 0, st, gathered, world, sc, accuracy, iter, state_dev);
+	if (n_own <= 0) return 0;
+	float* xs = x + own_off;
+	float* s = search + own_off;
+	const float* t = tmp + own_off;
+	if (al16(xs) && al16(s) && al16(t)) {
+		hipLaunchKernelGGL(k_cg_update_search_x, dim3(blocks_for(n_own >> 2, BLOCK, 2048)), dim3(BLOCK), 0, st, n_own, sc, xs, s, t);
+		MF_LAUNCH_CHECK();
+		return 0;
+	}
+	hipLaunchKernelGGL(k_cg_update_search_x_scalar, dim3(blocks_for(n_own, BLOCK, 2048)), dim3(BLOCK), 0, st, n_own, sc, xs, s, t);
+	MF_LAUNCH_CHECK();
+	return 0;
 }
 
 }  // extern "C"

@@ -243,6 +243,17 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     if phi is not None:
         # ApplyGhostFluidDiagonal (pressure.cpp:136-151): the diagonal of a fluid cell next to an empty one, from phi of the two
         lib.call("mf_apply_ghost_fluid_diagonal", sx, sy, sz, A0.ptr, flags.ptr, phi.ptr, float(gfClamp), st)
+    # The PCG runs on a WINDOW of the local grid: the owned planes plus ONE ghost plane per interior face (ApplyMatrix reads search at
+    # +-1 plane; everything else is local).  The advection ghosts beyond (G = 6 at max|v| dt = 2: 44 planes for 32 owned ones at
+    # 8 ranks) would only be swept and streamed for nothing.  Slabs are z-contiguous, so the window is a pointer offset.
+    w0, w1 = max(dom.gl - 1, 0), min(dom.gl + dom.nown + 1, sz)
+    wz, wgl = w1 - w0, dom.gl - w0                      # planes of the window, ghost planes below the owned ones inside it (0 or 1)
+    woff = w0 * XY                                       # first cell of the window in the local grids
+    off_w = wgl * XY                                     # first owned cell inside the window
+
+    def W(g):
+        return _off(g.data, woff)
+
     # slab-local MIC: ghost planes are not part of the block, the coupling across the slab faces is cut
     fmic = core.FlagGrid(s)
     fmic.copyFrom(flags)
@@ -255,7 +266,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     # (nothing there is needed; the outermost ghost plane has no neighbour plane to read, and the fused dot products below
     # multiply those values with the zero residual of the ghost planes), the owned planes are unaffected (the stencil never
     # looks at a neighbour's flags)
-    lib.call("mf_pack_matrix", sx, sy, sz, fmic.ptr, Ai.ptr, Aj.ptr, Ak.ptr, st)       # 13 instead of 28 B per cell
+    lib.call("mf_pack_matrix", sx, sy, wz, W(fmic), W(Ai), W(Aj), W(Ak), st)       # 13 instead of 28 B per cell
     Akm.copyFrom(Ak)
     av = Akm.data.view(sz, XY)
     if dom.gl:
@@ -295,9 +306,9 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     dev = s.device
     world = dom.comm.world
     red = torch.zeros(2, dtype=torch.float64, device=dev)     # {max|residual|, dot} of this rank
-    # the scalar block of include/manta_hip.h (CgScalars layout): sigma, alpha, nalpha, beta, resNorm, ... (fp32 like the
+    # the scalar block of include/manta_hip.h (CgScalars layout): sigma, alpha, nalpha, beta, resNorm, ... xpending (fp32 like the
     # reference's Real members)
-    sc = torch.zeros(12, dtype=torch.float32, device=dev)
+    sc = torch.zeros(16, dtype=torch.float32, device=dev)
     p_sc = ctypes.c_void_p(sc.data_ptr())
     p_sigma, p_alpha, p_beta, p_res = (ctypes.c_void_p(sc.data_ptr() + 4 * i) for i in (0, 1, 3, 4))
     p_red0, p_red1 = ctypes.c_void_p(red.data_ptr()), ctypes.c_void_p(red.data_ptr() + 8)
@@ -306,15 +317,15 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         lib.call("mf_grid_dot_dev", nown, _off(a.data, off), _off(b.data, off), p_red1, st)
 
     def mic(dst, src):
-        lib.call("mf_mic_apply", sx, sy, sz, fmic.ptr, dst.ptr, src.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, st)
+        lib.call("mf_mic_apply", sx, sy, wz, W(fmic), W(dst), W(src), W(Ap), W(Aim), W(Ajm), W(Akm), st)
 
     # All scalars stay on the device (fp32 like the reference's Real members); each reduction point is ONE all-gather whose
-    # rows are combined in rank order by a one-thread kernel; the host reads one number per iteration (the stopping test).
+    # rows are combined in rank order by a one-thread kernel; the host reads one number per STOP_POLL iterations (the stopping test).
     # doInit, conjugategrad.cpp:210-235
     pressure.clear()
     residual.copyFrom(rhs)
     # the y / x blocking travels with this system (flags / Aprecond / Aj / Ak pointers), not with the process
-    lib.call("mf_mic_init_blocked", sx, sy, sz, fmic.ptr, Ap.ptr, A0.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, jblock, xblock, st)
+    lib.call("mf_mic_init_blocked", sx, sy, wz, W(fmic), W(Ap), W(A0), W(Aim), W(Ajm), W(Akm), jblock, xblock, st)
     mic(tmp, residual)
     search.copyFrom(tmp)
     dot_own(tmp, residual)
@@ -322,8 +333,8 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     g0 = dom.comm.allgather_dev(red)          # (kept referenced until the kernel that reads it has been queued behind it)
     lib.call("mf_cg_slab_beta", _ptr(g0), world, p_sigma, p_beta, p_res, 0.0, 0, None, st)
     # The stopping test runs on the device (state = {stop, iteration}); the host looks at it every STOP_POLL iterations.
-    # Iterations queued past the stop are no-ops for pressure and residual (alpha = 0), so the result is the one the
-    # reference stops with, and the host never drains the stream inside the loop.
+    # Iterations queued past the stop are no-ops for pressure and residual (alpha = 0, no pending update), so the result is the
+    # one the reference stops with, and the host never drains the stream inside the loop.
     state = torch.zeros(2, dtype=torch.int32, device=dev)
     p_state = ctypes.c_void_p(state.data_ptr())
     acc32 = float(np.float32(cgAccuracy))
@@ -331,17 +342,17 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     iters, resNorm, stop = 0, 1e20, 0
     for it in range(1, maxIter + 1):
         dom.exchange(search, 1)
-        # tmp = A search with dot(tmp, search) over the owned planes fused in; x += alpha search, r -= alpha tmp with max|r| fused in
-        lib.call("mf_apply_matrix_dot_dev", sx, sy, sz, fmic.ptr, tmp.ptr, search.ptr, A0.ptr, Ai.ptr, Aj.ptr, Ak.ptr,
-                 dom.gl, dom.gl + dom.nown, p_sc, p_red1, st)
+        # tmp = A search with dot(tmp, search) over the owned planes fused in
+        lib.call("mf_apply_matrix_dot_dev", sx, sy, wz, W(fmic), W(tmp), W(search), W(A0), W(Ai), W(Aj), W(Ak),
+                 wgl, wgl + dom.nown, p_sc, p_red1, st)
         g1 = dom.comm.allgather_dev(red)
-        # alpha (conjugategrad.cpp:252-254); x += alpha search, r -= alpha tmp with max|r| fused in; tmp = M^-1 r with dot(tmp, r) fused
-        # in (the residual is zero on the ghost planes: the sum is the owned one) -- one call for the stretch up to the next gather
-        lib.call("mf_cg_slab_after_dp", _ptr(g1), world, p_sc, p_state, off, nown, pressure.ptr, search.ptr, residual.ptr, tmp.ptr, p_red0,
-                 sx, sy, sz, fmic.ptr, Ap.ptr, Aim.ptr, Ajm.ptr, Akm.ptr, p_red1, st)
+        # alpha (conjugategrad.cpp:252-254); r -= alpha tmp with max|r| fused in; tmp = M^-1 r with dot(tmp, r) fused in (the residual
+        # is zero on the ghost planes: the sum is the owned one) -- one call for the stretch up to the next gather
+        lib.call("mf_cg_slab_after_dp", _ptr(g1), world, p_sc, p_state, off_w, nown, W(residual), W(tmp), p_red0,
+                 sx, sy, wz, W(fmic), W(Ap), W(Aim), W(Ajm), W(Akm), p_red1, st)
         g2 = dom.comm.allgather_dev(red)
-        # beta + stopping test on the device, search = tmp + beta search
-        lib.call("mf_cg_slab_after_zr", _ptr(g2), world, p_sc, acc32, it, p_state, off, nown, search.ptr, tmp.ptr, st)
+        # beta + stopping test on the device; x += alpha search and search = tmp + beta search in one pass over `search`
+        lib.call("mf_cg_slab_after_zr", _ptr(g2), world, p_sc, acc32, it, p_state, off_w, nown, W(pressure), W(search), W(tmp), st)
         keep.append((g1, g2))                                     # gathered rows stay alive until the stream has consumed them
         if it % STOP_POLL == 0 or it == maxIter:
             stop, at = (int(v) for v in state.tolist())           # the one host read per STOP_POLL iterations

@@ -3042,22 +3042,50 @@ int mf_time_apply_matrix_packed(int sx, int sy, int sz, const int32_t* flags, fl
 	return fail("mf_time_apply_matrix_packed: HIP only");
 }
 
-/* the two composite stretches of the z-slab PCG iteration (same calls in the same order as the HIP library) */
+/* the two composite stretches of the z-slab PCG iteration (same arithmetic in the same order as the HIP library): as in
+ * GridCg::iterate (conjugategrad.cpp:250-291), with `x += alpha * search` (:254) deferred to the search update (:283) -- nothing in
+ * between reads x.  scalars = {sigma, alpha, nalpha, beta, resNorm, ..., word 12: xpending} */
 int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
-                        float* x, const float* search, float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
+                        float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
                         const int32_t* flags, const float* Aprecond, const float* Ai, const float* Aj, const float* Ak, double* dot_dev,
                         void* st) {
 	float* sc = (float*)scalars;
 	int rc = mf_cg_slab_alpha(gathered, world, sc + 0, sc + 1, state_dev, st);
 	if (rc) return rc;
-	rc = mf_cg_slab_axpy2(n_own, scalars, x + own_off, search + own_off, residual + own_off, tmp + own_off, maxabs_dev, st);
-	if (rc) return rc;
+	const int stopped = state_dev && state_dev[0];
+	((int32_t*)scalars)[12] = stopped ? 0 : 1;
+	if (!stopped) {
+		const float nalpha = sc[2];
+		float* r = residual + own_off;
+		const float* t = tmp + own_off;
+		float lo = 3.402823466e38f, hi = -3.402823466e38f;
+		for (int64_t i = 0; i < n_own; i++) {
+			const float v = r[i] + nalpha * t[i];
+			r[i] = v;
+			lo = v < lo ? v : lo;
+			hi = v > hi ? v : hi;
+		}
+		lo = fabsf(lo);
+		hi = fabsf(hi);
+		maxabs_dev[0] = n_own > 0 ? (double)(lo > hi ? lo : hi) : 0.0;
+	}
 	return mf_mic_apply_dot_dev(sx, sy, sz, flags, tmp, residual, Aprecond, Ai, Aj, Ak, dot_dev, st);
 }
 int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float accuracy, int iter, int32_t* state_dev, int64_t own_off,
-                        int64_t n_own, float* search, const float* tmp, void* st) {
+                        int64_t n_own, float* x, float* search, const float* tmp, void* st) {
 	float* sc = (float*)scalars;
 	int rc = mf_cg_slab_beta(gathered, world, sc + 0, sc + 3, sc + 4, accuracy, iter, state_dev, st);
 	if (rc) return rc;
-	return mf_update_search_vec_dev(n_own, search + own_off, tmp + own_off, sc + 3, st);
+	if (!((int32_t*)scalars)[12]) return 0;
+	const int stopped = state_dev && state_dev[0];
+	const float alpha = sc[1], beta = sc[3];
+	float* xs = x + own_off;
+	float* s = search + own_off;
+	const float* t = tmp + own_off;
+	for (int64_t i = 0; i < n_own; i++) {
+		const float sv = s[i];
+		xs[i] = xs[i] + alpha * sv;
+		if (!stopped) s[i] = t[i] + beta * sv;
+	}
+	return 0;
 }
