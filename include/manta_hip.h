@@ -54,7 +54,7 @@ const char* mf_backend(void);
  *   2  round 2: mf_semi_lagrange_{real,vec3,mac}, mf_interpolate_grid, mf_interpolate_mac_grid take `int orderSpace` before `stream`;
  *      mf_apply_noise_vec3 takes four uv arguments; mf_set_mic_blocking / mf_set_mic_blocking_x replaced by mf_mic_init_blocked
  *   3  round 3: mf_abi_version itself; mf_set_mic_mode knows "rows" and "levels" only; mf_cg_slab_after_dp / _after_zr: the pressure
- *      update moved from the former to the latter (arguments changed) */
+ *      update moved from the former to the latter (arguments changed); mf_pack_matrix takes A0 */
 #define MF_ABI_VERSION 3
 int mf_abi_version(void);
 
@@ -120,9 +120,11 @@ int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, co
                     const float* A0, const float* Ai, const float* Aj, const float* Ak, void* stream);
 /* Optional accelerator for repeated mf_apply_matrix calls on one matrix: packs flags + Ai + Aj + Ak into one byte per cell
  * (valid only if every off-diagonal is exactly +0 or -1, checked here; one stream synchronisation).  Later mf_apply_matrix
- * calls with exactly these pointers read 13 instead of 28 B per cell; results are bit-identical.  The grids must not change
+ * calls with exactly these pointers read 13 instead of 28 B per cell; results are bit-identical.  With A0 (nullable; revision 3)
+ * the diagonal travels in the same byte when every fluid cell's A0 is a small non-negative integer (MakeLaplaceMatrix's count of
+ * non-obstacle neighbours; bit patterns compared) -- 9 B per cell for calls that pass this A0.  The grids must not change
  * while the packed bytes are in use; a new call replaces them. */
-int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak,
+int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak,
                    void* stream);
 /* MakeLaplaceMatrix, conjugategrad.h:154-187.  A0..Ak must be zeroed by the caller (fresh temp grids).
  * fractions: nullable SoA MAC grid. */

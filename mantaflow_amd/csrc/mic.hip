@@ -1142,7 +1142,7 @@ struct FlowState {
 	int* upack_ok = nullptr;
 	size_t upack_cap = 0;
 	int upack_ok_host = 0;
-	const void *up_flags = nullptr, *up_Ai = nullptr, *up_Aj = nullptr, *up_Ak = nullptr;
+	const void *up_flags = nullptr, *up_Ai = nullptr, *up_Aj = nullptr, *up_Ak = nullptr, *up_A0 = nullptr;
 	unsigned long long *sxj = nullptr, *sxk = nullptr;
 	unsigned long long *sxj1 = nullptr, *sxk1 = nullptr;      // second hand-off value of the init sweep (k_mic_rows_init)
 	size_t sx_cap = 0;
@@ -1247,7 +1247,7 @@ static int mic_mode_() {
 	}
 	return g_mic_mode;
 }
-extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, void* stream) {
+extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	int dev = 0;
@@ -1264,12 +1264,13 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 	}
 	if (!f.upack_ok) MF_HIP(hipMalloc((void**)&f.upack_ok, 2 * sizeof(int)));
 	MF_HIP(hipMemsetAsync(f.upack_ok, 1, 2 * sizeof(int), st));
-	hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, flags, (const float*)nullptr, Ai, Aj, Ak, f.upack, f.upack_ok);
+	hipLaunchKernelGGL(k_mic_pack, dim3((unsigned)((d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, flags, A0, Ai, Aj, Ak, f.upack, f.upack_ok);
 	MF_LAUNCH_CHECK();
-	int ok = 0;
-	MF_HIP(hipMemcpyAsync(&ok, f.upack_ok, sizeof(int), hipMemcpyDeviceToHost, st));
+	int ok[2] = {0, 0};
+	MF_HIP(hipMemcpyAsync(ok, f.upack_ok, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
 	MF_HIP(hipStreamSynchronize(st));
-	f.upack_ok_host = ok != 0;
+	f.upack_ok_host = ok[0] != 0;
+	f.up_A0 = (ok[0] && ok[1] && A0) ? A0 : nullptr;      // the diagonal this set of bytes carries in bits 4-7, if any
 	f.up_flags = flags;
 	f.up_Ai = Ai;
 	f.up_Aj = Aj;
@@ -1372,11 +1373,13 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const fl
 	return 0;
 }
 // packed bytes built by mf_pack_matrix for exactly these grids (no synchronisation: the verdict was read when they were built)
-const unsigned char* mic_pack_user(const int32_t* flags, const float* Ai, const float* Aj, const float* Ak) {
+const unsigned char* mic_pack_user(const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak, bool* a0_packed) {
+	*a0_packed = false;
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return nullptr;
 	FlowState& f = g_flow[dev];
 	if (!f.upack || !f.upack_ok_host || f.up_flags != flags || f.up_Ai != Ai || f.up_Aj != Aj || f.up_Ak != Ak) return nullptr;
+	*a0_packed = f.up_A0 != nullptr && f.up_A0 == A0;
 	return f.upack;
 }
 int mic_flow_error() {

@@ -23,8 +23,8 @@ int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* 
 // synchronises the stream once.  *a0_packed: bits 4-7 of every byte hold the (small integer) diagonal A0 of these grids as well
 int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak,
                    const unsigned char** pack, bool* a0_packed, hipStream_t st);
-// packed bytes built by mf_pack_matrix for exactly these grids, or nullptr (no synchronisation)
-const unsigned char* mic_pack_user(const int32_t* flags, const float* Ai, const float* Aj, const float* Ak);
+// packed bytes built by mf_pack_matrix for exactly these grids, or nullptr (no synchronisation); *a0_packed: they carry this A0
+const unsigned char* mic_pack_user(const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak, bool* a0_packed);
 int mic_mode();          // 0 levels, 1 tiles, 2 rows
 int mic_flow_error();    // reads (and clears) the deadlock-guard flag of the single-launch sweeps; needs a synchronised stream
 }  // namespace mf

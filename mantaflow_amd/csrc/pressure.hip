@@ -998,7 +998,9 @@ int mf_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, co
                     const float* Ai, const float* Aj, const float* Ak, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
-	return launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, (hipStream_t)stream, nullptr, mic_pack_user(flags, Ai, Aj, Ak));
+	bool a0p = false;
+	const unsigned char* pk = mic_pack_user(flags, A0, Ai, Aj, Ak, &a0p);
+	return launch_apply_matrix<false>(d, flags, dst, src, A0, Ai, Aj, Ak, nullptr, nullptr, (hipStream_t)stream, nullptr, pk, 0, 0x7fffffff, nullptr, a0p);
 }
 
 static int time_apply_matrix(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* src, const float* A0,
@@ -1120,7 +1122,9 @@ int mf_apply_matrix_dot_dev(int sx, int sy, int sz, const int32_t* flags, float*
 	const CgScalars* sc = (const CgScalars*)scalars;
 	int nb = 0;
 	bool ranged = false;
-	MF_TRY(launch_apply_matrix<true>(d, flags, dst, src, A0, Ai, Aj, Ak, ws->partials, sc, st, &nb, mic_pack_user(flags, Ai, Aj, Ak), k0, k1, &ranged));
+	bool a0p = false;
+	const unsigned char* pk = mic_pack_user(flags, A0, Ai, Aj, Ak, &a0p);
+	MF_TRY(launch_apply_matrix<true>(d, flags, dst, src, A0, Ai, Aj, Ak, ws->partials, sc, st, &nb, pk, k0, k1, &ranged, a0p));
 	if (!ranged) {
 		// the fallback kernels sum over the whole grid: redo the dot over the requested planes
 		const int64_t XY = (int64_t)sx * sy, n = (int64_t)(k1 - k0) * XY;

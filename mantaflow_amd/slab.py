@@ -266,7 +266,7 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     # (nothing there is needed; the outermost ghost plane has no neighbour plane to read, and the fused dot products below
     # multiply those values with the zero residual of the ghost planes), the owned planes are unaffected (the stencil never
     # looks at a neighbour's flags)
-    lib.call("mf_pack_matrix", sx, sy, wz, W(fmic), W(Ai), W(Aj), W(Ak), st)       # 13 instead of 28 B per cell
+    lib.call("mf_pack_matrix", sx, sy, wz, W(fmic), W(A0), W(Ai), W(Aj), W(Ak), st)       # 9 (13 with a ghost-fluid diagonal) instead of 28 B per cell
     Akm.copyFrom(Ak)
     av = Akm.data.view(sz, XY)
     if dom.gl:
@@ -340,6 +340,12 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
     acc32 = float(np.float32(cgAccuracy))
     keep = []
     iters, resNorm, stop = 0, 1e20, 0
+    # the host looks at the stop state one batch of STOP_POLL iterations BEHIND what it has queued (pinned copies + events), so the
+    # stream never runs dry while Python queues the next batch; iterations queued past the stop are no-ops
+    on_gpu = state.is_cuda
+    hstate = [torch.zeros(2, dtype=torch.int32).pin_memory() if on_gpu else None for _ in range(2)]
+    hev = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
+    slot, pending = 0, -1
     for it in range(1, maxIter + 1):
         dom.exchange(search, 1)
         # tmp = A search with dot(tmp, search) over the owned planes fused in
@@ -353,14 +359,29 @@ def solvePressure(dom, vel, pressure, flags, cgAccuracy=1e-3, cgMaxIterFac=1.5, 
         g2 = dom.comm.allgather_dev(red)
         # beta + stopping test on the device; x += alpha search and search = tmp + beta search in one pass over `search`
         lib.call("mf_cg_slab_after_zr", _ptr(g2), world, p_sc, acc32, it, p_state, off_w, nown, W(pressure), W(search), W(tmp), st)
-        keep.append((g1, g2))                                     # gathered rows stay alive until the stream has consumed them
+        keep.append(g1)                                           # gathered rows stay alive until the stream has consumed them
+        keep.append(g2)
         if it % STOP_POLL == 0 or it == maxIter:
-            stop, at = (int(v) for v in state.tolist())           # the one host read per STOP_POLL iterations
-            keep.clear()
+            if not on_gpu or it == maxIter:
+                stop, at = (int(v) for v in state.tolist())
+                keep.clear()
+            else:
+                hstate[slot].copy_(state, non_blocking=True)
+                hev[slot].record()
+                stop, at = 0, 0
+                if pending >= 0:
+                    hev[pending].synchronize()
+                    stop, at = (int(v) for v in hstate[pending].tolist())
+                    del keep[:2 * STOP_POLL]                      # rows of iterations the stream has certainly consumed
+                pending, slot = slot, slot ^ 1
             if stop:
                 iters = at
                 break
             iters = it
+    if on_gpu and not stop:
+        stop, at = (int(v) for v in state.tolist())               # the final state, after everything that was queued
+        if stop:
+            iters = at
     resNorm = float(sc[4])
     lib.call("mf_mic_check", st)
     if stop == 2:

@@ -45,7 +45,8 @@ int mf_mic_check(void* stream) {
 	(void)stream;
 	return 0;
 }
-int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* Ai, const float* Aj, const float* Ak, void* st) {
+int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak, void* st) {
+	(void)A0;
 	(void)sx; (void)sy; (void)sz; (void)flags; (void)Ai; (void)Aj; (void)Ak; (void)st; /* an accelerator of the HIP library only */
 	return 0;
 }

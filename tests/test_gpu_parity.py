@@ -199,7 +199,7 @@ def test_apply_matrix_with_packed_coefficients(hip, oracle, dims):
     hip.call("mf_apply_matrix", sx, sy, sz, f, dst, s_, *dA, None)
     hip.sync()
     assert_bitexact(hip.host(dst), want, "general kernel")
-    hip.call("mf_pack_matrix", sx, sy, sz, f, dA[1], dA[2], dA[3], None)
+    hip.call("mf_pack_matrix", sx, sy, sz, f, dA[0], dA[1], dA[2], dA[3], None)
     dst2 = hip.dev(np.full((sz, sy, sx), 7.0, np.float32))
     hip.call("mf_apply_matrix", sx, sy, sz, f, dst2, s_, *dA, None)
     hip.sync()
@@ -209,7 +209,7 @@ def test_apply_matrix_with_packed_coefficients(hip, oracle, dims):
     B[2] *= np.float32(0.5)
     wantB = cases.run_apply_matrix_impl(oracle, dims, flags, B, src)
     dB = [hip.dev(b) for b in B]
-    hip.call("mf_pack_matrix", sx, sy, sz, f, dB[1], dB[2], dB[3], None)
+    hip.call("mf_pack_matrix", sx, sy, sz, f, dB[0], dB[1], dB[2], dB[3], None)
     dst3 = hip.dev(np.full((sz, sy, sx), 7.0, np.float32))
     hip.call("mf_apply_matrix", sx, sy, sz, f, dst3, s_, *dB, None)
     hip.sync()
