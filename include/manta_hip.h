@@ -54,7 +54,7 @@ const char* mf_backend(void);
  *   2  round 2: mf_semi_lagrange_{real,vec3,mac}, mf_interpolate_grid, mf_interpolate_mac_grid take `int orderSpace` before `stream`;
  *      mf_apply_noise_vec3 takes four uv arguments; mf_set_mic_blocking / mf_set_mic_blocking_x replaced by mf_mic_init_blocked
  *   3  round 3: mf_abi_version itself; mf_set_mic_mode knows "rows" and "levels" only; mf_cg_slab_after_dp / _after_zr: the pressure
- *      update moved from the former to the latter (arguments changed); mf_pack_matrix takes A0 */
+ *      update moved from the former to the latter (arguments changed); mf_pack_matrix takes A0; mf_solve_pressure_fused */
 #define MF_ABI_VERSION 3
 int mf_abi_version(void);
 
@@ -455,6 +455,16 @@ int mf_cg_slab_alpha(const double* gathered, int world, const float* sigma_dev, 
                      const int32_t* state_dev, void* stream);
 int mf_cg_slab_beta(const double* gathered, int world, float* sigma_dev, float* beta_dev, float* res_dev,
                     float accuracy, int iter, int32_t* state_dev, void* stream);
+/* solvePressureSystem for the plain case -- a MakeLaplaceMatrix system (no fractions, no ghost-fluid diagonal, no pressure fixing) with
+ * the plain MakeRhs (no perCellCorr / obvel / surface tension / enforceCompatibility), MIC preconditioner, 3D, sx % 8 == 0 -- without the
+ * coefficient grids: ONE pass over flags and vel writes rhs (MakeRhs, pressure.cpp:32-84; every cell, 0 outside the fluid) and the packed
+ * byte of every cell ({fluid, Ai / Aj / Ak == -1, integer A0}: MakeLaplaceMatrix, conjugategrad.h:154-187), the MIC factor is built from
+ * those bytes (conjugategrad.cpp:66-97) and the PCG of mf_cg_solve runs on them.  Same arithmetic per cell, same iterates as
+ * mf_make_rhs + mf_make_laplace_matrix + mf_cg_solve; rhs / residual / search / tmp / Aprecond are work grids that need not be cleared.
+ * out_host as in mf_cg_solve.  HIP: fails for other grids (callers fall back to the three calls); the oracle composes the three calls. */
+int mf_solve_pressure_fused(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* pressure, float* rhs,
+                            float* residual, float* search, float* tmp, float* Aprecond, float accuracy, int maxIter,
+                            int useL2Norm, float* out_host, void* stream);
 /* fused pieces of one slab PCG iteration.  `scalars` points to a device block laid out as
  *   float sigma, alpha, nalpha, beta, resNorm, dp, sigmaNew, accuracy; int32 iterations, done, diverged, useL2
  * (zero-initialised by the caller; mf_cg_slab_alpha writes alpha and nalpha = -alpha, mf_cg_slab_beta sigma / beta / resNorm):

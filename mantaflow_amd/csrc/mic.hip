@@ -761,7 +761,10 @@ __global__ void __launch_bounds__(ROWS_THREADS)
 k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
                 unsigned long long* xj, unsigned long long* xk, unsigned long long* xj1, unsigned long long* xk1, unsigned gen,
                 const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ A0,
-                const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak) {
+                const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
+                const unsigned char* __restrict__ pack) {
+	// pack (nullable): the matrix-free set-up of mf_solve_pressure_fused -- flags, the 0 / -1 off-diagonals and the integer diagonal of a
+	// MakeLaplaceMatrix system as one byte per cell (k_mic_pack's layout); flags / A0 / Ai / Aj / Ak are then not read
 	constexpr bool REV = false;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane & 7, c = lane >> 3;
 	const int skew = b + c;
@@ -909,11 +912,24 @@ k_mic_rows_init(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, cons
 					chunk_geom(n, rowidx, nv);
 					int rF[8];
 					float r0[8], ri[8], rj[8], rk[8];
-					load_row8i<VEC, REV>(flags, rowidx, nv, rF);
-					load_row8<VEC, REV>(A0, rowidx, nv, r0);
-					load_row8<VEC, REV>(Ai, rowidx, nv, ri);
-					load_row8<VEC, REV>(Aj, rowidx, nv, rj);
-					load_row8<VEC, REV>(Ak, rowidx, nv, rk);
+					if (pack) {
+						const unsigned long long W = nv > 0 ? *(const unsigned long long*)(pack + rowidx) : 0ull;     // sx % 8 == 0
+#pragma unroll
+						for (int a = 0; a < 8; a++) {
+							const unsigned bits = (unsigned)(W >> (8 * a)) & 0xffu;
+							rF[a] = (bits & 1u) ? MF_FLUID : 0;
+							r0[a] = (float)(bits >> 4);
+							ri[a] = (bits & 2u) ? -1.f : 0.f;
+							rj[a] = (bits & 4u) ? -1.f : 0.f;
+							rk[a] = (bits & 8u) ? -1.f : 0.f;
+						}
+					} else {
+						load_row8i<VEC, REV>(flags, rowidx, nv, rF);
+						load_row8<VEC, REV>(A0, rowidx, nv, r0);
+						load_row8<VEC, REV>(Ai, rowidx, nv, ri);
+						load_row8<VEC, REV>(Aj, rowidx, nv, rj);
+						load_row8<VEC, REV>(Ak, rowidx, nv, rk);
+					}
 					if (n >= ROWS_RING / 8) wait_for(&s_flushed, n - ROWS_RING / 8 + 1);
 					if (n >= ROWS_RING / 8) wait_for(&s_pub, 2 * (n - ROWS_RING / 8 + 2) + 2);
 					const int p0 = 8 * n + skew + 2;
@@ -1395,6 +1411,56 @@ int mic_flow_error() {
 	return 0;
 }
 int mic_mode() { return mic_mode_(); }      // the requested mode (0 levels, 2 rows)
+// matrix-free set-up (mf_solve_pressure_fused): the handle's packed-byte and empty-bundle buffers for a d-sized system, the map
+// preset to "empty" (the set-up kernel clears the entry of every bundle it finds a fluid cell in)
+int mic_fused_begin(const Dim& d, hipStream_t st, unsigned char** pack, int** bempty, int* nbj) {
+	if (!d.is3d || (d.sx % 8) != 0) return fail("mic_fused_begin: needs a 3D grid with sx % 8 == 0");
+	FlowState* f;
+	MF_TRY(rows_prepare(d, &f, st, 0, 0));
+	if (f->nblocks + 1 > f->bempty_cap) {
+		MF_HIP(hipStreamSynchronize(st));
+		if (f->bempty) MF_HIP(hipFree(f->bempty));
+		MF_HIP(hipMalloc((void**)&f->bempty, sizeof(int) * (f->nblocks + 1)));
+		f->bempty_cap = f->nblocks + 1;
+	}
+	if ((size_t)d.n > f->pack_cap) {
+		MF_HIP(hipStreamSynchronize(st));
+		if (f->pack) MF_HIP(hipFree(f->pack));
+		MF_HIP(hipMalloc((void**)&f->pack, (size_t)d.n + 64));
+		f->pack_cap = (size_t)d.n;
+	}
+	if (!f->pack_ok) MF_HIP(hipMalloc((void**)&f->pack_ok, 2 * sizeof(int)));
+	MF_HIP(hipMemsetD32Async((hipDeviceptr_t)f->bempty, 1, f->nblocks + 1, st));
+	MF_HIP(hipMemsetAsync(f->pack_ok, 1, 2 * sizeof(int), st));      // both verdicts hold by construction
+	f->be_flags = nullptr;
+	*pack = f->pack;
+	*bempty = f->bempty;
+	*nbj = f->nbj;
+	return 0;
+}
+// ... and the MIC factor from those bytes (k_mic_rows_init), registered as the system of (flags, Aprecond) with no coefficient arrays
+int mic_fused_finish(const Dim& d, const int32_t* flags, float* Aprecond, hipStream_t st) {
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState* f;
+	MF_TRY(rows_prepare(d, &f, st, 0, 0));
+	MF_HIP(hipMemsetAsync(Aprecond, 0, sizeof(float) * d.n, st));
+	MF_TRY(rows_next_gen(f, st));
+	int ncu = 256;
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+	const int grid = f->nblocks < ncu ? f->nblocks : ncu;
+	if (!al16(Aprecond)) return fail("mic_fused_finish: Aprecond must be 16-byte aligned");
+	hipLaunchKernelGGL((k_mic_rows_init<true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const unsigned char*)f->pack);
+	MF_LAUNCH_CHECK();
+	f->mode = 2;
+	f->blk_rows = f->blk_cells = 0;
+	f->be_flags = flags;
+	f->be_Ap = Aprecond;
+	f->be_Aj = f->be_Ak = nullptr;
+	f->pk_flags = flags;
+	f->pk_A0 = f->pk_Ai = f->pk_Aj = f->pk_Ak = nullptr;
+	return 0;
+}
 }  // namespace mf
 
 extern "C" {
@@ -1427,9 +1493,9 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 	const int grid = f->nblocks < ncu ? f->nblocks : ncu;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(Aprecond) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	if (vec)
-		hipLaunchKernelGGL((k_mic_rows_init<true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
+		hipLaunchKernelGGL((k_mic_rows_init<true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak, (const unsigned char*)nullptr);
 	else
-		hipLaunchKernelGGL((k_mic_rows_init<false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak);
+		hipLaunchKernelGGL((k_mic_rows_init<false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border, f->ctl, f->rows_xt, f->sxj, f->sxk, f->sxj1, f->sxk1, f->sgen, flags, Aprecond, A0, Ai, Aj, Ak, (const unsigned char*)nullptr);
 	MF_LAUNCH_CHECK();
 	// which row bundles the apply sweeps of THIS system may leave out (valid for the grids given here)
 	f->blk_rows = rows_j;

@@ -25,6 +25,10 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const fl
                    const unsigned char** pack, bool* a0_packed, hipStream_t st);
 // packed bytes built by mf_pack_matrix for exactly these grids, or nullptr (no synchronisation); *a0_packed: they carry this A0
 const unsigned char* mic_pack_user(const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak, bool* a0_packed);
-int mic_mode();          // 0 levels, 1 tiles, 2 rows
+int mic_mode();          // the requested sweep mode: 0 levels, 2 rows
+// matrix-free set-up of mf_solve_pressure_fused: buffers of the system handle (empty-bundle map preset to 1 = empty), then the MIC
+// factor from the packed bytes and the registration of (flags, Aprecond) as a system without coefficient arrays
+int mic_fused_begin(const Dim& d, hipStream_t st, unsigned char** pack, int** bempty, int* nbj);
+int mic_fused_finish(const Dim& d, const int32_t* flags, float* Aprecond, hipStream_t st);
 int mic_flow_error();    // reads (and clears) the deadlock-guard flag of the single-launch sweeps; needs a synchronised stream
 }  // namespace mf

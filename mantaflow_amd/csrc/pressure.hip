@@ -966,6 +966,9 @@ k_diffusion_matrix(int64_t n, const int32_t* __restrict__ flags, float* __restri
 	}
 }
 
+static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const float* rhs, float* residual, float* search, float* tmp,
+                         const float* A0, const float* Ai, const float* Aj, const float* Ak, float* Aprecond, int pc, float accuracy,
+                         int maxIter, int useL2Norm, float* out_host, void* stream, const unsigned char* free_pack);
 // the system of mf_cg_solve with its rows padded from sx to px cells (pad cells: obstacle, zero coefficients, zero rhs), and back
 __global__ void __launch_bounds__(BLOCK)
 k_pad_system(int sx, int px, int64_t np_, const int32_t* __restrict__ flags, const float* __restrict__ rhs, const float* __restrict__ A0,
@@ -1169,7 +1172,6 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
                 float accuracy, int maxIter, int useL2Norm, float* out_host, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
-	const int64_t n = d.n;
 	hipStream_t st = (hipStream_t)stream;
 	if (pc != MF_PC_NONE && pc != MF_PC_MICP) return fail("GridCg<APPLYMAT>::setICPreconditioner: Invalid method specified.");
 	if (pc == MF_PC_MICP && !d.is3d) pc = MF_PC_NONE;  // conjugategrad.cpp:315-321
@@ -1222,6 +1224,19 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 			return 0;
 		}
 	}
+	return cg_solve_core(d, flags, dst, rhs, residual, search, tmp, A0, Ai, Aj, Ak, Aprecond, pc, accuracy, maxIter, useL2Norm, out_host, stream, nullptr);
+}
+
+}  // extern "C"
+
+// doInit + iterate loop of GridCg (conjugategrad.cpp:210-307).  free_pack (mf_solve_pressure_fused): the system exists as packed bytes
+// only -- A0 / Ai / Aj / Ak are null, the MIC factor is already in Aprecond and the system is registered with the sweeps
+static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const float* rhs, float* residual, float* search, float* tmp,
+                         const float* A0, const float* Ai, const float* Aj, const float* Ak, float* Aprecond, int pc, float accuracy,
+                         int maxIter, int useL2Norm, float* out_host, void* stream, const unsigned char* free_pack) {
+	const int sx = d.sx, sy = d.sy, sz = d.sz;
+	const int64_t n = d.n;
+	hipStream_t st = (hipStream_t)stream;
 	Workspace* ws;
 	MF_TRY(get_workspace(&ws));
 	CgScalars* sc = (CgScalars*)ws->scalars;
@@ -1235,7 +1250,7 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	MF_HIP(hipMemsetAsync(dst, 0, sizeof(float) * n, st));
 	MF_HIP(hipMemcpyAsync(residual, rhs, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
 	if (pc == MF_PC_MICP) {
-		MF_TRY(mf_mic_init(sx, sy, sz, flags, Aprecond, A0, Ai, Aj, Ak, stream));
+		if (!free_pack) MF_TRY(mf_mic_init(sx, sy, sz, flags, Aprecond, A0, Ai, Aj, Ak, stream));
 		MF_TRY(mf_mic_apply(sx, sy, sz, flags, tmp, residual, Aprecond, Ai, Aj, Ak, stream));
 	} else {
 		MF_HIP(hipMemcpyAsync(tmp, residual, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
@@ -1248,7 +1263,12 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	// ApplyMatrix reads the same packed coefficient bytes as the MIC sweeps when mf_mic_init found the matrix packable
 	const unsigned char* am_pack = nullptr;
 	bool am_a0p = false;
-	if (pc == MF_PC_MICP) MF_TRY(mic_pack_query(d, flags, A0, Ai, Aj, Ak, &am_pack, &am_a0p, st));
+	if (free_pack) {
+		am_pack = free_pack;
+		am_a0p = true;
+	} else if (pc == MF_PC_MICP) {
+		MF_TRY(mic_pack_query(d, flags, A0, Ai, Aj, Ak, &am_pack, &am_a0p, st));
+	}
 
 	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done`, one batch behind the batch it has just queued
 	// (every kernel of an iteration returns at once when `done` is already set, so running ahead costs a few empty
@@ -1311,6 +1331,95 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 	if (pc == MF_PC_MICP) MF_TRY(mic_flow_error());
 	if (h.diverged) return fail("GridCg::iterate: The CG solver diverged, residual norm > 1e30, stopping.");
 	return 0;
+}
+
+// ---- matrix-free set-up of a plain MakeLaplaceMatrix system (no fractions, no ghost fluid, no optional rhs terms): ONE pass over
+// flags and vel writes rhs (MakeRhs, pressure.cpp:32-84), the packed byte of every cell -- fluid bit, "Ai / Aj / Ak is -1" bits and the
+// integer diagonal in bits 4-7 (MakeLaplaceMatrix, conjugategrad.h:154-187; k_mic_pack's layout) -- and clears the empty-bundle entry
+// of every 8 x 8 bundle of rows that holds a fluid cell.  The float arrays A0 / Ai / Aj / Ak never exist.  A thread owns 4 cells.
+__global__ void __launch_bounds__(BLOCK)
+k_setup_fused(Dim d, const int32_t* __restrict__ flags, const float* __restrict__ vel, float* __restrict__ rhs, unsigned char* __restrict__ pack,
+              int* __restrict__ bempty, int nbj) {
+	const int qx = d.sx >> 2;
+	const int64_t T = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
+	if (T >= (int64_t)qx * d.sy * d.sz) return;
+	const int qi = (int)(T % qx);
+	const int64_t rg = T / qx;
+	const int j = (int)(rg % d.sy), k = (int)(rg / d.sy), i0 = 4 * qi;
+	const int64_t Y = d.Y, Z = d.Z, n = d.n;
+	const int64_t idx = i0 + Y * j + Z * k;
+	const int4 f4 = *(const int4*)(flags + idx);
+	const int f[4] = {f4.x, f4.y, f4.z, f4.w};
+	float r[4] = {0.f, 0.f, 0.f, 0.f};
+	unsigned bytes = 0;
+	const bool row_in = j >= 1 && j <= d.sy - 2 && k >= 1 && k <= d.sz - 2;
+	if (row_in) {
+		const int4 ym4 = *(const int4*)(flags + idx - Y), yp4 = *(const int4*)(flags + idx + Y);
+		const int4 zm4 = *(const int4*)(flags + idx - Z), zp4 = *(const int4*)(flags + idx + Z);
+		const int ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w}, yp[4] = {yp4.x, yp4.y, yp4.z, yp4.w};
+		const int zm[4] = {zm4.x, zm4.y, zm4.z, zm4.w}, zp[4] = {zp4.x, zp4.y, zp4.z, zp4.w};
+		const int fxm = i0 > 0 ? flags[idx - 1] : MF_OBSTACLE, fxp = i0 + 4 < d.sx ? flags[idx + 4] : MF_OBSTACLE;
+		const float *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+		const float4 ux4 = *(const float4*)(vx + idx), uy4 = *(const float4*)(vy + idx), uyp4 = *(const float4*)(vy + idx + Y);
+		const float4 uz4 = *(const float4*)(vz + idx), uzp4 = *(const float4*)(vz + idx + Z);
+		const float uxp = i0 + 4 < d.sx ? vx[idx + 4] : 0.f;
+		const float ux[5] = {ux4.x, ux4.y, ux4.z, ux4.w, uxp};
+		const float uy[4] = {uy4.x, uy4.y, uy4.z, uy4.w}, uyp[4] = {uyp4.x, uyp4.y, uyp4.z, uyp4.w};
+		const float uz[4] = {uz4.x, uz4.y, uz4.z, uz4.w}, uzp[4] = {uzp4.x, uzp4.y, uzp4.z, uzp4.w};
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const int i = i0 + c;
+			const bool fl = (f[c] & MF_FLUID) != 0;
+			unsigned b = fl ? 1u : 0u;
+			if (fl && i >= 1 && i <= d.sx - 2) {
+				const int xm = c > 0 ? f[c - 1] : fxm, xp = c < 3 ? f[c + 1] : fxp;
+				const unsigned a0 = (unsigned)!(xm & MF_OBSTACLE) + (unsigned)!(xp & MF_OBSTACLE) + (unsigned)!(ym[c] & MF_OBSTACLE) +
+				                    (unsigned)!(yp[c] & MF_OBSTACLE) + (unsigned)!(zm[c] & MF_OBSTACLE) + (unsigned)!(zp[c] & MF_OBSTACLE);
+				b |= ((xp & MF_FLUID) ? 2u : 0u) | ((yp[c] & MF_FLUID) ? 4u : 0u) | ((zp[c] & MF_FLUID) ? 8u : 0u) | (a0 << 4);
+				float set = ux[c] - ux[c + 1] + uy[c] - uyp[c];
+				set += uz[c] - uzp[c];
+				r[c] = set;
+			}
+			bytes |= b << (8 * c);
+		}
+	} else {
+#pragma unroll
+		for (int c = 0; c < 4; c++) bytes |= ((f[c] & MF_FLUID) ? 1u : 0u) << (8 * c);
+	}
+	*(float4*)(rhs + idx) = make_float4(r[0], r[1], r[2], r[3]);
+	*(unsigned*)(pack + idx) = bytes;
+	if (bytes & 0x01010101u) bempty[(k >> 3) * nbj + (j >> 3)] = 0;
+}
+
+extern "C" {
+
+int mf_solve_pressure_fused(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* pressure, float* rhs, float* residual,
+                            float* search, float* tmp, float* Aprecond, float accuracy, int maxIter, int useL2Norm, float* out_host,
+                            void* stream) {
+	MF_TRY(check_dim(sx, sy, sz));
+	const Dim d = mkdim(sx, sy, sz);
+	hipStream_t st = (hipStream_t)stream;
+	if (!d.is3d || (sx % 8) != 0 || mic_mode() != 2) return fail("mf_solve_pressure_fused: needs a 3D grid with sx % 8 == 0 and the \"rows\" sweeps");
+	if (!(al16(flags) && al16(vel) && al16(pressure) && al16(rhs) && al16(residual) && al16(search) && al16(tmp) && al16(Aprecond)))
+		return fail("mf_solve_pressure_fused: grids must be 16-byte aligned");
+	unsigned char* pack;
+	int* bempty;
+	int nbj;
+	MF_TRY(mic_fused_begin(d, st, &pack, &bempty, &nbj));
+	const int64_t nthr = (int64_t)(sx >> 2) * sy * sz;
+	hipLaunchKernelGGL(k_setup_fused, dim3((unsigned)((nthr + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d, flags, vel, rhs, pack, bempty, nbj);
+	MF_LAUNCH_CHECK();
+	MF_TRY(mic_fused_finish(d, flags, Aprecond, st));
+	if (maxIter <= 0) {
+		out_host[0] = 0.f;
+		out_host[1] = 1e20f;
+		out_host[2] = 0.f;
+		return 0;
+	}
+	// the sweeps never write a non-fluid cell of tmp: it has to start from zeros (a fresh temp grid in the reference)
+	MF_HIP(hipMemsetAsync(tmp, 0, sizeof(float) * d.n, st));
+	return cg_solve_core(d, flags, pressure, rhs, residual, search, tmp, nullptr, nullptr, nullptr, nullptr, Aprecond, MF_PC_MICP, accuracy, maxIter,
+	                     useL2Norm, out_host, stream, pack);
 }
 
 

@@ -313,6 +313,22 @@ def solvePressure(vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=N
                   cgMaxIterFac=1.5, precondition=True, preconditioner=PcMIC, enforceCompatibility=False, useL2Norm=False,
                   zeroPressureFixing=False, curv=None, surfTens=0., retRhs=None):
     _chk(vel, MACGrid, "MACGrid")
+    if _plain_system(vel, pressure, flags, cgAccuracy, phi, perCellCorr, fractions, obvel, precondition, preconditioner,
+                     enforceCompatibility, zeroPressureFixing, curv, surfTens):
+        # the plain case (every smoke scene, FLIP without ghost fluid): rhs + packed matrix in one pass, MIC factor and PCG on the
+        # packed bytes -- the coefficient grids A0 / Ai / Aj / Ak and pca1..3 of pressure.cpp:332-338, 412-415 are never made
+        s = flags.parent
+        sx, sy, sz = flags.dims
+        rhs, residual, search, tmp, pca0 = (_scratch_grid(s) for _ in range(5))
+        maxIter = int(np.float32(cgMaxIterFac) * np.float32(max(sx, sy, sz)))        # pressure.cpp:410 (3D)
+        out = (ctypes.c_float * 3)()
+        s.lib.call("mf_solve_pressure_fused", sx, sy, sz, flags.ptr, vel.ptr, pressure.ptr, rhs.ptr, residual.ptr, search.ptr, tmp.ptr,
+                   pca0.ptr, float(cgAccuracy), int(maxIter), int(bool(useL2Norm)), out, s.stream)
+        _last_cg["iterations"], _last_cg["residual"] = int(out[0]), float(out[1])
+        correctVelocity(vel, pressure, flags, notiming=True)
+        if retRhs is not None and not (isinstance(retRhs, int) and retRhs == 0):
+            _chk(retRhs, Grid, "Grid<Real>").copyFrom(rhs)
+        return
     rhs = Grid(vel.parent)
     common = dict(cgAccuracy=cgAccuracy, phi=phi, perCellCorr=perCellCorr, fractions=fractions, gfClamp=gfClamp,
                   cgMaxIterFac=cgMaxIterFac, precondition=precondition, preconditioner=preconditioner,
@@ -323,6 +339,36 @@ def solvePressure(vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=N
     correctVelocity(vel, pressure, flags, **common)
     if retRhs is not None and not (isinstance(retRhs, int) and retRhs == 0):
         _chk(retRhs, Grid, "Grid<Real>").copyFrom(rhs)
+
+
+def _scratch_grid(s):
+    """a Real temp grid from the solver's pool WITHOUT the clear of the Grid constructor, for callees that overwrite every cell"""
+    g = Grid.__new__(Grid)
+    core.PbClass.__init__(g, s, "")
+    g.sx, g.sy, g.sz = s.mGridSize
+    g.n = g.sx * g.sy * g.sz
+    g.data = s._alloc(g._kind, zero=False)
+    g._external = False
+    return g
+
+
+def _plain_system(vel, pressure, flags, cgAccuracy, phi, perCellCorr, fractions, obvel, precondition, preconditioner,
+                  enforceCompatibility, zeroPressureFixing, curv, surfTens):
+    """can mf_solve_pressure_fused take this solvePressure call?  (3D, rows of a multiple of 8 cells, MIC, MakeLaplaceMatrix system
+    with the plain MakeRhs)"""
+    if not (isinstance(pressure, Grid) and isinstance(flags, FlagGrid)) or not flags.is3D():
+        return False
+    none = lambda v: v is None or (isinstance(v, int) and not isinstance(v, bool) and v == 0)
+    if not (none(phi) and none(perCellCorr) and none(fractions) and none(obvel) and none(curv)):
+        return False
+    if precondition is not True or preconditioner != PcMIC or enforceCompatibility or zeroPressureFixing or cgAccuracy < 1e-07:
+        return False
+    if flags.sx % 8 != 0 or _fused_off:
+        return False
+    return (vel.sx, vel.sy, vel.sz) == flags.dims == (pressure.sx, pressure.sy, pressure.sz)
+
+
+_fused_off = bool(__import__("os").environ.get("MF_NO_FUSED_SETUP"))
 
 
 def lastCgStats():

@@ -3043,6 +3043,28 @@ int mf_time_apply_matrix_packed(int sx, int sy, int sz, const int32_t* flags, fl
 	return fail("mf_time_apply_matrix_packed: HIP only");
 }
 
+/* the same three calls the plugin layer makes for a plain system (pressure.cpp:32-84, conjugategrad.h:154-187, conjugategrad.cpp:210-307);
+ * the coefficient grids are scratch of this call */
+int mf_solve_pressure_fused(int sx, int sy, int sz, const int32_t* flags, const float* vel, float* pressure, float* rhs,
+                            float* residual, float* search, float* tmp, float* Aprecond, float accuracy, int maxIter,
+                            int useL2Norm, float* out_host, void* st) {
+	const int64_t n = (int64_t)sx * sy * sz;
+	if (sz <= 1) return fail("mf_solve_pressure_fused: 3D only");
+	float* A = (float*)calloc((size_t)(4 * n), sizeof(float));
+	if (!A) return fail("mf_solve_pressure_fused: out of memory");
+	memset(rhs, 0, sizeof(float) * (size_t)n);
+	memset(residual, 0, sizeof(float) * (size_t)n);
+	memset(search, 0, sizeof(float) * (size_t)n);
+	memset(tmp, 0, sizeof(float) * (size_t)n);
+	memset(Aprecond, 0, sizeof(float) * (size_t)n);
+	int rc = mf_make_rhs(sx, sy, sz, flags, rhs, vel, NULL, NULL, NULL, NULL, NULL, 0.f, 1e-4f, NULL, NULL, st);
+	if (!rc) rc = mf_make_laplace_matrix(sx, sy, sz, flags, A, A + n, A + 2 * n, A + 3 * n, NULL, st);
+	if (!rc) rc = mf_cg_solve(sx, sy, sz, flags, pressure, rhs, residual, search, tmp, A, A + n, A + 2 * n, A + 3 * n, Aprecond, MF_PC_MICP, accuracy,
+	                          maxIter, useL2Norm, out_host, st);
+	free(A);
+	return rc;
+}
+
 /* the two composite stretches of the z-slab PCG iteration (same arithmetic in the same order as the HIP library): as in
  * GridCg::iterate (conjugategrad.cpp:250-291), with `x += alpha * search` (:254) deferred to the search update (:283) -- nothing in
  * between reads x.  scalars = {sigma, alpha, nalpha, beta, resNorm, ..., word 12: xpending} */
