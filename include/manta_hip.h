@@ -207,7 +207,8 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
  * Advection (plugin/advection.cpp)
  * ---------------------------------------------------------------------------------------------- */
 /* SemiLagrange<Real>, advection.cpp:25-42 (orderTrace 1|2: first-order / midpoint back trace; orderSpace 1|2: linear interpolation,
- * util/interpol.h, or cubic, util/interpolHigh.h -- Grid::getInterpolatedHi, grid.h:153-159).  bnd=1: border untouched */
+ * util/interpol.h, or cubic, util/interpolHigh.h -- Grid::getInterpolatedHi, grid.h:153-159).  KERNEL(bnd=1) into a fresh temp grid: the
+ * border cells of dst are written as 0 (mf_semi_lagrange_vec3 / _mac alike), the caller need not clear dst */
 int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
                           int orderTrace, int orderSpace, void* stream);
 /* SemiLagrange<Vec3> (cell-centred Vec3 grid, SoA) */

@@ -31,7 +31,12 @@ template <int NCOMP, int OS>
 __global__ void __launch_bounds__(BLOCK)
 k_semi_lagrange(Dim d, const float* __restrict__ vel, float* __restrict__ dst, const float* __restrict__ src, float dt, int orderTrace) {
 	CELL_IJK(d)
-	if (!INTERIOR(d)) return;
+	if (!INTERIOR(d)) {
+		// KERNEL(bnd=1) leaves the boundary of a fresh (cleared) temp grid alone: written here, so that the caller need not clear dst
+#pragma unroll
+		for (int c = 0; c < NCOMP; c++) dst[c * d.n + idx] = 0.f;
+		return;
+	}
 	float vx, vy, vz, px, py, pz;
 	get_centered(d, vel, idx, vx, vy, vz);
 	const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)(k + d.zoff) + 0.5f;
@@ -76,7 +81,14 @@ k_semi_lagrange_zmarch(Dim d, const float* __restrict__ vel, float* __restrict__
 	const int64_t ij = q - g * plane;
 	const int i = (int)(ij % d.sx), j = (int)(ij / d.sx);
 	const int k0 = (int)g * SLZ;
-	if (k0 >= d.sz || i < 1 || i >= d.sx - 1 || j < 1 || j >= d.sy - 1) return;
+	if (k0 >= d.sz) return;
+	if (i < 1 || i >= d.sx - 1 || j < 1 || j >= d.sy - 1) {
+		// boundary columns: the zeros of a cleared temp grid (the caller need not clear dst)
+		for (int t = 0; t < SLZ && k0 + t < d.sz; t++)
+#pragma unroll
+			for (int c = 0; c < NCOMP; c++) dst[c * d.n + ij + (int64_t)(k0 + t) * d.Z] = 0.f;
+		return;
+	}
 	const float* vx_ = vel;
 	const float* vy_ = vel + d.n;
 	const float* vz_ = vel + 2 * d.n;
@@ -99,7 +111,10 @@ k_semi_lagrange_zmarch(Dim d, const float* __restrict__ vel, float* __restrict__
 			nby = vy_[nidx + d.sx];
 			nbz = (k + 2 < d.sz) ? vz_[nidx + d.Z] : 0.f;
 		}
-		if (k >= 1 && k < d.sz - 1) {
+		if (k < 1 || k >= d.sz - 1) {
+#pragma unroll
+			for (int c = 0; c < NCOMP; c++) dst[c * d.n + idx] = 0.f;      // first / last plane: boundary zeros
+		} else {
 			const float vx = 0.5f * (ax + bx), vy = 0.5f * (ay + by), vz = 0.5f * (az + bz);      // getCentered
 			const float cz = (float)(k + d.zoff) + 0.5f;
 			const float px = cx - vx * dt, py = cy - vy * dt, pz = cz - vz * dt;
@@ -119,11 +134,18 @@ __device__ __forceinline__ float mac_component_hi(const Dim& d, const float* __r
 	return OS == 1 ? interpol1(d, src + (int64_t)C * d.n, x, y, z) : interpol_cubic_mac<C>(d, src, x, y, z);
 }
 // SemiLagrangeMAC, advection.cpp:45-78
+// (Round 3, built and dropped: a workgroup copying the velocity of its 32 x 4 x 4 tile + halo into LDS and forming getAtMACX/Y/Z from
+// there -- 7 coalesced loads per cell instead of 27 neighbour loads -- is bit-exact and SLOWER, 355 vs 293 us here and 563 vs 469 us
+// in the fused clamp: the neighbour loads were L1 hits all along, the kernels are bound by the traced, divergent gathers and by the
+// latency of the position -> address -> value chain, and the tile costs occupancy, a barrier and index arithmetic.)
 template <int OS>
 __global__ void __launch_bounds__(BLOCK)
 k_semi_lagrange_mac(Dim d, const float* __restrict__ vel, float* __restrict__ dst, const float* __restrict__ src, float dt, int orderTrace) {
 	CELL_IJK(d)
-	if (!INTERIOR(d)) return;
+	if (!INTERIOR(d)) {
+		dst[idx] = dst[d.n + idx] = dst[2 * d.n + idx] = 0.f;      // boundary zeros of a cleared temp grid
+		return;
+	}
 	const float cx = (float)i + 0.5f, cy = (float)j + 0.5f, cz = (float)(k + d.zoff) + 0.5f;
 	const int kg = k + d.zoff;
 	float vx, vy, vz, rx, ry, rz;

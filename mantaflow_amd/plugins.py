@@ -127,13 +127,15 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
     t = grid.getType()
     if t & GridBase.TypeMAC:
         # fnAdvectSemiLagrange<MACGrid>, advection.cpp:407-437
-        fwd = MACGrid(s)
+        # (the three temp grids are written in every cell by their kernels -- the semi-Lagrange steps put the zeros of a fresh grid
+        # on the border themselves -- so they come from the pool without the constructor's clear)
+        fwd = _scratch_grid(s, MACGrid)
         lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), int(orderSpace), st)
         if order == 1:
             _apply_outflow_bc(flags, fwd, grid, dt)
             grid.swap(fwd)
         else:
-            bwd, newg = MACGrid(s), MACGrid(s)
+            bwd, newg = _scratch_grid(s, MACGrid), _scratch_grid(s, MACGrid)
             lib.call("mf_semi_lagrange_mac", sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), int(orderSpace), st)
             # MacCormackCorrectMAC + MacCormackClampMAC, fused (the clamp reads the corrected value of its own cell only)
             lib.call("mf_maccormack_correct_clamp_mac", sx, sy, sz, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr, float(strength),
@@ -145,12 +147,12 @@ def advectSemiLagrange(flags, vel, grid, order=1, strength=1.0, orderSpace=1, op
         ncomp = 1 if (t & GridBase.TypeReal) else 3
         G = type(grid)
         sl = "mf_semi_lagrange_real" if ncomp == 1 else "mf_semi_lagrange_vec3"
-        fwd = G(s)
+        fwd = _scratch_grid(s, G)
         lib.call(sl, sx, sy, sz, vel.ptr, fwd.ptr, grid.ptr, dt, int(orderTrace), int(orderSpace), st)
         if order == 1:
             grid.swap(fwd)
         else:
-            bwd, newg = G(s), G(s)
+            bwd, newg = _scratch_grid(s, G), _scratch_grid(s, G)
             lib.call(sl, sx, sy, sz, vel.ptr, bwd.ptr, fwd.ptr, -dt, int(orderTrace), int(orderSpace), st)
             lib.call("mf_maccormack_correct_clamp", sx, sy, sz, ncomp, flags.ptr, vel.ptr, newg.ptr, grid.ptr, fwd.ptr, bwd.ptr,
                      float(strength), dt, int(clampMode), st)
@@ -341,9 +343,10 @@ def solvePressure(vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=N
         _chk(retRhs, Grid, "Grid<Real>").copyFrom(rhs)
 
 
-def _scratch_grid(s):
-    """a Real temp grid from the solver's pool WITHOUT the clear of the Grid constructor, for callees that overwrite every cell"""
-    g = Grid.__new__(Grid)
+def _scratch_grid(s, cls=None):
+    """a temp grid from the solver's pool WITHOUT the clear of the Grid constructor, for callees that overwrite every cell"""
+    cls = cls or Grid
+    g = cls.__new__(cls)
     core.PbClass.__init__(g, s, "")
     g.sx, g.sy, g.sz = s.mGridSize
     g.n = g.sx * g.sy * g.sz

@@ -931,11 +931,13 @@ static int semi_lagrange(int sx, int sy, int sz, int ncomp, const float* vel, fl
 int mf_semi_lagrange_real(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
                           int orderTrace, int orderSpace, void* st) {
 	(void)st;
+	memset(dst, 0, sizeof(float) * (size_t)sx * sy * sz);      /* the border: zeros of the reference's fresh temp grid */
 	return semi_lagrange(sx, sy, sz, 1, vel, dst, src, dt, orderTrace, orderSpace);
 }
 int mf_semi_lagrange_vec3(int sx, int sy, int sz, const float* vel, float* dst, const float* src, float dt,
                           int orderTrace, int orderSpace, void* st) {
 	(void)st;
+	memset(dst, 0, sizeof(float) * 3 * (size_t)sx * sy * sz);
 	return semi_lagrange(sx, sy, sz, 3, vel, dst, src, dt, orderTrace, orderSpace);
 }
 /* SemiLagrangeMAC, advection.cpp:45-78 */
@@ -950,6 +952,7 @@ int mf_semi_lagrange_mac(int sx, int sy, int sz, const float* vel, float* dst, c
 	const int64_t n = d.n;
 	if (orderTrace != 1 && orderTrace != 2) return fail("Unknown backtracing order");
 	if (orderSpace != 1 && orderSpace != 2) return fail("Unknown interpolation order");
+	memset(dst, 0, sizeof(float) * 3 * (size_t)n);      /* the border: zeros of the reference's fresh temp grid */
 #pragma omp parallel for
 	for (int k = K0(d, 1); k < K1(d, 1); k++)
 		for (int j = 1; j < sy - 1; j++)
