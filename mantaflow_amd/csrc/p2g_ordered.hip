@@ -259,8 +259,8 @@ k_bin_sort_big(const int32_t* __restrict__ start, int32_t* __restrict__ order, c
 //                   component's own axis replaced by that of the shifted half of BUILD_INDEX_SHIFT, and the value to spread.
 //                   The other weight of a pair is (float)(1. - (double)w1) in every case: that is how the reference forms it, and
 //                   the clamps set the pairs (1,0) / (0,1).
-//   link[T][slot] = {next entry of the same cell with the same e bit: p << 4 | distance (0: none, 15: 15 or more),
-//                    next entry of the same cell: p << 1 (0xffffffff: none) -- bit 0: this entry's e bit}
+//   link[T][slot] = p | e << 28 | dist << 29: this entry's particle, its e bit along T's axis, and the distance to the next entry of
+//                   the same cell with the same e bit (0: none, 7: seven or more -- walk)
 // e = (ex, ey, ez): shifted base = B + e per axis.  spe[slot] = p | e << PBITS.
 template <int NV>
 __global__ void __launch_bounds__(BLOCK)
@@ -287,69 +287,91 @@ k_bin_payload(Dim d, const int32_t* __restrict__ start, int64_t ps, const float*
 // link words of every slot: a look-ahead inside the slot's own cell run
 __global__ void __launch_bounds__(BLOCK)
 k_bin_links(Dim d, const int32_t* __restrict__ start, const int32_t* __restrict__ keys, const uint32_t* __restrict__ spe, bool mac, int64_t cp,
-            uint2* __restrict__ link) {
+            uint32_t* __restrict__ link) {
 	const int64_t slot = blockIdx.x * (int64_t)BLOCK + threadIdx.x;
 	if (slot >= start[d.n]) return;
 	const unsigned w = spe[slot];
 	const int end = start[keys[w & PMASK] + 1];
-	const unsigned any = slot + 1 < end ? ((spe[slot + 1] & PMASK) << 1) : 0xfffffffeu;
+	const unsigned own = w & PMASK;
 	if (!mac) {
-		link[slot] = make_uint2(0u, any);
+		link[slot] = own;
 		return;
 	}
-	unsigned same[3] = {0u, 0u, 0u};
+	unsigned dist[3] = {0u, 0u, 0u};
 	int found = 0;
 	for (int64_t a = slot + 1; a < end && found != 7; a++) {
 		const unsigned u = spe[a];
-		const unsigned dist = a - slot < 15 ? (unsigned)(a - slot) : 15u;
+		const unsigned dd = a - slot < 7 ? (unsigned)(a - slot) : 7u;
 #pragma unroll
 		for (int c = 0; c < 3; c++)
 			if (!(found & (1 << c)) && ((u ^ w) >> (PBITS + c) & 1u) == 0u) {
-				same[c] = ((u & PMASK) << 4) | dist;
+				dist[c] = dd;
 				found |= 1 << c;
 			}
 	}
 #pragma unroll
-	for (int c = 0; c < 3; c++) link[c * cp + slot] = make_uint2(same[c], any | ((w >> (PBITS + c)) & 1u));
+	for (int c = 0; c < 3; c++) link[c * cp + slot] = own | (((w >> (PBITS + c)) & 1u) << 28) | (dist[c] << 29);
 }
 
-// ---- the gather: one thread per node, NCOMP values per particle (1 for a MAC component / Real grid, 3 for a Vec3 grid) ----
-// All active waves are resident at once, so the kernel takes as long as one node's chain  minimum -> cursor -> next head  times
-// its contributions: list heads live in registers as (p << 4 | list) words (one v_min chain finds the next particle AND its
-// list), the cursors of the 12 lists live in LDS ([list][thread]: a dynamic list index costs one ds_read instead of a 12-way
-// select), the next head comes from the winner's link word (ONE global round trip per contribution, no filter loop), and the
-// weights / value of a contribution are consumed one iteration later, so that their load never sits on the chain.
-// where a node's merge reads its lists from: the sorted arrays in global memory
+// ---- the gather: one thread per node ------------------------------------------------------------------------------------
+// where a node's merge reads its lists from: the sorted arrays in global memory ...
 struct SrcGlobal {
 	const float4* __restrict__ rec_;
-	const uint2* __restrict__ link_;
+	const uint32_t* __restrict__ link_;
 	const float* __restrict__ sv_;
 	int64_t cp;
-	const uint32_t* __restrict__ spe_;
 	const int32_t* __restrict__ start;
 	int sx, sy;
-	__device__ __forceinline__ void range(int bx, int by, int bz, unsigned& a, unsigned& e) const {
+	// slots [a, e) of a cell's run; *delta: what turns such a slot into the global slot of its record
+	__device__ __forceinline__ void range(int bx, int by, int bz, unsigned& a, unsigned& e, int& delta) const {
 		const int64_t c = (int64_t)bx + sx * ((int64_t)by + (int64_t)sy * bz);
 		a = (unsigned)start[c];
 		e = (unsigned)start[c + 1];
+		delta = 0;
 	}
-	__device__ __forceinline__ unsigned spe(unsigned a) const { return spe_[a]; }
-	__device__ __forceinline__ uint2 link(unsigned a) const { return link_[a]; }
-	__device__ __forceinline__ float4 rec(unsigned a) const { return rec_[a]; }
-	__device__ __forceinline__ float sv(int c, unsigned a) const { return sv_[c * cp + a]; }
+	__device__ __forceinline__ unsigned link(unsigned a) const { return link_[a]; }
+	__device__ __forceinline__ float4 rec(unsigned g) const { return rec_[g]; }
+	__device__ __forceinline__ float sv(int c, unsigned g) const { return sv_[c * cp + g]; }
+	// a list's cursor in LDS: {slot, end | offsets << PBITS}
+	typedef uint2 Cursor;
+	static __device__ __forceinline__ Cursor cur_make(unsigned a, unsigned e, unsigned meta) { return make_uint2(a, e | (meta << PBITS)); }
+	static __device__ __forceinline__ void cur_get(const Cursor& c, unsigned& a, unsigned& e, unsigned& meta) { a = c.x; e = c.y & PMASK; meta = c.y >> PBITS; }
+	static __device__ __forceinline__ void cur_set(Cursor& c, unsigned a) { c.x = a; }
 };
+// ... or the wave's copy of the link words of its tile's neighbourhood in LDS (local slot numbers; records stay in global memory)
+struct SrcWave {
+	const float4* __restrict__ rec_;
+	const uint32_t* link_;       // LDS
+	const int* lstart;           // LDS: local slot of every cell of the neighbourhood (+ one past the end)
+	const int* gstart;           // LDS: global slot of every cell's first entry
+	int x0, y0, z0, bxn, byn;
+	__device__ __forceinline__ void range(int bx, int by, int bz, unsigned& a, unsigned& e, int& delta) const {
+		const int idx = (bx - x0) + bxn * ((by - y0) + byn * (bz - z0));
+		a = (unsigned)lstart[idx];
+		e = (unsigned)lstart[idx + 1];
+		delta = gstart[idx] - (int)a;
+	}
+	__device__ __forceinline__ unsigned link(unsigned a) const { return link_[a]; }
+	__device__ __forceinline__ float4 rec(unsigned g) const { return rec_[g]; }
+	__device__ __forceinline__ float sv(int, unsigned) const { return 0.f; }
+	// local slots fit 12 bits (WCAP <= 4095): slot | end << 12 | offsets << 24 in one word -- LDS per wave is what bounds the occupancy
+	typedef unsigned Cursor;
+	static __device__ __forceinline__ Cursor cur_make(unsigned a, unsigned e, unsigned meta) { return a | (e << 12) | (meta << 24); }
+	static __device__ __forceinline__ void cur_get(const Cursor& c, unsigned& a, unsigned& e, unsigned& meta) { a = c & 4095u; e = (c >> 12) & 4095u; meta = c >> 24; }
+	static __device__ __forceinline__ void cur_set(Cursor& c, unsigned a) { c = (c & ~4095u) | a; }
+};
+
 // ---- the merge of one node: NCOMP values per particle (1 for a MAC component / Real grid, 3 for a Vec3 grid) ----
 // The kernel takes as long as one node's chain  minimum -> cursor -> next head  times its contributions: list heads live in
 // registers as (p << 4 | list) words (one v_min chain finds the next particle AND its list), the cursors of the 12 lists live
-// in LDS ([list][thread]: a dynamic list index costs one ds_read instead of a 12-way select), the next head comes from the
-// winner's link word (no filter loop), and the weights / value of a contribution are consumed one iteration later, so that
-// their load never sits on the chain.
+// in LDS ([list][thread]: a dynamic list index costs one ds_read instead of a 12-way select), the next head comes from link
+// words (no filter loop), and the weights / value of a contribution are consumed one iteration later, so that their load never
+// sits on the chain.
 template <int MODE, int NCOMP, int NT, class Src>
-__device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, const Src& src, uint2 (*s_ce)[NT], float* __restrict__ ref,
-                                           int64_t rstride, float* __restrict__ sum) {
+__device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, const Src& src, typename Src::Cursor (*s_ce)[NT], int (*s_delta)[NT],
+                                           float* __restrict__ ref, int64_t rstride, float* __restrict__ sum) {
 	constexpr int NL = (MODE == 3) ? 8 : 12;
 	constexpr unsigned INF = 0xffffffffu;
-	constexpr int ESH = PBITS + (MODE == 3 ? 0 : MODE);
 	// list q: offsets (o0, o1, o2) below the node along (shifted axis, next axis, next axis) for a MAC component -- 0 / 1 / 2
 	// along the shifted axis, of which offset 2 takes the entries with e = 1, offset 0 those with e = 0, offset 1 both -- and
 	// along (x, y, z) for a cell-centred grid.  meta = o0 | o1 << 2 | o2 << 3.
@@ -370,23 +392,27 @@ __device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, co
 		const bool ok = bx >= 0 && by >= 0 && bz >= 0 && (d.is3d || o[2] == 0);
 		const unsigned want = (MODE == 3) ? 2u : ((meta & 3u) == 2u ? 1u : ((meta & 3u) == 0u ? 0u : 2u));
 		unsigned a = 0, e = 0;
-		if (ok) src.range(bx, by, bz, a, e);
+		int delta = 0;
+		if (ok) src.range(bx, by, bz, a, e, delta);
 		unsigned h = INF;        // first entry that passes the filter
 		while (a < e) {
-			const unsigned w = src.spe(a);
-			if (want == 2u || ((w >> ESH) & 1u) == want) {
-				h = ((w & PMASK) << 4) | (unsigned)q;
+			const unsigned y = src.link(a);
+			if (want == 2u || ((y >> 28) & 1u) == want) {
+				h = ((y & PMASK) << 4) | (unsigned)q;
 				break;
 			}
 			a++;
 		}
-		s_ce[q][threadIdx.x] = make_uint2(a, e | (meta << PBITS));
+		s_ce[q][threadIdx.x] = Src::cur_make(a, e, meta);
+		s_delta[q][threadIdx.x] = delta;
 		head[q] = h;
 	}
 	float acc_w = 0.f, acc_v[NCOMP];
 #pragma unroll
 	for (int c = 0; c < NCOMP; c++) acc_v[c] = 0.f;
-	// the contribution whose record is still in flight
+	// the contribution whose record is still in flight (consumed one iteration after its load was issued; two iterations, three
+	// register slots in rotation, was built as well: 1.49 instead of 1.42 ms per mapPartsToMAC -- the record is not what the chain
+	// waits for)
 	bool pend = false;
 	float4 prec = make_float4(0.f, 0.f, 0.f, 0.f);
 	float pv1 = 0.f, pv2 = 0.f;
@@ -420,41 +446,41 @@ __device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, co
 		for (int q = 1; q < NL; q++) best = head[q] < best ? head[q] : best;
 		if (best == INF) break;
 		const unsigned bq = best & 15u;
-		const uint2 ce = s_ce[bq][threadIdx.x];
-		const unsigned slot = ce.x, e = ce.y & PMASK, meta = ce.y >> PBITS;
-		const uint2 lk = src.link(slot);
-		const float4 r = src.rec(slot);
+		typename Src::Cursor ce = s_ce[bq][threadIdx.x];
+		unsigned slot, e, meta;
+		Src::cur_get(ce, slot, e, meta);
+		const unsigned g = (unsigned)((int)slot + s_delta[bq][threadIdx.x]);       // the record's global slot
+		const unsigned osh = meta & 3u;
+		const bool both = (MODE == 3) || osh == 1u;
+		const unsigned lk = src.link(slot);
+		// where the winner's list goes on: slot + 1 for a list that takes every entry, slot + dist (from the link word) for one that
+		// takes the entries with one e bit; the next head is that entry's particle -- one more link word
+		const unsigned dist = both ? 1u : (lk >> 29);
+		unsigned a = slot + dist;
+		const unsigned ny = (dist != 0u && a < e) ? src.link(a) : 0u;
+		const float4 r = src.rec(g);
 		float v1 = 0.f, v2 = 0.f;
 		if (NCOMP == 3) {
-			v1 = src.sv(0, slot);
-			v2 = src.sv(1, slot);
+			v1 = src.sv(0, g);
+			v2 = src.sv(1, g);
 		}
 		if (pend) accumulate(prec, pv1, pv2, pd0, pd1, pd2);
-		// advance the winner's list: the link word names the next entry (and its particle) without another load
-		const unsigned osh = meta & 3u;
-		unsigned a, h;
-		if (MODE == 3 || osh == 1u) {
-			a = slot + 1;
-			h = (a < e) ? (((lk.y >> 1) << 4) | bq) : INF;
-		} else {
-			const unsigned dist = lk.x & 15u;
-			a = slot + dist;
-			h = dist ? ((lk.x & ~15u) | bq) : INF;
-			if (dist == 15u) {
-				// the next entry with this e bit is 15 or more slots away: walk
-				const unsigned want = osh == 2u ? 1u : 0u;
-				h = INF;
-				while (a < e) {
-					const unsigned w = src.spe(a);
-					if (((w >> ESH) & 1u) == want) {
-						h = ((w & PMASK) << 4) | bq;
-						break;
-					}
-					a++;
+		unsigned h = (dist != 0u && a < e) ? (((ny & PMASK) << 4) | bq) : INF;
+		if (!both && dist == 7u && h != INF) {
+			// seven or more slots away: the entry at slot + 7 need not be the one -- walk
+			const unsigned want = osh == 2u ? 1u : 0u;
+			h = INF;
+			while (a < e) {
+				const unsigned y = src.link(a);
+				if (((y >> 28) & 1u) == want) {
+					h = ((y & PMASK) << 4) | bq;
+					break;
 				}
+				a++;
 			}
 		}
-		s_ce[bq][threadIdx.x].x = a;
+		Src::cur_set(ce, a);
+		s_ce[bq][threadIdx.x] = ce;
 #pragma unroll
 		for (int q = 0; q < NL; q++) head[q] = (bq == (unsigned)q) ? h : head[q];
 		// corner of this node as seen from the particle: offset - e along the shifted axis, the offset itself elsewhere
@@ -463,7 +489,7 @@ __device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, co
 		} else {
 			int dd[3];
 			constexpr int a1 = (MODE + 1) % 3, a2 = (MODE + 2) % 3;
-			dd[MODE] = (int)osh - (int)(lk.y & 1u);
+			dd[MODE] = (int)osh - (int)((lk >> 28) & 1u);
 			dd[a1] = (meta >> 2) & 1;
 			dd[a2] = (meta >> 3) & 1;
 			pd0 = dd[0]; pd1 = dd[1]; pd2 = dd[2];
@@ -481,18 +507,15 @@ __device__ __forceinline__ void merge_node(const Dim& d, int i, int j, int k, co
 }
 
 // one thread per node; a wave owns a compact GX x GY x GZ tile of nodes, so that the runs its 64 merges walk (a cell's run feeds up
-// to 12 nodes of the tile) are pulled into the CU's L1 once.  (Tried and dropped, both bit-exact: a workgroup copying the runs of
-// its tile's neighbourhood into LDS first -- 79 KB per 128 nodes leave one wave per SIMD, and a lone wave needs ~2000 cycles per
-// contribution for this chain: 0.61 ms per component against 0.39 ms; and rec + link as ONE 32-byte record, one cache line per
-// contribution: the gathers go from 0.35 to 0.325 ms, the two payload kernels from 0.13 to 0.31 ms.)  Where the time goes (PMC,
-// 128^3, 3.8 M particles, one component): 1.7 M load instructions touch 67 M cache lines, 17 % of them L1 hits -- the merges of
-// the ~15 waves of a CU walk ~30 KB of runs each, far more than its 32 KB L1 -- so the kernel runs at the L2 -> L1 request rate.
+// to 12 nodes of the tile) are pulled into the CU's L1 once.  Lists read from global memory: 2-D grids, Vec3 sources, and the
+// fallback of k_gather_wave.
 constexpr int GBLOCK = 64, GX = 4, GY = 4, GZ = 4;
 template <int MODE, int NCOMP>
 __global__ void __launch_bounds__(GBLOCK)
-k_gather(Dim d, int ntx, int nty, const float4* __restrict__ rec, const uint2* __restrict__ link, const float* __restrict__ sv, int64_t cp,
-         const uint32_t* __restrict__ spe, const int32_t* __restrict__ start, float* __restrict__ ref, int64_t rstride, float* __restrict__ sum) {
-	__shared__ uint2 s_ce[(MODE == 3) ? 8 : 12][GBLOCK];       // {cursor, end | offsets << PBITS}
+k_gather(Dim d, int ntx, int nty, const float4* __restrict__ rec, const uint32_t* __restrict__ link, const float* __restrict__ sv, int64_t cp,
+         const int32_t* __restrict__ start, float* __restrict__ ref, int64_t rstride, float* __restrict__ sum) {
+	__shared__ SrcGlobal::Cursor s_ce[(MODE == 3) ? 8 : 12][GBLOCK];
+	__shared__ int s_delta[(MODE == 3) ? 8 : 12][GBLOCK];
 	const int tile = xcd_swizzle(blockIdx.x, gridDim.x), t = threadIdx.x;
 	const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
 	// 2-D grids: the tile is GX*GZ x GY x 1
@@ -500,8 +523,125 @@ k_gather(Dim d, int ntx, int nty, const float4* __restrict__ rec, const uint2* _
 	const int j = d.is3d ? ty * GY + (t / GX) % GY : ty * GY + t / (GX * GZ);
 	const int k = d.is3d ? tz * GZ + t / (GX * GY) : 0;
 	if (i >= d.sx || j >= d.sy || k >= d.sz) return;
-	const SrcGlobal src{rec, link, sv, cp, spe, start, d.sx, d.sy};
-	merge_node<MODE, NCOMP, GBLOCK>(d, i, j, k, src, s_ce, ref, rstride, sum);
+	const SrcGlobal src{rec, link, sv, cp, start, d.sx, d.sy};
+	merge_node<MODE, NCOMP, GBLOCK>(d, i, j, k, src, s_ce, s_delta, ref, rstride, sum);
+}
+
+// 3-D grids, one value per particle: the wave first copies the link words of every cell its 64 nodes reach -- (GX + 2) x (GY + 1) x
+// (GZ + 1) cells for the X component, each row of cells one contiguous piece of the sorted arrays -- into LDS (6 KB; with the
+// cursors 16 KB per wave: 10 waves per CU -- the merge is a serial chain per node, only more waves per SIMD hide its latencies), so that the chain  minimum -> cursor -> link -> next head  never leaves the CU; only the
+// record of a contribution (off the chain, consumed one iteration later) comes from global memory.  With the links in global
+// memory every contribution pulls its own cache line: 67 M lines for 1.7 M load instructions per component at 128^3 / 3.8 M
+// particles, 17 % L1 hits -- the kernel ran at the L2 -> L1 request rate.  (Round 3 also tried a 128-node workgroup staging records
+// AND links, 79 KB: one wave per SIMD left, 0.61 ms against 0.35 ms.)  A tile whose neighbourhood holds more than WCAP particles
+// merges from global memory.
+constexpr int WCAP = 1536;
+static_assert(WCAP <= 4095, "local slots are 12-bit fields of SrcWave::Cursor");
+template <int MODE>
+__global__ void __launch_bounds__(GBLOCK)
+k_gather_wave(Dim d, int ntx, int nty, const float4* __restrict__ rec, const uint32_t* __restrict__ link, const int32_t* __restrict__ start,
+              float* __restrict__ ref, float* __restrict__ sum) {
+	constexpr int NL = (MODE == 3) ? 8 : 12;
+	constexpr int LX = (MODE == 0) ? 2 : 1, LY = (MODE == 1) ? 2 : 1, LZ = (MODE == 2) ? 2 : 1;
+	constexpr int BXN = GX + LX, BYN = GY + LY, BZN = GZ + LZ, NCELL = BXN * BYN * BZN, NROW = BYN * BZN;
+	constexpr int PER = (NCELL + GBLOCK - 1) / GBLOCK;
+	__shared__ SrcWave::Cursor s_ce[NL][GBLOCK];
+	__shared__ int s_delta[NL][GBLOCK];
+	__shared__ __attribute__((aligned(16))) uint32_t s_link[WCAP];
+	__shared__ int s_lstart[NCELL + 1], s_gstart[NCELL];
+	const int t = threadIdx.x;
+	const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+	const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+	const int x0 = tx * GX - LX, y0 = ty * GY - LY, z0 = tz * GZ - LZ;
+	// cell table: run length of every cell of the neighbourhood (0 outside the grid), exclusive scan over the wave -> local slots
+	int cnt[PER], gst[PER], tot = 0;
+#pragma unroll
+	for (int q = 0; q < PER; q++) {
+		const int idx = t * PER + q;
+		cnt[q] = 0;
+		gst[q] = 0;
+		if (idx < NCELL) {
+			const int bx = x0 + idx % BXN, by = y0 + (idx / BXN) % BYN, bz = z0 + idx / (BXN * BYN);
+			if (bx >= 0 && by >= 0 && bz >= 0 && bx < d.sx && by < d.sy && bz < d.sz) {
+				const int64_t c = (int64_t)bx + d.sx * ((int64_t)by + (int64_t)d.sy * bz);
+				gst[q] = start[c];
+				cnt[q] = start[c + 1] - gst[q];
+			}
+		}
+		tot += cnt[q];
+	}
+	int inc = tot;
+	for (int o = 1; o < 64; o <<= 1) {
+		const int u = __shfl_up(inc, o);
+		if (t >= o) inc += u;
+	}
+	const int total = __shfl(inc, 63);
+	int run = inc - tot;
+#pragma unroll
+	for (int q = 0; q < PER; q++) {
+		const int idx = t * PER + q;
+		if (idx < NCELL) {
+			s_lstart[idx] = run;
+			s_gstart[idx] = gst[q];
+		}
+		run += cnt[q];
+	}
+	if (t == 0) s_lstart[NCELL] = total;
+	__syncthreads();
+	const int i = tx * GX + (t % GX), j = ty * GY + (t / GX) % GY, k = tz * GZ + t / (GX * GY);
+	const bool inside = i < d.sx && j < d.sy && k < d.sz;
+	if (total > WCAP) {
+		if (inside) {
+			const SrcGlobal src{rec, link, nullptr, 0, start, d.sx, d.sy};
+			// the fallback's cursors hold global slots: two words each, in the space of the link copy it does not make
+			static_assert(sizeof(SrcGlobal::Cursor) * NL * GBLOCK <= sizeof(uint32_t) * WCAP, "fallback cursors alias s_link");
+			merge_node<MODE, 1, GBLOCK>(d, i, j, k, src, (SrcGlobal::Cursor(*)[GBLOCK])s_link, s_delta, ref, 0, sum);
+		}
+		return;
+	}
+	if (total == 0) {
+		if (inside) {
+			const int64_t node = (int64_t)i + d.sx * ((int64_t)j + (int64_t)d.sy * k);
+			sum[node] = 0.f;
+			ref[node] = 0.f;
+		}
+		return;
+	}
+	// the rows of the neighbourhood: cells along x are consecutive in the sorted arrays; entry t (and t + 64, ...) of RU rows per
+	// round trip
+	constexpr int RU = 8;
+	const int xin = x0 < 0 ? -x0 : 0;          // first cell of a row inside the grid (cells outside are empty)
+	for (int r0 = 0; r0 < NROW; r0 += RU) {
+		uint32_t vl[RU];
+		int dst[RU];
+#pragma unroll
+		for (int u = 0; u < RU; u++) {
+			const int r = r0 + u;
+			dst[u] = -1;
+			if (r < NROW) {
+				const int first = r * BXN;
+				const int l0 = s_lstart[first], len = s_lstart[first + BXN] - l0;
+				if (t < len) {
+					dst[u] = l0 + t;
+					vl[u] = link[s_gstart[first + xin] + t];
+				}
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < RU; u++)
+			if (dst[u] >= 0) s_link[dst[u]] = vl[u];
+	}
+	for (int r = 0; r < NROW; r++) {            // rows longer than the wave
+		const int first = r * BXN;
+		const int l0 = s_lstart[first], len = s_lstart[first + BXN] - l0;
+		const int g0 = s_gstart[first + xin];
+		for (int q = t + GBLOCK; q < len; q += GBLOCK) s_link[l0 + q] = link[g0 + q];
+	}
+	__syncthreads();
+	if (inside) {
+		const SrcWave src{rec, s_link, s_lstart, s_gstart, x0, y0, z0, BXN, BYN};
+		merge_node<MODE, 1, GBLOCK>(d, i, j, k, src, s_ce, s_delta, ref, 0, sum);
+	}
 }
 
 // ---- APIC (knApicMapLinearVec3ToMACGrid, apic.cpp:19-90): same gather, other weights.  The reference addresses the 8 nodes
@@ -658,16 +798,22 @@ int p2g_ordered_mac(const Dim& d, float* vel, float* weight, int64_t np, int64_t
 	MF_TRY((bin_particles<3>(d, np, ps, pos, pflag, ptype, exclude, s, st)));
 	const int64_t cp = s->cap_p;
 	float4* rec = (float4*)s->pay;
-	uint2* link = (uint2*)(s->pay + 12 * cp);
+	uint32_t* link = (uint32_t*)(s->pay + 12 * cp);
 	// the number of binned particles is start[n], known on the device only: the payload kernels are launched over np slots and
 	// bound themselves
 	hipLaunchKernelGGL((k_bin_payload<3>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, ps, pos, pvel, ps, s->order, true, rec, (float*)nullptr, cp, s->spe);
 	hipLaunchKernelGGL(k_bin_links, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, s->keys, s->spe, true, cp, link);
 	const int ntx = d.is3d ? (d.sx + GX - 1) / GX : (d.sx + GX * GZ - 1) / (GX * GZ), nty = (d.sy + GY - 1) / GY, ntz = d.is3d ? (d.sz + GZ - 1) / GZ : 1;
 	const unsigned nb = (unsigned)(ntx * nty * ntz);
-	hipLaunchKernelGGL((k_gather<0, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, (const float*)nullptr, cp, s->spe, s->start, vel, d.n, weight);
-	hipLaunchKernelGGL((k_gather<1, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + cp, link + cp, (const float*)nullptr, cp, s->spe, s->start, vel + d.n, d.n, weight + d.n);
-	hipLaunchKernelGGL((k_gather<2, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + 2 * cp, link + 2 * cp, (const float*)nullptr, cp, s->spe, s->start, vel + 2 * d.n, d.n, weight + 2 * d.n);
+	if (d.is3d) {
+		hipLaunchKernelGGL((k_gather_wave<0>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, s->start, vel, weight);
+		hipLaunchKernelGGL((k_gather_wave<1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + cp, link + cp, s->start, vel + d.n, weight + d.n);
+		hipLaunchKernelGGL((k_gather_wave<2>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + 2 * cp, link + 2 * cp, s->start, vel + 2 * d.n, weight + 2 * d.n);
+	} else {
+		hipLaunchKernelGGL((k_gather<0, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, (const float*)nullptr, cp, s->start, vel, d.n, weight);
+		hipLaunchKernelGGL((k_gather<1, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + cp, link + cp, (const float*)nullptr, cp, s->start, vel + d.n, d.n, weight + d.n);
+		hipLaunchKernelGGL((k_gather<2, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec + 2 * cp, link + 2 * cp, (const float*)nullptr, cp, s->start, vel + 2 * d.n, d.n, weight + 2 * d.n);
+	}
 	MF_LAUNCH_CHECK();
 	return 0;
 }
@@ -681,7 +827,7 @@ int p2g_ordered_cell(const Dim& d, int ncomp, float* target, float* wsum, int64_
 	const int64_t cp = s->cap_p;
 	float4* rec = (float4*)s->pay;
 	float* sv = s->pay + 4 * cp;                 // the second and third value plane of a Vec3 source
-	uint2* link = (uint2*)(s->pay + 12 * cp);
+	uint32_t* link = (uint32_t*)(s->pay + 12 * cp);
 	const int ntx = d.is3d ? (d.sx + GX - 1) / GX : (d.sx + GX * GZ - 1) / (GX * GZ), nty = (d.sy + GY - 1) / GY, ntz = d.is3d ? (d.sz + GZ - 1) / GZ : 1;
 	const unsigned nb = (unsigned)(ntx * nty * ntz);
 	if (ncomp == 1)
@@ -689,10 +835,12 @@ int p2g_ordered_cell(const Dim& d, int ncomp, float* target, float* wsum, int64_
 	else
 		hipLaunchKernelGGL((k_bin_payload<3>), dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, ps, pos, psrc, ps, s->order, false, rec, sv, cp, s->spe);
 	hipLaunchKernelGGL(k_bin_links, dim3(nblk_n(np)), dim3(BLOCK), 0, st, d, s->start, s->keys, s->spe, false, cp, link);
-	if (ncomp == 1)
-		hipLaunchKernelGGL((k_gather<3, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, sv, cp, s->spe, s->start, target, d.n, wsum);
+	if (ncomp == 1 && d.is3d)
+		hipLaunchKernelGGL((k_gather_wave<3>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, s->start, target, wsum);
+	else if (ncomp == 1)
+		hipLaunchKernelGGL((k_gather<3, 1>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, sv, cp, s->start, target, d.n, wsum);
 	else
-		hipLaunchKernelGGL((k_gather<3, 3>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, sv, cp, s->spe, s->start, target, d.n, wsum);
+		hipLaunchKernelGGL((k_gather<3, 3>), dim3(nb), dim3(GBLOCK), 0, st, d, ntx, nty, rec, link, sv, cp, s->start, target, d.n, wsum);
 	MF_LAUNCH_CHECK();
 	return 0;
 }
