@@ -56,67 +56,61 @@ const float kA[32] = {0.000334, -0.001528, 0.000410, 0.003545, -0.000938, -0.008
                       0.019120, 0.002172, -0.008233, -0.000938, 0.003546, 0.000410, -0.001528, 0.000334};
 const float kP[4] = {0.25, 0.75, 0.75, 0.25};
 
-// WaveletNoiseField::downsample / upsample, noisefield.cpp:42-63 (the up-sampling sum is formed in double and rounded
-// back to float after every term, exactly as `to[i] += 0.5 * pp[..] * from[..]` does with Real = float)
-void downsample(const float* from, float* to, int n, int stride) {
-	const float* a = &kA[16];
-	for (int i = 0; i < n / 2; i++) {
-		float acc = 0;
-		for (int k = 2 * i - 16; k < 2 * i + 16; k++) acc += a[k - 2 * i] * from[(k & 127) * stride];
-		to[i * stride] = acc;
+// The wavelet noise tile (WaveletNoiseField::generateTile, noisefield.cpp:95-186; Cook & DeRose 2005): Gaussian noise minus its
+// coarse part, i.e. minus what survives "analyse + decimate, then synthesise" along x, then y, then z -- plus a shifted copy of the
+// result to decorrelate it.  Host set-up code; the bits matter (the tile is scene input), so every sum keeps the reference's order
+// and precision: the analysis sum is an fp32 accumulation over the 32 taps in ascending order (noisefield.cpp:42-50), the synthesis sum
+// adds `0.5 * p * sample` in double and rounds to fp32 after every term (:52-63).
+constexpr int TILE_N = 128, TILE_H = TILE_N / 2;
+
+// coarse part of one periodic line of TILE_N samples, in place (`line[q * stride]`)
+static void line_keep_coarse(float* line, int stride) {
+	float half[TILE_H];
+	for (int q = 0; q < TILE_H; q++) {                      // analysis filter centred between samples 2q - 1 and 2q, decimated
+		float sum = 0;
+		for (int tap = -16; tap < 16; tap++) sum += kA[16 + tap] * line[((2 * q + tap) & (TILE_N - 1)) * stride];
+		half[q] = sum;
 	}
-}
-void upsample(const float* from, float* to, int n, int stride) {
-	const float* pp = &kP[1];
-	const int h = n / 2;
-	for (int i = 0; i < n; i++) {
-		float acc = 0;
-		for (int k = i / 2 - 1; k < i / 2 + 3; k++) {
-			int m = k % h;
-			if (m < 0) m += h;
-			acc = (float)((double)acc + 0.5 * (double)pp[k - i / 2] * (double)from[m * stride]);
+	float full[TILE_N];
+	for (int q = 0; q < TILE_N; q++) {                      // synthesis: four taps {0.25, 0.75, 0.75, 0.25} around q / 2
+		float sum = 0;
+		for (int tap = -1; tap < 3; tap++) {
+			const int src = ((q / 2 + tap) % TILE_H + TILE_H) % TILE_H;
+			sum = (float)((double)sum + 0.5 * (double)kP[1 + tap - 0] * (double)half[src]);
 		}
-		to[i * stride] = acc;
+		full[q] = sum;
 	}
+	for (int q = 0; q < TILE_N; q++) line[q * stride] = full[q];
 }
-// WaveletNoiseField::generateTile, noisefield.cpp:95-186
-void generate_tile(float* noise3, int seed) {
-	const int n = 128;
-	const int64_t n3 = (int64_t)n * n * n, n3d = 3 * n3;
-	std::vector<float> t1(n3d, 0.f), t2(n3d, 0.f);
-	float* temp13 = t1.data();
-	float* temp23 = t2.data();
+void generate_tile(float* tile3, int seed) {
+	const int64_t plane = (int64_t)TILE_N * TILE_N, vol = plane * TILE_N, total = 3 * vol;
 	MTRand mt((uint32_t)seed);
-	for (int64_t i = 0; i < n3d; i++) noise3[i] = (float)mt.randNorm(0.0, 1.0);
-	for (int t = 0; t < 3; t++) {
-		for (int iy = 0; iy < n; iy++)
-			for (int iz = 0; iz < n; iz++) {
-				const int64_t i = iy * n + (int64_t)iz * n * n + t * n3;
-				downsample(&noise3[i], &temp13[i], n, 1);
-				upsample(&temp13[i], &temp23[i], n, 1);
-			}
-		for (int ix = 0; ix < n; ix++)
-			for (int iz = 0; iz < n; iz++) {
-				const int64_t i = ix + (int64_t)iz * n * n + t * n3;
-				downsample(&temp23[i], &temp13[i], n, n);
-				upsample(&temp13[i], &temp23[i], n, n);
-			}
-		for (int ix = 0; ix < n; ix++)
-			for (int iy = 0; iy < n; iy++) {
-				const int64_t i = ix + iy * n + t * n3;
-				downsample(&temp23[i], &temp13[i], n, n * n);
-				upsample(&temp13[i], &temp23[i], n, n * n);
-			}
+	for (int64_t q = 0; q < total; q++) tile3[q] = (float)mt.randNorm(0.0, 1.0);
+	std::vector<float> coarse(tile3, tile3 + total);
+	// along x, then y, then z: every line of the three component volumes; `first` = index of a line's first sample
+	const int64_t strides[3] = {1, TILE_N, plane};
+	for (int comp = 0; comp < 3; comp++)
+		for (int axis = 0; axis < 3; axis++) {
+			const int64_t su = strides[(axis + 1) % 3], sv = strides[(axis + 2) % 3];
+			for (int u = 0; u < TILE_N; u++)
+				for (int v = 0; v < TILE_N; v++) line_keep_coarse(coarse.data() + comp * vol + u * su + v * sv, (int)strides[axis]);
+		}
+	std::vector<float> detail(total);
+	for (int64_t q = 0; q < total; q++) {
+		tile3[q] -= coarse[q];
+		detail[q] = tile3[q];
 	}
-	for (int64_t i = 0; i < n3d; i++) noise3[i] -= temp23[i];
-	const int offset = 65;   // n/2, made odd (noisefield.cpp:161-162)
-	int64_t icnt = 0;
-	for (int t = 0; t < 3; t++)
-		for (int ix = 0; ix < n; ix++)
-			for (int iy = 0; iy < n; iy++)
-				for (int iz = 0; iz < n; iz++)
-					temp13[icnt++] = noise3[((ix + offset) & 127) + ((iy + offset) & 127) * n + (int64_t)((iz + offset) & 127) * n * n + t * n3];
-	for (int64_t i = 0; i < n3d; i++) noise3[i] += temp13[i];
+	// the decorrelating copy: the sample stored at (slow, mid, fast) = (a, b, c) receives the detail at x = a + 65, y = b + 65,
+	// z = c + 65 (an odd offset; the reference fills its temporary in (x, y, z) loop order and adds it linearly -- a transposed
+	// shifted copy, noisefield.cpp:161-177)
+	const int shift = TILE_H + 1;
+	for (int comp = 0; comp < 3; comp++)
+		for (int a = 0; a < TILE_N; a++)
+			for (int b = 0; b < TILE_N; b++)
+				for (int c = 0; c < TILE_N; c++) {
+					const int x = (a + shift) & (TILE_N - 1), y = (b + shift) & (TILE_N - 1), z = (c + shift) & (TILE_N - 1);
+					tile3[comp * vol + a * plane + b * TILE_N + c] += detail[comp * vol + x + y * TILE_N + z * plane];
+				}
 }
 
 struct NoiseParams {

@@ -85,7 +85,8 @@ def test_dam_break_loop_two_ranks_on_hip(tmp_path):
 def test_wavelet_turbulence_loop_two_ranks_on_hip(tmp_path):
     """BASELINE config 5 on slabs: the up-res loop of waveletTurbulence.py (coarse + 2x fine solver on the same z-ranges) through
     the HIP library, 2 ranks on the one GPU vs 1 rank (bit-exact before the first solve), and the single-rank HIP run against the
-    oracle's (every field bit-exact up to the solve; identical CG iteration counts, fields within 1e-5 after)"""
+    oracle's (every field bit-exact up to the solve; identical CG iteration counts; after the solves at most 0.1 % of the cells beyond 1e-5 --
+    clamp selections flipping, see below)"""
     gs = (24, 32, 32)
     single = run_wavelet_world(tmp_path, 1, "hip", gs=gs)
     multi = run_wavelet_world(tmp_path, 2, "hip", gs=gs)
@@ -94,6 +95,10 @@ def test_wavelet_turbulence_loop_two_ranks_on_hip(tmp_path):
     assert single["iters"] == ora["iters"]
     for k in ("vel_pre0", "dens_pre0", "energy0", "xl_vel0", "xl_dens0"):
         util.assert_bitexact(single[k], ora[k], k + " hip vs oracle")
+    # after the solves the bar is NOT "every cell within 1e-5": the MacCormack clamp (clampMode 2) is a selection -- it reverts a cell to
+    # the first-order value when the corrected value leaves the [min, max] of its 8 corner cells -- so a <= 1e-5 difference of the
+    # pressure-projected velocity can flip single cells between two values that differ by far more.  Stated bar: at most
+    # 0.1 % of the cells beyond 1e-5 of the field's scale, every other cell within it.
     for k in ("dens", "vel", "energy", "xl_dens", "xl_vel"):
         d = np.abs(single[k] - ora[k])
         scale = max(np.abs(ora[k]).max(), 1e-3)
