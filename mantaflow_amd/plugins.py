@@ -324,13 +324,22 @@ def solvePressure(vel, pressure, flags, cgAccuracy=1e-3, phi=None, perCellCorr=N
         rhs, residual, search, tmp, pca0 = (_scratch_grid(s) for _ in range(5))
         maxIter = int(np.float32(cgMaxIterFac) * np.float32(max(sx, sy, sz)))        # pressure.cpp:410 (3D)
         out = (ctypes.c_float * 3)()
-        s.lib.call("mf_solve_pressure_fused", sx, sy, sz, flags.ptr, vel.ptr, pressure.ptr, rhs.ptr, residual.ptr, search.ptr, tmp.ptr,
-                   pca0.ptr, float(cgAccuracy), int(maxIter), int(bool(useL2Norm)), out, s.stream)
-        _last_cg["iterations"], _last_cg["residual"] = int(out[0]), float(out[1])
-        correctVelocity(vel, pressure, flags, notiming=True)
-        if retRhs is not None and not (isinstance(retRhs, int) and retRhs == 0):
-            _chk(retRhs, Grid, "Grid<Real>").copyFrom(rhs)
-        return
+        took = True
+        try:
+            s.lib.call("mf_solve_pressure_fused", sx, sy, sz, flags.ptr, vel.ptr, pressure.ptr, rhs.ptr, residual.ptr, search.ptr, tmp.ptr,
+                       pca0.ptr, float(cgAccuracy), int(maxIter), int(bool(useL2Norm)), out, s.stream)
+        except RuntimeError as e:
+            # the library declines before it touches anything (e.g. mf_set_mic_mode("levels")): the three-call path below
+            if not str(e).startswith("mf_solve_pressure_fused: needs"):
+                raise
+            took = False
+        if took:
+            _last_cg["iterations"], _last_cg["residual"] = int(out[0]), float(out[1])
+            correctVelocity(vel, pressure, flags, notiming=True)
+            if retRhs is not None and not (isinstance(retRhs, int) and retRhs == 0):
+                _chk(retRhs, Grid, "Grid<Real>").copyFrom(rhs)
+            return
+        del rhs, residual, search, tmp, pca0
     rhs = Grid(vel.parent)
     common = dict(cgAccuracy=cgAccuracy, phi=phi, perCellCorr=perCellCorr, fractions=fractions, gfClamp=gfClamp,
                   cgMaxIterFac=cgMaxIterFac, precondition=precondition, preconditioner=preconditioner,

@@ -334,6 +334,33 @@ def test_solve_pressure_vs_reference(hip_backend, dims, liquid):
     _close(a["vel"], b["vel"], "vel")
 
 
+def test_solve_pressure_plain_system_paths(hip, hip_backend):
+    """solvePressure on a plain system takes mf_solve_pressure_fused (matrix-free set-up) when the rows are a multiple of 8 cells and the
+    "rows" sweeps are on; with mf_set_mic_mode("levels") the library declines and the plugin falls back to mf_make_rhs +
+    mf_make_laplace_matrix + mf_cg_solve.  Both against the oracle: rhs bit-exact, same iteration count, fields within 1e-5 -- and
+    the two GPU paths agree bit for bit on rhs and in iteration count."""
+    from mantaflow_amd import _lib, plugins
+    dims = (32, 24, 16)
+    flags, vel, _ = cases.pressure_inputs(dims, 21, False)
+    a = cases.run_solve_pressure_pkg(dims, flags, vel, None)
+    it_a = plugins.lastCgStats()["iterations"]
+    assert hip.lib.cdll.mf_set_mic_mode(b"levels") == 0
+    try:
+        c = cases.run_solve_pressure_pkg(dims, flags, vel, None)
+        it_c = plugins.lastCgStats()["iterations"]
+    finally:
+        assert hip.lib.cdll.mf_set_mic_mode(None) == 0
+    _lib.use_library(util.build_oracle(), "cpu")
+    b = cases.run_solve_pressure_pkg(dims, flags, vel, None)
+    it_b = plugins.lastCgStats()["iterations"]
+    _lib.reset()
+    assert it_a == it_b == it_c and it_b > 3, (it_a, it_b, it_c)
+    for got in (a, c):
+        assert_bitexact(got["rhs"], b["rhs"], "rhs")
+        _close(got["pressure"], b["pressure"], "pressure")
+        _close(got["vel"], b["vel"], "vel")
+
+
 @pytest.mark.parametrize("terms,liquid", cases.PRESSURE_OPTIONAL_CASES)
 @pytest.mark.parametrize("dims", [(24, 20, 16), cases.SIZE_2D])
 def test_solve_pressure_optional_terms(hip_backend, dims, terms, liquid):
