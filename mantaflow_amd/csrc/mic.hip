@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
+#include <vector>
 
 using namespace mf;
 
@@ -399,9 +400,13 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		const int64_t sid = ((int64_t)xb * nbk + tkl) * nbj + tjl;
 		// A bundle without fluid cells (bempty, k_bundle_empty) is not swept: its cells pass through unchanged and everything it
 		// would hand to its neighbours multiplies a zero coefficient there, so neighbours neither wait for it nor publish to it.
+		// (Its share of the fused dot(dst, var1) comes from k_mic_empty_dot, launched next to the backward sweep: summed here -- a lane
+		// per row, 384 strided loads each -- it kept a workgroup off the ticket queue for tens of microseconds per empty bundle, and a
+		// liquid scene has hundreds of them: the backward sweep of the 379 x 356 x 124 dam break took 166 us against 103 us forward.)
+		// Where every workgroup draws one ticket only (nstreams <= gridDim.x) nobody waits for this workgroup, and the sum stays here (one
+		// launch less per iteration: 128^3).
 		if (bempty && bempty[tk * nbj + tj]) {
-			if (MODE == 2 && with_dot && wave == 0) {
-				// its share of dot(dst, var1), summed like the write-back wave sums it (x descending, then the butterfly)
+			if (MODE == 2 && with_dot && wave == 0 && nstreams <= (int)gridDim.x) {
 				double dacc = 0.0;
 				if (row_in)
 					for (int x = xlim - 1; x >= 0; x--) dacc += (double)(dst[rowbase + x] * var1[rowbase + x]);
@@ -1131,6 +1136,30 @@ k_bundle_empty(Dim d, int nbj, const int32_t* __restrict__ flags, const float* _
 	}
 }
 
+// dot(dst, var1) share of the bundles the backward sweep leaves out (dotpart[sid] of an empty bundle; the sweep writes the others): one
+// workgroup per bundle and x-block, lanes along x (coalesced), rows in order, block_sum -- a fixed order, so the same bits on every
+// run.  (In a pressure solve the share is exactly +0: the residual vanishes outside the fluid.)
+__global__ void __launch_bounds__(BLOCK)
+k_mic_empty_dot(Dim d, int nbj, int nbk, int X8, const int* __restrict__ bempty, const float* __restrict__ dst, const float* __restrict__ var1,
+                const CgScalars* __restrict__ sc, double* __restrict__ dotpart) {
+	if (sc && sc->done) return;
+	const int sid = blockIdx.x;
+	const int tjl = sid % nbj, tkl = (sid / nbj) % nbk, xb = sid / (nbj * nbk);
+	const int tj = nbj - 1 - tjl, tk = nbk - 1 - tkl;          // the backward sweep's logical -> physical bundle
+	if (!bempty[tk * nbj + tj]) return;
+	const int xoff = xb * X8;
+	const int xlim = d.sx - xoff < X8 ? d.sx - xoff : X8;
+	double acc = 0.0;
+	for (int r = threadIdx.x >> 6; r < 64; r += BLOCK / 64) {
+		const int j = tj * 8 + (r & 7), k = tk * 8 + (r >> 3);
+		if (j >= d.sy || k >= d.sz) continue;
+		const int64_t rowbase = d.Y * j + d.Z * k + xoff;
+		for (int x = threadIdx.x & 63; x < xlim; x += 64) acc += (double)(dst[rowbase + x] * var1[rowbase + x]);
+	}
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) dotpart[sid] = acc;
+}
+
 // The system handle of the sweeps (per device; built by mf_mic_init_blocked / mf_pack_matrix, used by the apply sweeps of the
 // grids it was built for): sweep mode, preconditioner blocks, bundle order, hand-off buffers, packed operands, empty-bundle map.
 struct FlowState {
@@ -1144,6 +1173,7 @@ struct FlowState {
 	// it was given, used by the apply sweeps only when they are given the same grids
 	int* bempty = nullptr;
 	int bempty_cap = 0;
+	int nempty_host = -1;        // number of empty bundles of the registered system as the host knows it (-1: not read back yet)
 	const void *be_flags = nullptr, *be_Ap = nullptr, *be_Aj = nullptr, *be_Ak = nullptr;
 	// preconditioner blocks of the system mf_mic_init_blocked was given (0 = uncut): the apply sweeps use them only when they
 	// are called with the same flags / Aprecond / Aj / Ak (be_*), any other system is swept as the uncut reference algorithm
@@ -1332,6 +1362,20 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			const unsigned char* pk = use_pack ? f->pack : nullptr;
 			double* dotp = (MODE == 2 && al16(var1) && f->nblocks <= MAX_BLOCKS) ? g_dot_request : nullptr;
 			g_dot_count = dotp ? f->nblocks : 0;
+			if (MODE == 2 && dotp && be && f->nblocks > grid) {
+				if (f->nempty_host < 0) {
+					// once per system: does any bundle sit out the sweeps?  (smoke scenes: none -- no extra launch per iteration)
+					static thread_local std::vector<int> hb;
+					hb.resize((size_t)f->nbj * f->nbk);
+					MF_HIP(hipMemcpyAsync(hb.data(), f->bempty, sizeof(int) * hb.size(), hipMemcpyDeviceToHost, st));
+					MF_HIP(hipStreamSynchronize(st));
+					int cnt = 0;
+					for (int v : hb) cnt += v != 0;
+					f->nempty_host = cnt;
+				}
+				if (f->nempty_host > 0 && f->nblocks > grid)
+					hipLaunchKernelGGL(k_mic_empty_dot, dim3(f->nblocks), dim3(BLOCK), 0, st, d, f->nbj, f->nbk, f->nchunks * 8, be, dst, var1, sc, dotp);
+			}
 			if (vec)
 				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok);
 			else
@@ -1457,6 +1501,7 @@ int mic_fused_finish(const Dim& d, const int32_t* flags, float* Aprecond, hipStr
 	f->be_flags = flags;
 	f->be_Ap = Aprecond;
 	f->be_Aj = f->be_Ak = nullptr;
+	f->nempty_host = -1;
 	f->pk_flags = flags;
 	f->pk_A0 = f->pk_Ai = f->pk_Aj = f->pk_Ak = nullptr;
 	return 0;
@@ -1513,6 +1558,7 @@ int mf_mic_init_blocked(int sx, int sy, int sz, const int32_t* flags, float* Apr
 	f->be_Ap = Aprecond;
 	f->be_Aj = Aj;
 	f->be_Ak = Ak;
+	f->nempty_host = -1;
 	// packed operands for the apply sweeps
 	if ((size_t)d.n > f->pack_cap) {
 		MF_HIP(hipStreamSynchronize(st));
