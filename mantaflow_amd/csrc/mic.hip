@@ -325,7 +325,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
            const CgScalars* __restrict__ sc, double* __restrict__ dotpart, const int* __restrict__ bempty,
-           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok) {
+           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok, int empty_ext) {
+	// empty_ext: the dot shares of the bundles left out are summed by the caller's residual update (mf_cg_solve) -- their entries are 0
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
 	// write-back wave, one partial per bundle (and x-block) at dotpart[sid] -- the sum the PCG needs right after this sweep
@@ -406,7 +407,9 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		// Where every workgroup draws one ticket only (nstreams <= gridDim.x) nobody waits for this workgroup, and the sum stays here (one
 		// launch less per iteration: 128^3).
 		if (bempty && bempty[tk * nbj + tj]) {
-			if (MODE == 2 && with_dot && wave == 0 && nstreams <= (int)gridDim.x) {
+			if (MODE == 2 && with_dot && wave == 0 && empty_ext) {
+				if (lane == 0) dotpart[sid] = 0.0;
+			} else if (MODE == 2 && with_dot && wave == 0 && nstreams <= (int)gridDim.x) {
 				double dacc = 0.0;
 				if (row_in)
 					for (int x = xlim - 1; x >= 0; x--) dacc += (double)(dst[rowbase + x] * var1[rowbase + x]);
@@ -1327,6 +1330,7 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 // set by mic_launch_dot for the duration of one backward-sweep launch
 static thread_local double* g_dot_request = nullptr;
 static thread_local int g_dot_count = 0;
+static thread_local bool g_dot_empty_ext = false;
 template <int MODE>
 static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                       const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
@@ -1362,7 +1366,8 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 			const unsigned char* pk = use_pack ? f->pack : nullptr;
 			double* dotp = (MODE == 2 && al16(var1) && f->nblocks <= MAX_BLOCKS) ? g_dot_request : nullptr;
 			g_dot_count = dotp ? f->nblocks : 0;
-			if (MODE == 2 && dotp && be && f->nblocks > grid) {
+			const int empty_ext = (MODE == 2 && dotp && be && g_dot_empty_ext) ? 1 : 0;
+			if (MODE == 2 && dotp && be && f->nblocks > grid && !empty_ext) {
 				if (f->nempty_host < 0) {
 					// once per system: does any bundle sit out the sweeps?  (smoke scenes: none -- no extra launch per iteration)
 					static thread_local std::vector<int> hb;
@@ -1377,9 +1382,9 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 					hipLaunchKernelGGL(k_mic_empty_dot, dim3(f->nblocks), dim3(BLOCK), 0, st, d, f->nbj, f->nbk, f->nchunks * 8, be, dst, var1, sc, dotp);
 			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
@@ -1405,11 +1410,13 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 // backward sweep with GridDotProduct(dst, var1) fused: *ndot = number of partials written to dotpart (0: not fused in
 // this mode -- the caller runs its own dot kernel)
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
-                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st) {
+                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext) {
 	g_dot_request = dotpart;
+	g_dot_empty_ext = empty_ext;
 	g_dot_count = 0;
 	const int rc = launch_mic<2>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
 	g_dot_request = nullptr;
+	g_dot_empty_ext = false;
 	*ndot = g_dot_count;
 	return rc;
 }
@@ -1430,6 +1437,35 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const fl
 	MF_HIP(hipStreamSynchronize(st));
 	if (ok[0]) *pack = f.pack;
 	*a0_packed = ok[0] && ok[1] && f.pk_A0 == A0 && A0 != nullptr;
+	return 0;
+}
+// the empty-bundle map of the system registered for (flags, Ap, Aj, Ak) in "rows" mode, if that system has empty bundles and its sweeps
+// draw several tickets per workgroup (then the shares of those bundles in the fused dot are worth summing elsewhere): one small read-back
+// per system.  *bempty = nullptr otherwise.
+int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st) {
+	*bempty = nullptr;
+	*nbj = 0;
+	int dev = 0;
+	MF_HIP(hipGetDevice(&dev));
+	FlowState& f = g_flow[dev];
+	if (!d.is3d || f.mode != 2 || !f.bempty || f.be_flags != flags || f.be_Ap != Ap || f.be_Aj != Aj || f.be_Ak != Ak) return 0;
+	if (f.nbj != (d.sy + 7) / 8 || f.nbk != (d.sz + 7) / 8 || f.nxb != 1) return 0;
+	int ncu = 256;
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+	if (f.nblocks <= ncu) return 0;
+	if (f.nempty_host < 0) {
+		static thread_local std::vector<int> hb;
+		hb.resize((size_t)f.nbj * f.nbk);
+		MF_HIP(hipMemcpyAsync(hb.data(), f.bempty, sizeof(int) * hb.size(), hipMemcpyDeviceToHost, st));
+		MF_HIP(hipStreamSynchronize(st));
+		int cnt = 0;
+		for (int v : hb) cnt += v != 0;
+		f.nempty_host = cnt;
+	}
+	if (f.nempty_host > 0) {
+		*bempty = f.bempty;
+		*nbj = f.nbj;
+	}
 	return 0;
 }
 // packed bytes built by mf_pack_matrix for exactly these grids (no synchronisation: the verdict was read when they were built)

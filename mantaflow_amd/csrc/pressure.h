@@ -18,7 +18,9 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 // backward substitution with GridDotProduct(dst, var1) fused into the sweep ("rows" mode): *ndot partials in dotpart, summed in
 // index order by the caller; *ndot == 0 when the active mode cannot fuse it (the caller then runs its own dot kernel)
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
-                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st);
+                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext = false);
+// empty_ext: the caller sums the shares of the bundles the sweep leaves out itself (mic_empty_map tells which), their entries come out 0
+int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st);
 // packed {fluid, Ai, Aj, Ak} bytes built by the last mf_mic_init for exactly these grids (nullptr when unavailable / not exact);
 // synchronises the stream once.  *a0_packed: bits 4-7 of every byte hold the (small integer) diagonal A0 of these grids as well
 int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak,

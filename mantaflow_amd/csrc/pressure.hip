@@ -648,15 +648,20 @@ __global__ void __launch_bounds__(BLOCK) k_cg_alpha(CgScalars* sc, int nb, const
 // (Folding this pass into the loader waves of the forward MIC sweep -- they read residual and tmp anyway -- was built and measured:
 // bit-exact, the 30 us of this kernel go away and the sweep gets 21 us slower (its middle third already streams ~4 TB/s): 75.5 ms per
 // 256^3 step either way.  Not kept.)
-template <bool COPY_TMP>
+// EDOT (liquid scenes): the MIC sweeps leave bundles of rows without fluid out, so tmp is in those cells what it is here and their share
+// of dot(M^-1 r, r) = sum tmp * r_new can be formed in this pass, which streams both anyway (bempty / nbj: mic_empty_map; sx % 4 == 0,
+// so a quad lies in one row); the shares go to epart[block] and are appended to the sweep's partials (whose entries for those bundles
+// are 0).  A kernel of its own for them cost 33 us per iteration in the 379 x 356 x 124 dam break.
+template <bool COPY_TMP, bool EDOT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart,
-            double* __restrict__ dpart) {
+            double* __restrict__ dpart, const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0,
+            double* __restrict__ epart = nullptr) {
 	if (sc->done) return;
 	const float nalpha = sc->nalpha;
 	const bool l2 = sc->useL2 != 0;
 	float lo = FLT_MAX, hi = -FLT_MAX;
-	double ss = 0.0;
+	double ss = 0.0, es = 0.0;
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
 		float4 r = ((float4*)residual)[q];
@@ -664,6 +669,16 @@ k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ res
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		if (COPY_TMP) ((float4*)tmp)[q] = r;
+		if (EDOT) {
+			const int64_t row = (4 * q) / sx;
+			const int j = (int)(row % sy), k = (int)(row / sy);
+			if (bempty[(k >> 3) * nbj + (j >> 3)]) {
+				es += (double)(t.x * r.x);
+				es += (double)(t.y * r.y);
+				es += (double)(t.z * r.z);
+				es += (double)(t.w * r.w);
+			}
+		}
 		if (l2) {
 			ss += (double)r.x * (double)r.x;
 			ss += (double)r.y * (double)r.y;
@@ -692,6 +707,11 @@ k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ res
 			fpart[2 * blockIdx.x] = lo;
 			fpart[2 * blockIdx.x + 1] = hi;
 		}
+	}
+	if (EDOT) {
+		__syncthreads();
+		es = block_sum(es);
+		if (threadIdx.x == 0) epart[blockIdx.x] = es;
 	}
 }
 // dst += alpha*search ; residual += (-alpha)*tmp ; [PC_NONE: tmp = residual] ; partial min/max (or sum of
@@ -1273,6 +1293,11 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	// ---- iterate, conjugategrad.cpp:238-299; the host only polls `done`, one batch behind the batch it has just queued
 	// (every kernel of an iteration returns at once when `done` is already set, so running ahead costs a few empty
 	// launches after convergence and keeps the GPU from idling between iterations) ----
+	// liquid scenes whose sweeps leave bundles out: their dot shares ride on the residual update (k_cg_axpy_r<.., EDOT>)
+	const int* be_map = nullptr;
+	int be_nbj = 0;
+	if (pc == MF_PC_MICP && (sx % 4) == 0) MF_TRY(mic_empty_map(d, flags, Aprecond, Aj, Ak, &be_map, &be_nbj, st));
+	const int be_nb = ((sy + 7) / 8) * ((sz + 7) / 8);      // the sweep's partials (one per bundle) come first, the nbs of the residual update behind them
 	const int batch = (pc == MF_PC_MICP && mic_mode() == 0) ? 1 : 4;
 	CgScalars h;
 	memset(&h, 0, sizeof h);
@@ -1295,10 +1320,18 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
-				hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
+				if (be_map)
+					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, be_map, be_nbj, sx, sy, p_sig + be_nb);
+				else
+					hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
-				// sigma_new = dot(tmp, residual) comes out of the backward sweep's write-back (one partial per row bundle)
-				MF_TRY(mic_launch_dot(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, p_sig, &nsig, st));
+				// sigma_new = dot(tmp, residual) comes out of the backward sweep's write-back (one partial per row bundle); the shares of
+				// the bundles the sweeps leave out: from the residual update above, behind the sweep's partials
+				MF_TRY(mic_launch_dot(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, p_sig, &nsig, st, be_map != nullptr));
+				if (be_map) {
+					if (nsig != be_nb) return fail("mf_cg_solve: the backward sweep wrote %d dot partials, %d expected", nsig, be_nb);
+					nsig += nbs;
+				}
 			} else {
 				hipLaunchKernelGGL((k_cg_axpy_r<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 			}
