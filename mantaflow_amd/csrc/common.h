@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "../../include/manta_hip.h"
+#include <float.h>
 
 namespace mf {
 
@@ -159,6 +160,75 @@ __device__ __forceinline__ void block_minmax(float& lo, float& hi) {
 		for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
 			lo = fminf(lo, shl[i]);
 			hi = fmaxf(hi, shh[i]);
+		}
+	}
+}
+
+// ---- partials that another workgroup of the SAME launch folds (the beta step as the tail of the backward MIC sweep): written with
+// one agent-scope (sc1, write-through) store whose completion the writer waits for before its workgroup reports in, read with
+// agent-scope (sc1) loads -- the protocol of the sweeps' face granules, no fence
+__device__ __forceinline__ void part_store(double* p, double v) {
+	__hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ double part_load(const double* p) {
+	return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// strided_sum + block_sum of a 256-thread block, executed by threads 0..255 of a workgroup of any size (every thread calls: barriers);
+// result valid in thread 0.  SC1: the partials are of this launch (part_store)
+template <bool SC1>
+__device__ __forceinline__ double tail_sum256(const double* p, int nb) {
+	__shared__ double sh_t[4];
+	const int tid = threadIdx.x;
+	double acc = 0.0;
+	if (tid < 256) {
+		int i = tid;
+		const int S = 256;
+		for (; i + 7 * S < nb; i += 8 * S) {
+			double v[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) v[q] = SC1 ? part_load(p + i + q * S) : p[i + q * S];
+#pragma unroll
+			for (int q = 0; q < 8; q++) acc += v[q];
+		}
+		for (; i < nb; i += S) acc += SC1 ? part_load(p + i) : p[i];
+		acc = wave_sum(acc);
+	}
+	__syncthreads();
+	if (tid < 256 && (tid & 63) == 0) sh_t[tid >> 6] = acc;
+	__syncthreads();
+	if (tid == 0) {
+		acc = sh_t[0];
+		for (int q = 1; q < 4; q++) acc += sh_t[q];
+	}
+	return acc;
+}
+// the min / max fold of block_minmax over fpart[2 * i], fpart[2 * i + 1] as a 256-thread block does it; valid in thread 0
+__device__ __forceinline__ void tail_minmax256(const float* fpart, int nb, float& lo, float& hi) {
+	__shared__ float shl_t[4], shh_t[4];
+	const int tid = threadIdx.x;
+	lo = FLT_MAX;
+	hi = -FLT_MAX;
+	if (tid < 256) {
+		for (int i = tid; i < nb; i += 256) {
+			lo = fminf(lo, fpart[2 * i]);
+			hi = fmaxf(hi, fpart[2 * i + 1]);
+		}
+		lo = wave_min(lo);
+		hi = wave_max(hi);
+	}
+	__syncthreads();
+	if (tid < 256 && (tid & 63) == 0) {
+		shl_t[tid >> 6] = lo;
+		shh_t[tid >> 6] = hi;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		lo = shl_t[0];
+		hi = shh_t[0];
+		for (int q = 1; q < 4; q++) {
+			lo = fminf(lo, shl_t[q]);
+			hi = fmaxf(hi, shh_t[q]);
 		}
 	}
 }

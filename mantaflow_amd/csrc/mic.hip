@@ -325,7 +325,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
            const CgScalars* __restrict__ sc, double* __restrict__ dotpart, const int* __restrict__ bempty,
-           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok, int empty_ext) {
+           const unsigned char* __restrict__ pack, const int* __restrict__ pack_ok, int empty_ext, BetaTail tail) {
 	// empty_ext: the dot shares of the bundles left out are summed by the caller's residual update (mf_cg_solve) -- their entries are 0
 	static_assert(MODE == 1 || MODE == 2, "row-streaming kernel implements the apply sweeps");
 	// dotpart (backward sweep only): GridDotProduct(dst, var1) (conjugategrad.cpp:175-178: fp32 product, fp64 sum) fused into the
@@ -408,14 +408,14 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		// launch less per iteration: 128^3).
 		if (bempty && bempty[tk * nbj + tj]) {
 			if (MODE == 2 && with_dot && wave == 0 && empty_ext) {
-				if (lane == 0) dotpart[sid] = 0.0;
+				if (lane == 0) part_store(&dotpart[sid], 0.0);
 			} else if (MODE == 2 && with_dot && wave == 0 && nstreams <= (int)gridDim.x) {
 				double dacc = 0.0;
 				if (row_in)
 					for (int x = xlim - 1; x >= 0; x--) dacc += (double)(dst[rowbase + x] * var1[rowbase + x]);
 #pragma unroll
 				for (int o = 32; o >= 1; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
-				if (lane == 0) dotpart[sid] = dacc;
+				if (lane == 0) part_store(&dotpart[sid], dacc);
 			}
 			__syncthreads();
 			continue;
@@ -640,7 +640,7 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 					// fixed butterfly over the 64 rows of the bundle: the same bits on every run
 #pragma unroll
 					for (int o = 32; o >= 1; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
-					if (lane == 0) dotpart[sid] = dacc;
+					if (lane == 0) part_store(&dotpart[sid], dacc);      // sc1 + completion: the last workgroup may fold it (tail)
 				}
 			}
 		} else {
@@ -748,11 +748,47 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		__syncthreads();
 	}
 	if (spins > FLOW_SPIN_LIMIT) atomicExch(&ctl->err, 1);
+	__shared__ int s_lastwg;
 	if (threadIdx.x == 0) {
 		const int f = atomicAdd(&ctl->finished, 1);
-		if (f == (int)gridDim.x - 1) {
+		s_lastwg = (f == (int)gridDim.x - 1) ? 1 : 0;
+		if (s_lastwg) {
 			xt[0] = 0;
 			ctl->finished = 0;
+		}
+	}
+	if (MODE == 2 && tail.sc) {
+		// the beta step (k_cg_beta) in the workgroup that finished last: every other workgroup's dot partials were complete before
+		// it reported in.  Same folds in the same order as the one-block kernel (256 threads take part).
+		__syncthreads();
+		if (!s_lastwg) return;
+		CgScalars* w = tail.sc;
+		const bool l2 = w->useL2 != 0;
+		float lo = FLT_MAX, hi = -FLT_MAX;
+		double ss = 0.0;
+		if (l2) ss = tail_sum256<false>(tail.dpart_res, tail.nbr);
+		else tail_minmax256(tail.fpart, tail.nbr, lo, hi);
+		__syncthreads();
+		const double dd = tail_sum256<true>(dotpart, tail.nsig);
+		if (threadIdx.x == 0) {
+			float resNorm;
+			if (l2)
+				resNorm = (float)ss;
+			else {
+				const float alo = fabsf(lo), ahi = fabsf(hi);
+				resNorm = alo > ahi ? alo : ahi;
+			}
+			w->resNorm = resNorm;
+			if (resNorm < w->accuracy) {
+				w->sigma = resNorm;
+				w->done = 1;
+			} else {
+				const float sigmaNew = (float)dd;
+				w->beta = sigmaNew / w->sigma;
+				w->sigmaNew = sigmaNew;
+				w->sigma = sigmaNew;
+				if (!((double)resNorm < 1e35)) w->diverged = 1;
+			}
 		}
 	}
 }
@@ -1331,6 +1367,8 @@ extern "C" int mf_pack_matrix(int sx, int sy, int sz, const int32_t* flags, cons
 static thread_local double* g_dot_request = nullptr;
 static thread_local int g_dot_count = 0;
 static thread_local bool g_dot_empty_ext = false;
+static thread_local BetaTail g_dot_tail = BetaTail{nullptr, 0, nullptr, nullptr, 0};
+static thread_local bool g_dot_tail_done = false;
 template <int MODE>
 static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                       const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
@@ -1381,10 +1419,17 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				if (f->nempty_host > 0 && f->nblocks > grid)
 					hipLaunchKernelGGL(k_mic_empty_dot, dim3(f->nblocks), dim3(BLOCK), 0, st, d, f->nbj, f->nbk, f->nchunks * 8, be, dst, var1, sc, dotp);
 			}
+			BetaTail ktail = BetaTail{nullptr, 0, nullptr, nullptr, 0};
+			if (MODE == 2 && dotp && g_dot_tail.sc && !(be && f->nblocks > grid && !empty_ext && f->nempty_host > 0)) {
+				// (not with the separate empty-share kernel: its partials are plain stores of another launch -- fine -- but keep it simple)
+				ktail = g_dot_tail;
+				ktail.nsig += f->nblocks;      // the sweep's own partials come first
+				g_dot_tail_done = true;
+			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext, ktail);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext, ktail);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
@@ -1410,13 +1455,18 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 // backward sweep with GridDotProduct(dst, var1) fused: *ndot = number of partials written to dotpart (0: not fused in
 // this mode -- the caller runs its own dot kernel)
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
-                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext) {
+                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext,
+                   BetaTail tail, bool* tail_done) {
 	g_dot_request = dotpart;
 	g_dot_empty_ext = empty_ext;
+	g_dot_tail = tail;
+	g_dot_tail_done = false;
 	g_dot_count = 0;
 	const int rc = launch_mic<2>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);
 	g_dot_request = nullptr;
 	g_dot_empty_ext = false;
+	g_dot_tail = BetaTail{nullptr, 0, nullptr, nullptr, 0};
+	if (tail_done) *tail_done = g_dot_tail_done;
 	*ndot = g_dot_count;
 	return rc;
 }

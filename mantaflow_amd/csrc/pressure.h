@@ -10,6 +10,16 @@ struct CgScalars {
 	int xpending;     // mf_cg_solve only: this iteration's dst += alpha * search is still to be done (by k_cg_update_search_x)
 };
 
+// the beta step of the PCG (k_cg_beta: residual norm, convergence test, beta; conjugategrad.cpp:268-295) as the tail of the backward MIC
+// sweep's last workgroup: the partials of the residual update (an earlier kernel) and the nsig dot partials (this launch's, plus what
+// the caller appended behind them)
+struct BetaTail {
+	CgScalars* sc;            // nullptr: no tail
+	int nbr;                  // blocks of the residual update
+	const float* fpart;       // their min / max pairs
+	const double* dpart_res;  // their sums of squares (L2 norm)
+	int nsig;                 // dot partials to fold
+};
 namespace mf {
 // mode 0: InitPreconditionModifiedIncompCholesky2 (dst := Aprecond, var1 := A0); 1 / 2: forward / backward substitution
 // of ApplyPreconditionModifiedIncompCholesky2.  sc (nullable): skip when sc->done.
@@ -18,7 +28,8 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 // backward substitution with GridDotProduct(dst, var1) fused into the sweep ("rows" mode): *ndot partials in dotpart, summed in
 // index order by the caller; *ndot == 0 when the active mode cannot fuse it (the caller then runs its own dot kernel)
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
-                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext = false);
+                   const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext = false,
+                   BetaTail tail = BetaTail{nullptr, 0, nullptr, nullptr, 0}, bool* tail_done = nullptr);
 // empty_ext: the caller sums the shares of the bundles the sweep leaves out itself (mic_empty_map tells which), their entries come out 0
 int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st);
 // packed {fluid, Ai, Aj, Ak} bytes built by the last mf_mic_init for exactly these grids (nullptr when unavailable / not exact);

@@ -1317,6 +1317,7 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 		const int todo = (maxIter - issued < batch) ? (maxIter - issued) : batch;
 		for (int it = 0; it < todo; it++) {
 			int nba = 0, nsig = 0;
+			bool beta_done = false;
 			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
@@ -1327,7 +1328,9 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
 				// sigma_new = dot(tmp, residual) comes out of the backward sweep's write-back (one partial per row bundle); the shares of
 				// the bundles the sweeps leave out: from the residual update above, behind the sweep's partials
-				MF_TRY(mic_launch_dot(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, p_sig, &nsig, st, be_map != nullptr));
+				// ... and the beta step is the tail of the sweep's last workgroup (one launch less per iteration)
+				MF_TRY(mic_launch_dot(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, p_sig, &nsig, st, be_map != nullptr,
+				                      BetaTail{sc, nbs, p_mm, p_res, be_map ? nbs : 0}, &beta_done));
 				if (be_map) {
 					if (nsig != be_nb) return fail("mf_cg_solve: the backward sweep wrote %d dot partials, %d expected", nsig, be_nb);
 					nsig += nbs;
@@ -1339,7 +1342,7 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 				hipLaunchKernelGGL(k_cg_dot, dim3(nbs), dim3(BLOCK), 0, st, n, sc, tmp, residual, p_sig);
 				nsig = nbs;
 			}
-			hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
+			if (!beta_done) hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
 			hipLaunchKernelGGL(k_cg_update_search_x, dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
 		}
 		MF_LAUNCH_CHECK();
