@@ -444,6 +444,23 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         result = slab.bench_slab_step(n, dt, a.steps, a.warmup, rank, world)
+        if rank == 0:
+            # the roofline object of the line, for the kernel north_star names, on what one rank computes per PCG iteration: its owned
+            # planes + one ghost plane per interior face (HIP events on the launch stream, after the timed region)
+            nz = n // world + (1 if world > 1 else 0) + (1 if world > 2 else 0)
+            s2 = core.Solver(gridSize=core.vec3(n, n, nz), dim=3)
+            fl2 = core.FlagGrid(s2); fl2.initDomain(); fl2.fillGrid()
+            g = [core.Grid(s2) for _ in range(6)]
+            lib.call("mf_make_laplace_matrix", n, n, nz, fl2.ptr, g[0].ptr, g[1].ptr, g[2].ptr, g[3].ptr, None, s2.stream)
+            g[4].from_numpy(np.random.default_rng(1234).uniform(-1, 1, (nz, n, n)).astype(np.float32))
+            us = ctypes.c_double()
+            lib.call("mf_time_apply_matrix", n, n, nz, fl2.ptr, g[5].ptr, g[4].ptr, g[0].ptr, g[1].ptr, g[2].ptr, g[3].ptr, 200, ctypes.byref(us), s2.stream)
+            gbs = APPLY_MATRIX_BYTES_PER_CELL * n * n * nz / (us.value * 1e-6) / 1e9
+            result["roofline"] = {"kernel": "k_apply_matrix_v5 (ApplyMatrix, conjugategrad.h:118-133) on one rank's PCG window %dx%dx%d" % (n, n, nz),
+                                  "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                  "traffic": None, "avg_launch_us": round(us.value, 2),
+                                  "algorithmic_bytes_per_launch": APPLY_MATRIX_BYTES_PER_CELL * n * n * nz}
+            del g, fl2, s2
     else:
         s = core.Solver(gridSize=core.vec3(n, n, n), dim=3)
         s.timestep = dt

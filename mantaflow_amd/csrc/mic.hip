@@ -757,6 +757,23 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 			ctl->finished = 0;
 		}
 	}
+	if (MODE == 2 && !tail.sc && tail.sum_out) {
+		// z-slab solver: the one-block folds behind the sweep (k_fin_maxabs_live, k_mic_fin_sum) in the workgroup that finished last
+		__syncthreads();
+		if (!s_lastwg) return;
+		float lo = FLT_MAX, hi = -FLT_MAX;
+		if (tail.nbr > 0) tail_minmax256(tail.fpart, tail.nbr, lo, hi);
+		__syncthreads();
+		const double dd = tail_sum256<true>(dotpart, tail.nsig);
+		if (threadIdx.x == 0) {
+			tail.sum_out[0] = dd;
+			if (tail.nbr > 0 && !(tail.live && tail.live->done)) {
+				const float alo = fabsf(lo), ahi = fabsf(hi);
+				tail.maxabs_out[0] = (double)(alo > ahi ? alo : ahi);
+			}
+		}
+		return;
+	}
 	if (MODE == 2 && tail.sc) {
 		// the beta step (k_cg_beta) in the workgroup that finished last: every other workgroup's dot partials were complete before
 		// it reported in.  Same folds in the same order as the one-block kernel (256 threads take part).
@@ -1420,7 +1437,7 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 					hipLaunchKernelGGL(k_mic_empty_dot, dim3(f->nblocks), dim3(BLOCK), 0, st, d, f->nbj, f->nbk, f->nchunks * 8, be, dst, var1, sc, dotp);
 			}
 			BetaTail ktail = BetaTail{nullptr, 0, nullptr, nullptr, 0};
-			if (MODE == 2 && dotp && g_dot_tail.sc && !(be && f->nblocks > grid && !empty_ext && f->nempty_host > 0)) {
+			if (MODE == 2 && dotp && (g_dot_tail.sc || g_dot_tail.sum_out) && !(be && f->nblocks > grid && !empty_ext && f->nempty_host > 0)) {
 				// (not with the separate empty-share kernel: its partials are plain stores of another launch -- fine -- but keep it simple)
 				ktail = g_dot_tail;
 				ktail.nsig += f->nblocks;      // the sweep's own partials come first
@@ -1444,6 +1461,32 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 	return 0;
 }
 
+
+// one-block sum of the per-bundle dot partials (index order) -- or, without fusion, a plain dot over the grid
+static __global__ void __launch_bounds__(BLOCK) k_mic_fin_sum(int nb, const double* __restrict__ partials, double* __restrict__ out) {
+	double acc = strided_sum(partials, nb);
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) out[0] = acc;
+}
+static __global__ void __launch_bounds__(BLOCK) k_mic_plain_dot(int64_t n, const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ partials) {
+	double acc = 0.0;
+	for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) acc += (double)(a[i] * b[i]);
+	acc = block_sum(acc);
+	if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+static __global__ void __launch_bounds__(BLOCK) k_mic_fin_maxabs_live(int nb, const float* __restrict__ fpart, double* __restrict__ out, const CgScalars* __restrict__ live) {
+	if (live && live->done) return;
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+		lo = fminf(lo, fpart[2 * i]);
+		hi = fmaxf(hi, fpart[2 * i + 1]);
+	}
+	block_minmax(lo, hi);
+	if (threadIdx.x == 0) {
+		const float alo = fabsf(lo), ahi = fabsf(hi);
+		out[0] = (double)(alo > ahi ? alo : ahi);
+	}
+}
 
 namespace mf {
 int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
@@ -1469,6 +1512,29 @@ int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* 
 	if (tail_done) *tail_done = g_dot_tail_done;
 	*ndot = g_dot_count;
 	return rc;
+}
+int mic_apply_dot_fold(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+                       const float* Aj, const float* Ak, double* dot_dev, int nbr, const float* fpart, double* maxabs_dev,
+                       const CgScalars* live, hipStream_t st) {
+	Workspace* ws;
+	MF_TRY(get_workspace(&ws));
+	double* part = ws->partials + 2 * MAX_BLOCKS;
+	// live->done (the z-slab solver's iterations queued past the stop): both sweeps return at once, *dot_dev / *maxabs_dev keep the
+	// values of the stopping iteration (dst and var1 have not changed since)
+	MF_TRY(mic_launch(1, d, flags, dst, var1, Ap, Ai, Aj, Ak, live, st));
+	int nsig = 0;
+	bool folded = false;
+	BetaTail tail = BetaTail{nullptr, nbr, fpart, nullptr, 0, dot_dev, maxabs_dev, live};
+	MF_TRY(mic_launch_dot(d, flags, dst, var1, Ap, Ai, Aj, Ak, live, part, &nsig, st, false, tail, &folded));
+	if (folded) return 0;
+	if (nsig == 0) {
+		nsig = blocks_for(d.n, BLOCK * 4, 2048);
+		hipLaunchKernelGGL(k_mic_plain_dot, dim3(nsig), dim3(BLOCK), 0, st, d.n, dst, var1, part);
+	}
+	hipLaunchKernelGGL(k_mic_fin_sum, dim3(1), dim3(BLOCK), 0, st, nsig, part, dot_dev);
+	if (nbr > 0) hipLaunchKernelGGL(k_mic_fin_maxabs_live, dim3(1), dim3(BLOCK), 0, st, nbr, fpart, maxabs_dev, live);
+	MF_LAUNCH_CHECK();
+	return 0;
 }
 // the packed flags/Ai/Aj/Ak bytes mf_mic_init built for exactly these grids, if every coefficient was +0 or -1 (one small
 // device-to-host read, i.e. a stream synchronisation: call it once per solve); *pack = nullptr otherwise
@@ -1672,37 +1738,12 @@ int mf_mic_apply(int sx, int sy, int sz, const int32_t* flags, float* dst, const
 	return mic_launch(2, d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, (hipStream_t)stream);
 }
 
-// one-block sum of the per-bundle dot partials (index order) -- or, without fusion, a plain dot over the grid
-__global__ void __launch_bounds__(BLOCK) k_mic_fin_sum(int nb, const double* __restrict__ partials, double* __restrict__ out) {
-	double acc = strided_sum(partials, nb);
-	acc = block_sum(acc);
-	if (threadIdx.x == 0) out[0] = acc;
-}
-__global__ void __launch_bounds__(BLOCK) k_mic_plain_dot(int64_t n, const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ partials) {
-	double acc = 0.0;
-	for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) acc += (double)(a[i] * b[i]);
-	acc = block_sum(acc);
-	if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
 int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* var1, const float* Aprecond,
                          const float* Ai, const float* Aj, const float* Ak, double* dot_dev, void* stream) {
 	MF_TRY(check_dim(sx, sy, sz));
 	const Dim d = mkdim(sx, sy, sz);
 	if (!d.is3d) return fail("mICP only supports 3D grids so far");
-	hipStream_t st = (hipStream_t)stream;
-	Workspace* ws;
-	MF_TRY(get_workspace(&ws));
-	double* part = ws->partials + 2 * MAX_BLOCKS;
-	MF_TRY(mic_launch(1, d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, st));
-	int nsig = 0;
-	MF_TRY(mic_launch_dot(d, flags, dst, var1, Aprecond, Ai, Aj, Ak, nullptr, part, &nsig, st));
-	if (nsig == 0) {
-		nsig = blocks_for(d.n, BLOCK * 4, 2048);
-		hipLaunchKernelGGL(k_mic_plain_dot, dim3(nsig), dim3(BLOCK), 0, st, d.n, dst, var1, part);
-	}
-	hipLaunchKernelGGL(k_mic_fin_sum, dim3(1), dim3(BLOCK), 0, st, nsig, part, dot_dev);
-	MF_LAUNCH_CHECK();
-	return 0;
+	return mf::mic_apply_dot_fold(d, flags, dst, var1, Aprecond, Ai, Aj, Ak, dot_dev, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // a dataflow sweep that gives up waiting for a face (FLOW_SPIN_LIMIT) latches an error flag on the device; mf_cg_solve

@@ -7,7 +7,8 @@
 struct CgScalars {
 	float sigma, alpha, nalpha, beta, resNorm, dp, sigmaNew, accuracy;
 	int iterations, done, diverged, useL2;
-	int xpending;     // mf_cg_solve only: this iteration's dst += alpha * search is still to be done (by k_cg_update_search_x)
+	int xpending;     // this iteration's dst += alpha * search is still to be done (by k_cg_update_search_x)
+	float sigmaPrev;  // z-slab solver: sigma as the alpha step saw it (the beta step's divisor while block 0 of the same kernel writes sigma)
 };
 
 // the beta step of the PCG (k_cg_beta: residual norm, convergence test, beta; conjugategrad.cpp:268-295) as the tail of the backward MIC
@@ -19,6 +20,12 @@ struct BetaTail {
 	const float* fpart;       // their min / max pairs
 	const double* dpart_res;  // their sums of squares (L2 norm)
 	int nsig;                 // dot partials to fold
+	// sc == nullptr and sum_out set: the z-slab solver's variant -- no beta step here (the scalars of all ranks are gathered first), the
+	// last workgroup only folds: *sum_out = sum of the nsig dot partials (k_mic_fin_sum's order) and, with nbr > 0, *maxabs_out =
+	// max |fpart| unless live->done (k_fin_maxabs_live)
+	double* sum_out;
+	double* maxabs_out;
+	const CgScalars* live;
 };
 namespace mf {
 // mode 0: InitPreconditionModifiedIncompCholesky2 (dst := Aprecond, var1 := A0); 1 / 2: forward / backward substitution
@@ -30,6 +37,12 @@ int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const f
 int mic_launch_dot(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                    const float* Aj, const float* Ak, const CgScalars* sc, double* dotpart, int* ndot, hipStream_t st, bool empty_ext = false,
                    BetaTail tail = BetaTail{nullptr, 0, nullptr, nullptr, 0}, bool* tail_done = nullptr);
+// forward + backward substitution with dot(dst, var1) -> *dot_dev and (nbr > 0) the max |.| of the nbr min / max pairs in fpart ->
+// *maxabs_dev (skipped once live->done): folded by the backward sweep's last workgroup where the active mode allows, by one-block
+// kernels behind it otherwise
+int mic_apply_dot_fold(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
+                       const float* Aj, const float* Ak, double* dot_dev, int nbr, const float* fpart, double* maxabs_dev,
+                       const CgScalars* live, hipStream_t st);
 // empty_ext: the caller sums the shares of the bundles the sweep leaves out itself (mic_empty_map tells which), their entries come out 0
 int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st);
 // packed {fluid, Ai, Aj, Ak} bytes built by the last mf_mic_init for exactly these grids (nullptr when unavailable / not exact);

@@ -910,6 +910,53 @@ __global__ void k_slab_alpha_x(const double* __restrict__ g, int world, CgScalar
 	sc->nalpha = -a;
 	sc->xpending = 1;
 	sc->done = 0;
+	sc->sigmaPrev = sc->sigma;
+}
+// k_slab_alpha_x + the residual update (k_cg_axpy_r, min / max partials) in one launch: every block forms alpha from the gathered rows
+// itself (the same bits everywhere), block 0 publishes the scalars for the kernels behind it.  Nothing this kernel writes is read by
+// another block of it (sigma and the stop state are written by the search update's kernel only).
+__global__ void __launch_bounds__(BLOCK)
+k_slab_axpy_r(int64_t n, const double* __restrict__ g, int world, CgScalars* __restrict__ sc, const int32_t* __restrict__ state,
+              float* __restrict__ residual, const float* __restrict__ tmp, float* __restrict__ fpart) {
+	const bool stopped = state[0] != 0;
+	float a = 0.f;
+	if (!stopped) {
+		double acc = 0.0;
+		for (int r = 0; r < world; r++) acc += g[2 * r + 1];
+		const float dp = (float)acc;
+		a = (fabs((double)dp) > 0.) ? sc->sigma / dp : 0.f;
+	}
+	const float nalpha = -a;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->alpha = a;
+		sc->nalpha = nalpha;
+		sc->xpending = stopped ? 0 : 1;
+		sc->done = stopped ? 1 : 0;
+		if (!stopped) sc->sigmaPrev = sc->sigma;
+	}
+	if (stopped) return;
+	float lo = FLT_MAX, hi = -FLT_MAX;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		float4 r = ((float4*)residual)[q];
+		const float4 t = ((const float4*)tmp)[q];
+		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
+		((float4*)residual)[q] = r;
+		lo = fminf(fminf(lo, r.x), fminf(r.y, fminf(r.z, r.w)));
+		hi = fmaxf(fmaxf(hi, r.x), fmaxf(r.y, fmaxf(r.z, r.w)));
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		const float r = residual[i] + nalpha * tmp[i];
+		residual[i] = r;
+		lo = fminf(lo, r);
+		hi = fmaxf(hi, r);
+	}
+	block_minmax(lo, hi);
+	if (threadIdx.x == 0) {
+		fpart[2 * blockIdx.x] = lo;
+		fpart[2 * blockIdx.x + 1] = hi;
+	}
 }
 __global__ void k_slab_beta_x(const double* __restrict__ g, int world, CgScalars* __restrict__ sc, float accuracy, int iter, int32_t* __restrict__ state) {
 	if (state && state[0]) return;
@@ -935,22 +982,55 @@ __global__ void k_slab_beta_x(const double* __restrict__ g, int world, CgScalars
 		}
 	}
 }
-
-// one-block finishers of the slab entry points
-__global__ void __launch_bounds__(BLOCK) k_fin_maxabs_live(int nb, const float* __restrict__ fpart, double* __restrict__ out, const CgScalars* __restrict__ sc) {
-	if (sc->done) return;
-	float lo = FLT_MAX, hi = -FLT_MAX;
-	for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-		lo = fminf(lo, fpart[2 * i]);
-		hi = fmaxf(hi, fpart[2 * i + 1]);
+// k_slab_beta_x + k_cg_update_search_x in one launch, the same way: every block forms beta and the stopping test from the gathered rows,
+// block 0 publishes them (sigma, the stop state) -- the other blocks read sigmaPrev / xpending / alpha, which the residual update's
+// kernel wrote
+__global__ void __launch_bounds__(BLOCK)
+k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgScalars* __restrict__ sc, float accuracy, int iter,
+                       int32_t* __restrict__ state, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp) {
+	if (!sc->xpending) return;          // stopped before this iteration
+	double acc = 0.0, mx = 0.0;
+	for (int r = 0; r < world; r++) {
+		acc += g[2 * r + 1];
+		mx = g[2 * r] > mx ? g[2 * r] : mx;
 	}
-	block_minmax(lo, hi);
-	if (threadIdx.x == 0) {
-		lo = fabsf(lo);
-		hi = fabsf(hi);
-		out[0] = (double)(lo > hi ? lo : hi);
+	const float sigmaNew = (float)acc;
+	const float rn = (float)mx;
+	const float beta = sigmaNew / sc->sigmaPrev;
+	const bool converged = rn < accuracy, diverged = !converged && !(rn < 1e35f);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		sc->resNorm = rn;
+		sc->beta = beta;
+		sc->sigma = sigmaNew;
+		if (converged || diverged) {
+			state[0] = converged ? 1 : 2;
+			state[1] = iter;
+			sc->done = 1;
+		}
+	}
+	const bool upd = !(converged || diverged);
+	const float alpha = sc->alpha;
+	const int64_t n4 = n >> 2;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		float4 s = ((float4*)search)[q];
+		float4 x = ((float4*)dst)[q];
+		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
+		((float4*)dst)[q] = x;
+		if (upd) {
+			const float4 t = ((const float4*)tmp)[q];
+			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
+			((float4*)search)[q] = s;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+		const int64_t i = (n4 << 2) + threadIdx.x;
+		const float s = search[i];
+		dst[i] = dst[i] + alpha * s;
+		if (upd) search[i] = tmp[i] + beta * s;
 	}
 }
+
+// one-block finishers of the slab entry points
 __global__ void __launch_bounds__(BLOCK) k_fin_sum(int nb, const double* __restrict__ partials, double* __restrict__ out) {
 	double acc = strided_sum(partials, nb);
 	acc = block_sum(acc);
@@ -1467,17 +1547,23 @@ int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const 
                         void* stream) {
 	hipStream_t st = (hipStream_t)stream;
 	CgScalars* sc = (CgScalars*)scalars;
-	hipLaunchKernelGGL(k_slab_alpha_x, dim3(1), dim3(1), 0, st, gathered, world, sc, state_dev);
 	float* r = residual + own_off;
 	float* t = tmp + own_off;
+	const bool one_launch = n_own > 0 && state_dev && al16(r) && al16(t);
+	if (!one_launch) hipLaunchKernelGGL(k_slab_alpha_x, dim3(1), dim3(1), 0, st, gathered, world, sc, state_dev);
 	if (n_own > 0) {
-		if (al16(r) && al16(t)) {
+		if (one_launch) {
 			Workspace* ws;
 			MF_TRY(get_workspace(&ws));
 			const int nb = blocks_for(n_own >> 2, BLOCK, 2048);
-			hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nb), dim3(BLOCK), 0, st, n_own, sc, r, t, ws->fpartials, ws->partials + MAX_BLOCKS);
-			hipLaunchKernelGGL(k_fin_maxabs_live, dim3(1), dim3(BLOCK), 0, st, nb, ws->fpartials, maxabs_dev, sc);
+			// the alpha step rides in the residual update (every block forms it from the gathered rows)
+			hipLaunchKernelGGL(k_slab_axpy_r, dim3(nb), dim3(BLOCK), 0, st, n_own, gathered, world, sc, state_dev, r, t, ws->fpartials);
 			MF_LAUNCH_CHECK();
+			// max |r| of these partials and dot(tmp, r): folded by the last workgroup of the backward sweep (no one-block launches)
+			MF_TRY(check_dim(sx, sy, sz));
+			const Dim d = mkdim(sx, sy, sz);
+			if (!d.is3d) return fail("mICP only supports 3D grids so far");
+			return mic_apply_dot_fold(d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, dot_dev, nb, ws->fpartials, maxabs_dev, sc, st);
 		} else {
 			// views that do not start on a 16-byte boundary (odd plane sizes): the unfused sequence (alpha is 0 once stopped)
 			MF_TRY(mf_grid_scaled_add_dev(n_own, r, t, &sc->alpha, -1.f, stream));
@@ -1490,16 +1576,18 @@ int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float 
                         int64_t n_own, float* x, float* search, const float* tmp, void* stream) {
 	hipStream_t st = (hipStream_t)stream;
 	CgScalars* sc = (CgScalars*)scalars;
-	hipLaunchKernelGGL(k_slab_beta_x, dim3(1), dim3(1), 0, st, gathered, world, sc, accuracy, iter, state_dev);
-	if (n_own <= 0) return 0;
 	float* xs = x + own_off;
 	float* s = search + own_off;
 	const float* t = tmp + own_off;
-	if (al16(xs) && al16(s) && al16(t)) {
-		hipLaunchKernelGGL(k_cg_update_search_x, dim3(blocks_for(n_own >> 2, BLOCK, 2048)), dim3(BLOCK), 0, st, n_own, sc, xs, s, t);
+	if (n_own > 0 && state_dev && al16(xs) && al16(s) && al16(t)) {
+		// the beta step and the stopping test ride in the search update
+		hipLaunchKernelGGL(k_slab_update_search_x, dim3(blocks_for(n_own >> 2, BLOCK, 2048)), dim3(BLOCK), 0, st, n_own, gathered, world, sc,
+		                   accuracy, iter, state_dev, xs, s, t);
 		MF_LAUNCH_CHECK();
 		return 0;
 	}
+	hipLaunchKernelGGL(k_slab_beta_x, dim3(1), dim3(1), 0, st, gathered, world, sc, accuracy, iter, state_dev);
+	if (n_own <= 0) return 0;
 	hipLaunchKernelGGL(k_cg_update_search_x_scalar, dim3(blocks_for(n_own, BLOCK, 2048)), dim3(BLOCK), 0, st, n_own, sc, xs, s, t);
 	MF_LAUNCH_CHECK();
 	return 0;
