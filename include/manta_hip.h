@@ -489,7 +489,8 @@ int mf_update_search_vec_dev(int64_t n, float* dst, const float* src, const floa
  *                          with maxabs_dev[0] = max |residual| ; mf_mic_apply_dot_dev (tmp = M^-1 residual, dot_dev[0] = dot(tmp, residual))
  *   mf_cg_slab_after_zr  : beta and the stopping test from the gathered rows ; x += alpha * search over the owned cells (this iteration's
  *                          update, also when the iteration is the one that converged) ; unless stopped, search = tmp + beta * search
- * `scalars`: the block described above plus int32 xpending at word 12 (16 words, zero-initialised by the caller).
+ * `scalars`: the block described above plus int32 xpending at word 12 and float sigmaPrev at word 13 (the library's own: sigma as
+ * the alpha step saw it); 16 words, zero-initialised by the caller.
  * `own_off` / `n_own`: first owned cell and number of owned cells of the slab's grids (ghost planes excluded). */
 int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const int32_t* state_dev, int64_t own_off, int64_t n_own,
                         float* residual, float* tmp, double* maxabs_dev, int sx, int sy, int sz,
