@@ -122,7 +122,10 @@ __global__ void __launch_bounds__(BLOCK)
 k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
                   const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
                   const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb,
-                  const unsigned char* __restrict__ pack, int dk0, int dk1, int a0p) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
+                  const unsigned char* __restrict__ pack, int dk0, int dk1, int a0p, const int* __restrict__ bempty = nullptr, int nbj = 0,
+                  const int* __restrict__ outside_bad = nullptr) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
+	// bempty (mf_cg_solve, liquid scenes): 8 x 8 bundles of rows without a fluid cell in which src is known to be zero (k_cg_outside_zero found
+	// rhs and the work grids zero there, and every kernel of the iteration keeps it so): dst = src = 0 is there already, nothing to do
 	// a0p (PACKED only): bits 4-7 of the packed bytes hold the diagonal (k_mic_pack) -- A0 is not read at all, 9 instead of 13 B per cell
 	if (DOT && sc->done) return;
 	const int qx = d.sx >> 2;
@@ -138,6 +141,8 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	const int64_t rg = T / qx;
 	const int j0 = (int)(rg % jgroups) * R;
 	const int k = (int)(rg / jgroups);
+	// (R divides 8: the rows of a thread lie in one bundle; the lanes this thread exchanges +-X neighbours with work on the same rows)
+	if (IS3D && bempty && outside_bad[0] == 0 && bempty[(k >> 3) * nbj + (j0 >> 3)]) continue;
 	const int lane = threadIdx.x & 63;
 	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 	const int64_t Y = d.Y, Z = d.Z;
@@ -301,7 +306,8 @@ template <bool DOT>
 static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, const float* src, const float* A0,
                                const float* Ai, const float* Aj, const float* Ak, double* partials,
                                const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr,
-                               int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr, bool a0p = false) {
+                               int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr, bool a0p = false, const int* bempty = nullptr,
+                               int nbj = 0, const int* outside_bad = nullptr) {
 	if (ranged) *ranged = false;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
@@ -317,11 +323,11 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
 		nb = (int)((vblocks + tpb - 1) / tpb);
 #define AM5(RR)                                                                                                                                   \
 	if (d.is3d && pack)                                                                                                                           \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad); \
 	else if (d.is3d)                                                                                                                              \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad); \
 	else                                                                                                                                          \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0);
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad);
 		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
 #undef AM5
 		if (ranged) *ranged = true;
@@ -656,23 +662,35 @@ template <bool COPY_TMP, bool EDOT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart,
             double* __restrict__ dpart, const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0,
-            double* __restrict__ epart = nullptr) {
+            double* __restrict__ epart = nullptr, const int* __restrict__ outside_bad = nullptr) {
 	if (sc->done) return;
+	// outside_bad[0] == 0 (k_cg_outside_zero): residual and tmp are zero in the bundles the sweeps leave out and stay so -- their quads
+	// are neither read nor written, they enter the min / max as the zeros they are and add nothing to the sums
+	const bool zero_outside = EDOT && outside_bad[0] == 0;
 	const float nalpha = sc->nalpha;
 	const bool l2 = sc->useL2 != 0;
 	float lo = FLT_MAX, hi = -FLT_MAX;
 	double ss = 0.0, es = 0.0;
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		bool in_empty = false;
+		if (EDOT) {
+			const int64_t row = (4 * q) / sx;
+			const int j = (int)(row % sy), k = (int)(row / sy);
+			in_empty = bempty[(k >> 3) * nbj + (j >> 3)] != 0;
+			if (in_empty && zero_outside) {
+				lo = fminf(lo, 0.f);
+				hi = fmaxf(hi, 0.f);
+				continue;
+			}
+		}
 		float4 r = ((float4*)residual)[q];
 		const float4 t = ((const float4*)tmp)[q];
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		if (COPY_TMP) ((float4*)tmp)[q] = r;
 		if (EDOT) {
-			const int64_t row = (4 * q) / sx;
-			const int j = (int)(row % sy), k = (int)(row / sy);
-			if (bempty[(k >> 3) * nbj + (j >> 3)]) {
+			if (in_empty) {
 				es += (double)(t.x * r.x);
 				es += (double)(t.y * r.y);
 				es += (double)(t.z * r.z);
@@ -854,13 +872,22 @@ k_cg_update_search(int64_t n, CgScalars* __restrict__ sc, float* __restrict__ se
 
 // dst += alpha*search (conjugategrad.cpp:254, left over from this iteration: xpending) and, unless the iteration has converged,
 // search = tmp + beta*search (:283) -- `search` is read once for both
+// SKIP (liquid scenes, see k_cg_outside_zero): dst, search and tmp are zero in the bundles without fluid and stay zero
+template <bool SKIP>
 __global__ void __launch_bounds__(BLOCK)
-k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp) {
+k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp,
+                     const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0, const int* __restrict__ outside_bad = nullptr) {
 	if (!sc->xpending) return;
 	const bool upd = !sc->done;
 	const float alpha = sc->alpha, beta = sc->beta;
 	const int64_t n4 = n >> 2;
+	const bool zero_outside = SKIP && outside_bad[0] == 0;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		if (SKIP && zero_outside) {
+			const int64_t row = (4 * q) / sx;
+			const int j = (int)(row % sy), k = (int)(row / sy);
+			if (bempty[(k >> 3) * nbj + (j >> 3)]) continue;
+		}
 		float4 s = ((float4*)search)[q];
 		float4 x = ((float4*)dst)[q];
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
@@ -1329,6 +1356,24 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 
 }  // extern "C"
 
+// Liquid scenes: most 8 x 8 bundles of rows hold no fluid cell (benchmark_dam.py: 6 % of the cells are fluid).  MakeRhs leaves rhs zero
+// outside the fluid and the work grids are fresh zero grids, so every PCG vector is zero in those bundles and stays zero (ApplyMatrix copies
+// src, the sweeps leave them out, the vector updates combine zeros) -- the kernels of an iteration then skip them altogether.  This kernel
+// is what establishes the premise, on the device, once per solve: bad[0] counts the quads of empty bundles in which rhs or tmp is not +0.
+__global__ void __launch_bounds__(BLOCK)
+k_cg_outside_zero(int64_t n, int sx, int sy, const int* __restrict__ bempty, int nbj, const float* __restrict__ rhs, const float* __restrict__ tmp,
+                  const float* __restrict__ search, int* __restrict__ bad) {
+	const int64_t n4 = n >> 2;
+	int found = 0;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
+		const int64_t row = (4 * q) / sx;
+		const int j = (int)(row % sy), k = (int)(row / sy);
+		if (!bempty[(k >> 3) * nbj + (j >> 3)]) continue;
+		const uint4 a = ((const uint4*)rhs)[q], b = ((const uint4*)tmp)[q], c = ((const uint4*)search)[q];
+		if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w) != 0u) found = 1;
+	}
+	if (__any(found) && (threadIdx.x & 63) == 0) atomicAdd(bad, 1);
+}
 // doInit + iterate loop of GridCg (conjugategrad.cpp:210-307).  free_pack (mf_solve_pressure_fused): the system exists as packed bytes
 // only -- A0 / Ai / Aj / Ak are null, the MIC factor is already in Aprecond and the system is registered with the sweeps
 static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const float* rhs, float* residual, float* search, float* tmp,
@@ -1378,6 +1423,13 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	int be_nbj = 0;
 	if (pc == MF_PC_MICP && (sx % 4) == 0) MF_TRY(mic_empty_map(d, flags, Aprecond, Aj, Ak, &be_map, &be_nbj, st));
 	const int be_nb = ((sy + 7) / 8) * ((sz + 7) / 8);      // the sweep's partials (one per bundle) come first, the nbs of the residual update behind them
+	int* p_bad = (int*)((char*)ws->scalars + 1024);
+	if (be_map) {
+		// (n % 4 == 0 here: sx % 4 == 0.)  residual = rhs and dst = 0 were set above; tmp and search are the caller's
+		MF_HIP(hipMemsetAsync(p_bad, 0, sizeof(int), st));
+		hipLaunchKernelGGL(k_cg_outside_zero, dim3(nbs), dim3(BLOCK), 0, st, n, sx, sy, be_map, be_nbj, rhs, tmp, search, p_bad);
+		MF_LAUNCH_CHECK();
+	}
 	const int batch = (pc == MF_PC_MICP && mic_mode() == 0) ? 1 : 4;
 	CgScalars h;
 	memset(&h, 0, sizeof h);
@@ -1398,11 +1450,12 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 		for (int it = 0; it < todo; it++) {
 			int nba = 0, nsig = 0;
 			bool beta_done = false;
-			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p));
+			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p, be_map,
+			                                 be_nbj, be_map ? p_bad : nullptr));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
 				if (be_map)
-					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, be_map, be_nbj, sx, sy, p_sig + be_nb);
+					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, be_map, be_nbj, sx, sy, p_sig + be_nb, p_bad);
 				else
 					hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
@@ -1423,7 +1476,10 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 				nsig = nbs;
 			}
 			if (!beta_done) hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
-			hipLaunchKernelGGL(k_cg_update_search_x, dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
+			if (be_map)
+				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, be_map, be_nbj, sx, sy, p_bad);
+			else
+				hipLaunchKernelGGL((k_cg_update_search_x<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
 		}
 		MF_LAUNCH_CHECK();
 		issued += todo;

@@ -23,6 +23,22 @@ def test_slab_two_ranks_on_hip(tmp_path):
     assert util.rel_err(single["pres"], ora["pres"]) < 1e-5
 
 
+def test_slab_planes_off_the_16_byte_grid_on_hip(tmp_path):
+    """30 x 21 planes (2520 bytes): the PCG window of a slab does not start on a 16-byte boundary, so the slab entry points take their
+    unfused branches (one-thread alpha / beta kernels, scalar search update) -- same results as the oracle's, same iteration count"""
+    dims = "30x21x24"
+    single = run_world(tmp_path, 1, "hip", dims=dims)
+    multi = run_world(tmp_path, 2, "hip", dims=dims)
+    check_against_single(single, multi)
+    ora = run_world(tmp_path, 1, "oracle", dims=dims)
+    ora2 = run_world(tmp_path, 2, "oracle", dims=dims)
+    util.assert_bitexact(single["dens"], ora["dens"], "density hip vs oracle")
+    util.assert_bitexact(single["vel_adv"], ora["vel_adv"], "velocity hip vs oracle")
+    assert single["iters"] == ora["iters"] and multi["iters"] == ora2["iters"]
+    assert util.rel_err(single["pres"], ora["pres"]) < 1e-5
+    assert util.rel_err(multi["pres"], ora2["pres"]) < 1e-4
+
+
 def test_slab_two_ranks_blocked_preconditioner_on_hip(tmp_path):
     """256 x 128 x 20: the y- and x-cuts of the P > 1 preconditioner (64 rows, 128 cells) are both active in the slab solver, with ghost
     planes, obstacle flags and the packed ApplyMatrix -- 2 ranks on the HIP library against the undivided run and against the oracle's
