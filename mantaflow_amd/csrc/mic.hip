@@ -1558,7 +1558,8 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const fl
 // the empty-bundle map of the system registered for (flags, Ap, Aj, Ak) in "rows" mode, if that system has empty bundles and its sweeps
 // draw several tickets per workgroup (then the shares of those bundles in the fused dot are worth summing elsewhere): one small read-back
 // per system.  *bempty = nullptr otherwise.
-int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st) {
+int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st,
+                  bool any_size) {
 	*bempty = nullptr;
 	*nbj = 0;
 	int dev = 0;
@@ -1568,7 +1569,7 @@ int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const flo
 	if (f.nbj != (d.sy + 7) / 8 || f.nbk != (d.sz + 7) / 8 || f.nxb != 1) return 0;
 	int ncu = 256;
 	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-	if (f.nblocks <= ncu) return 0;
+	if (f.nblocks <= ncu && !any_size) return 0;
 	if (f.nempty_host < 0) {
 		static thread_local std::vector<int> hb;
 		hb.resize((size_t)f.nbj * f.nbk);

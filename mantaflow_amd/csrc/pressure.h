@@ -44,7 +44,10 @@ int mic_apply_dot_fold(const Dim& d, const int32_t* flags, float* dst, const flo
                        const float* Aj, const float* Ak, double* dot_dev, int nbr, const float* fpart, double* maxabs_dev,
                        const CgScalars* live, hipStream_t st);
 // empty_ext: the caller sums the shares of the bundles the sweep leaves out itself (mic_empty_map tells which), their entries come out 0
-int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st);
+// (any_size: also where every workgroup draws one bundle only and the sweep sums the shares of the empty ones itself -- the map is then only
+// what the vector kernels of the PCG skip by)
+int mic_empty_map(const Dim& d, const int32_t* flags, const float* Ap, const float* Aj, const float* Ak, const int** bempty, int* nbj, hipStream_t st,
+                  bool any_size = false);
 // packed {fluid, Ai, Aj, Ak} bytes built by the last mf_mic_init for exactly these grids (nullptr when unavailable / not exact);
 // synchronises the stream once.  *a0_packed: bits 4-7 of every byte hold the (small integer) diagonal A0 of these grids as well
 int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak,

@@ -1424,10 +1424,14 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	if (pc == MF_PC_MICP && (sx % 4) == 0) MF_TRY(mic_empty_map(d, flags, Aprecond, Aj, Ak, &be_map, &be_nbj, st));
 	const int be_nb = ((sy + 7) / 8) * ((sz + 7) / 8);      // the sweep's partials (one per bundle) come first, the nbs of the residual update behind them
 	int* p_bad = (int*)((char*)ws->scalars + 1024);
-	if (be_map) {
+	// the map the vector kernels skip by: the same one, also where the sweep sums the shares of the empty bundles itself (<= one bundle per CU)
+	const int* sk_map = be_map;
+	int sk_nbj = be_nbj;
+	if (!sk_map && pc == MF_PC_MICP && (sx % 4) == 0) MF_TRY(mic_empty_map(d, flags, Aprecond, Aj, Ak, &sk_map, &sk_nbj, st, true));
+	if (sk_map) {
 		// (n % 4 == 0 here: sx % 4 == 0.)  residual = rhs and dst = 0 were set above; tmp and search are the caller's
 		MF_HIP(hipMemsetAsync(p_bad, 0, sizeof(int), st));
-		hipLaunchKernelGGL(k_cg_outside_zero, dim3(nbs), dim3(BLOCK), 0, st, n, sx, sy, be_map, be_nbj, rhs, tmp, search, p_bad);
+		hipLaunchKernelGGL(k_cg_outside_zero, dim3(nbs), dim3(BLOCK), 0, st, n, sx, sy, sk_map, sk_nbj, rhs, tmp, search, p_bad);
 		MF_LAUNCH_CHECK();
 	}
 	const int batch = (pc == MF_PC_MICP && mic_mode() == 0) ? 1 : 4;
@@ -1450,12 +1454,12 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 		for (int it = 0; it < todo; it++) {
 			int nba = 0, nsig = 0;
 			bool beta_done = false;
-			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p, be_map,
-			                                 be_nbj, be_map ? p_bad : nullptr));
+			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p, sk_map,
+			                                 sk_nbj, sk_map ? p_bad : nullptr));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
-				if (be_map)
-					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, be_map, be_nbj, sx, sy, p_sig + be_nb, p_bad);
+				if (sk_map)      // (without be_map the shares it writes behind the sweep's partials are not summed: the sweep has them)
+					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, sk_map, sk_nbj, sx, sy, p_sig + be_nb, p_bad);
 				else
 					hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
@@ -1476,8 +1480,8 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 				nsig = nbs;
 			}
 			if (!beta_done) hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
-			if (be_map)
-				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, be_map, be_nbj, sx, sy, p_bad);
+			if (sk_map)
+				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, sk_map, sk_nbj, sx, sy, p_bad);
 			else
 				hipLaunchKernelGGL((k_cg_update_search_x<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
 		}
