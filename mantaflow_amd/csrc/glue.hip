@@ -120,6 +120,77 @@ k_extrap_simple(Dim d, float* __restrict__ velc, int32_t* __restrict__ tmp, int 
 		velc[idx] = avg / (float)nbs;
 	}
 }
+// The same pass with four consecutive cells per thread (3-D): the markers of the quad and of its +-Y / +-Z neighbour quads come as
+// 16-byte loads (the +-Y ones from 4-byte aligned addresses when the row length is not a multiple of 4), 7 load instructions per 4 cells
+// instead of 28 -- nearly every cell of a liquid scene only ever reads markers (12 passes per extrapolateMACSimple call).  Neighbour
+// order and arithmetic per cell as above.
+struct __attribute__((packed, aligned(4))) I4u {
+	int x, y, z, w;
+};
+__global__ void __launch_bounds__(BLOCK)
+k_extrap_simple4(Dim d, float* __restrict__ velc, int32_t* __restrict__ tmp, int dd) {
+	const int64_t idx0 = 4 * (blockIdx.x * (int64_t)BLOCK + threadIdx.x);
+	if (idx0 + 3 >= d.n) {
+		// (the last, partial quad of a grid whose cell count is not a multiple of 4: border cells of the last plane -- never interior)
+		return;
+	}
+	const int4 m4 = *(const int4*)(tmp + idx0);
+	const int m[4] = {m4.x, m4.y, m4.z, m4.w};
+	if (m[0] != 0 && m[1] != 0 && m[2] != 0 && m[3] != 0) return;
+	const int64_t Y = d.Y, Z = d.Z;
+	int i = (int)(idx0 % d.sx), j = (int)((idx0 / d.sx) % d.sy), k = (int)(idx0 / ((int64_t)d.sx * d.sy));
+	// neighbour markers; a quad that would reach outside the grid belongs to border cells only, which do nothing
+	const int ml = idx0 > 0 ? tmp[idx0 - 1] : 0, mr = idx0 + 4 < d.n ? tmp[idx0 + 4] : 0;
+	I4u yp = {0, 0, 0, 0}, ym = {0, 0, 0, 0};
+	int4 zp = make_int4(0, 0, 0, 0), zm = make_int4(0, 0, 0, 0);
+	if (idx0 + Y + 3 < d.n) yp = *(const I4u*)(tmp + idx0 + Y);
+	if (idx0 - Y >= 0) ym = *(const I4u*)(tmp + idx0 - Y);
+	const bool zal = (Z & 3) == 0;
+	if (idx0 + Z + 3 < d.n) {
+		if (zal) zp = *(const int4*)(tmp + idx0 + Z);
+		else {
+			const I4u t = *(const I4u*)(tmp + idx0 + Z);
+			zp = make_int4(t.x, t.y, t.z, t.w);
+		}
+	}
+	if (idx0 - Z >= 0) {
+		if (zal) zm = *(const int4*)(tmp + idx0 - Z);
+		else {
+			const I4u t = *(const I4u*)(tmp + idx0 - Z);
+			zm = make_int4(t.x, t.y, t.z, t.w);
+		}
+	}
+	const int nxp[4] = {m[1], m[2], m[3], mr}, nxm[4] = {ml, m[0], m[1], m[2]};
+	const int nyp[4] = {yp.x, yp.y, yp.z, yp.w}, nym[4] = {ym.x, ym.y, ym.z, ym.w};
+	const int nzp[4] = {zp.x, zp.y, zp.z, zp.w}, nzm[4] = {zm.x, zm.y, zm.z, zm.w};
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		const int64_t idx = idx0 + c;
+		const bool interior = i >= 1 && i < d.sx - 1 && j >= 1 && j < d.sy - 1 && k >= 1 && k < d.sz - 1;
+		if (interior && m[c] == 0) {
+			int nbs = 0;
+			float avg = 0.f;
+			if (nxp[c] == dd) { avg += velc[idx + 1]; nbs++; }
+			if (nxm[c] == dd) { avg += velc[idx - 1]; nbs++; }
+			if (nyp[c] == dd) { avg += velc[idx + Y]; nbs++; }
+			if (nym[c] == dd) { avg += velc[idx - Y]; nbs++; }
+			if (nzp[c] == dd) { avg += velc[idx + Z]; nbs++; }
+			if (nzm[c] == dd) { avg += velc[idx - Z]; nbs++; }
+			if (nbs > 0) {
+				tmp[idx] = dd + 1;
+				velc[idx] = avg / (float)nbs;
+			}
+		}
+		// next cell of the quad
+		if (++i == d.sx) {
+			i = 0;
+			if (++j == d.sy) {
+				j = 0;
+				k++;
+			}
+		}
+	}
+}
 // knExtrapolateIntoBnd, fastmarch.cpp:261-300 (bnd = 0: every cell; only border cells change)
 __global__ void __launch_bounds__(BLOCK)
 k_extrap_into_bnd(Dim d, const int32_t* __restrict__ flags, float* __restrict__ vel, const float* __restrict__ velTmp) {
@@ -227,8 +298,13 @@ int mf_extrapolate_mac_simple(int sx, int sy, int sz, const int32_t* flags, floa
 	const int dim = d.is3d ? 3 : 2;
 	for (int c = 0; c < dim; c++) {
 		hipLaunchKernelGGL(k_extrap_mark, dim3(nblk(d)), dim3(BLOCK), 0, st, d, flags, tmp, c, intoObs);
-		for (int dd = 1; dd < 1 + distance; dd++)
-			hipLaunchKernelGGL(k_extrap_simple, dim3(nblk(d)), dim3(BLOCK), 0, st, d, vel + c * d.n, tmp, dd);
+		const bool quads = d.is3d && ((((uintptr_t)tmp) & 15) == 0);
+		for (int dd = 1; dd < 1 + distance; dd++) {
+			if (quads)
+				hipLaunchKernelGGL(k_extrap_simple4, dim3((unsigned)((d.n / 4 + BLOCK) / BLOCK)), dim3(BLOCK), 0, st, d, vel + c * d.n, tmp, dd);
+			else
+				hipLaunchKernelGGL(k_extrap_simple, dim3(nblk(d)), dim3(BLOCK), 0, st, d, vel + c * d.n, tmp, dd);
+		}
 	}
 	MF_HIP(hipMemcpyAsync(velTmp, vel, sizeof(float) * 3 * d.n, hipMemcpyDeviceToDevice, st));
 	hipLaunchKernelGGL(k_extrap_into_bnd, dim3(nblk(d)), dim3(BLOCK), 0, st, d, flags, vel, velTmp);

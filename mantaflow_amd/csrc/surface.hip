@@ -159,13 +159,16 @@ k_union_levelset(Dim d, int64_t ps, const float* __restrict__ pos, const int32_t
 	float phiv = (float)((double)radius * 1.0);
 	const int r = (int)radius + 1, rZ = d.is3d ? r : 0;
 	const float eps2 = 1e-6f * 1e-6f;
+	// the cells xj = i-r .. i+r of a row (yj, zj) are consecutive entries of the particle index: one [start, end) range per row -- two index
+	// loads instead of 2 (2r + 1), the particles in the reference's order (cell by cell, slot by slot).  Most cells of a liquid scene
+	// are far from every particle and only ever read the index.
+	const int xlo = i - r < 0 ? 0 : i - r, xhi = i + r > d.sx - 1 ? d.sx - 1 : i + r;
 	for (int zj = k - rZ; zj <= k + rZ; zj++)
-		for (int yj = j - r; yj <= j + r; yj++)
-			for (int xj = i - r; xj <= i + r; xj++) {
-				if (!in_bounds(d, xj, yj, zj)) continue;
-				const int64_t c = cidx(d, xj, yj, zj);
-				const int64_t pStart = index[c];
-				const int64_t pEnd = (c + 1 < d.n) ? (int64_t)index[c + 1] : n_indexed;
+		for (int yj = j - r; yj <= j + r; yj++) {
+				if (!in_bounds(d, xlo, yj, zj)) continue;
+				const int64_t c0 = cidx(d, xlo, yj, zj), c1 = cidx(d, xhi, yj, zj);
+				const int64_t pStart = index[c0];
+				const int64_t pEnd = (c1 + 1 < d.n) ? (int64_t)index[c1 + 1] : n_indexed;
 				for (int64_t q = pStart; q < pEnd; q++) {
 					const int psrc = isys[q];
 					if (ptype && (ptype[psrc] & exclude)) continue;
