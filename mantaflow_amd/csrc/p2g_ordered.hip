@@ -553,6 +553,29 @@ k_gather_wave(Dim d, int ntx, int nty, const float4* __restrict__ rec, const uin
 	const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
 	const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
 	const int x0 = tx * GX - LX, y0 = ty * GY - LY, z0 = tz * GZ - LZ;
+	// most tiles of a liquid scene have no particle anywhere near: the cells of a row of the neighbourhood are consecutive entries of
+	// `start`, so one lane per row (two loads) tells whether the whole neighbourhood is empty before the per-cell table is built
+	{
+		static_assert(NROW <= GBLOCK, "one lane per row of the neighbourhood");
+		int rowcnt = 0;
+		if (t < NROW) {
+			const int by = y0 + t % BYN, bz = z0 + t / BYN;
+			const int xa = x0 < 0 ? 0 : x0, xb = x0 + BXN > d.sx ? d.sx : x0 + BXN;      // cells [xa, xb) of the row
+			if (by >= 0 && bz >= 0 && by < d.sy && bz < d.sz && xa < xb) {
+				const int64_t c = d.sx * ((int64_t)by + (int64_t)d.sy * bz);
+				rowcnt = start[c + xb] - start[c + xa];
+			}
+		}
+		if (!__any(rowcnt != 0)) {
+			const int i = tx * GX + (t % GX), j = ty * GY + (t / GX) % GY, k = tz * GZ + t / (GX * GY);
+			if (i < d.sx && j < d.sy && k < d.sz) {
+				const int64_t node = (int64_t)i + d.sx * ((int64_t)j + (int64_t)d.sy * k);
+				sum[node] = 0.f;
+				ref[node] = 0.f;
+			}
+			return;
+		}
+	}
 	// cell table: run length of every cell of the neighbourhood (0 outside the grid), exclusive scan over the wave -> local slots
 	int cnt[PER], gst[PER], tot = 0;
 #pragma unroll
