@@ -320,7 +320,7 @@ constexpr int ROWS_THREADS = 448;
 #endif
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(ROWS_THREADS)
-k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int* __restrict__ order, FlowCtl* ctl, int* xt,
+k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, int xoff0, const int* __restrict__ order, FlowCtl* ctl, int* xt,
            unsigned long long* xj, unsigned long long* xk, unsigned gen, const int32_t* __restrict__ flags,
            float* __restrict__ dst, const float* __restrict__ var1, const float* __restrict__ Ap,
            const float* __restrict__ Ai, const float* __restrict__ Aj, const float* __restrict__ Ak,
@@ -386,8 +386,10 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, const int
 		const int j = tj * 8 + (REV ? 7 - b : b), k = tk * 8 + (REV ? 7 - c : c);
 		const bool row_in = (j < d.sy) && (k < d.sz);
 		// x-block xb (mf_set_mic_blocking_x: the caller has zeroed the Ai coupling across the block faces): an independent
-		// system of X8 cells starting at xoff; one x-block = the whole row = the reference algorithm
-		const int xoff = xb * X8;
+		// system of X8 cells starting at xoff; one x-block = the whole row = the reference algorithm.  xoff0 (mf_cg_solve, liquid
+		// scenes): the rows are swept over the cells [xoff0, xoff0 + X8) only -- every cell outside is a non-fluid cell without couplings
+		// (zero packed byte) whose value is +0 and stays +0, which is what the first / last cell inside would read from it
+		const int xoff = xb * X8 + xoff0;
 		const int xlim = d.sx - xoff < X8 ? d.sx - xoff : X8;          // cells of this x-block that exist
 		const int64_t rowbase = d.Y * j + d.Z * k + xoff;
 
@@ -1386,6 +1388,8 @@ static thread_local int g_dot_count = 0;
 static thread_local bool g_dot_empty_ext = false;
 static thread_local BetaTail g_dot_tail = BetaTail{nullptr, 0, nullptr, nullptr, 0};
 static thread_local bool g_dot_tail_done = false;
+// x-range the caller asks the sweeps of the registered system to keep to (mf::mic_set_trim): first cell, chunks of 8 cells; 0 = whole rows
+static thread_local int g_trim_xoff = 0, g_trim_chunks = 0;
 template <int MODE>
 static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                       const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
@@ -1436,6 +1440,12 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				if (f->nempty_host > 0 && f->nblocks > grid)
 					hipLaunchKernelGGL(k_mic_empty_dot, dim3(f->nblocks), dim3(BLOCK), 0, st, d, f->nbj, f->nbk, f->nchunks * 8, be, dst, var1, sc, dotp);
 			}
+			// rows trimmed to the x-range of the fluid (mic_set_trim; only for the registered system on its packed bytes)
+			int nch = f->nchunks, xoff0 = 0;
+			if (same_system && use_pack && g_trim_chunks > 0 && g_trim_chunks < f->nchunks && f->nxb == 1) {
+				nch = g_trim_chunks;
+				xoff0 = g_trim_xoff;
+			}
 			BetaTail ktail = BetaTail{nullptr, 0, nullptr, nullptr, 0};
 			if (MODE == 2 && dotp && (g_dot_tail.sc || g_dot_tail.sum_out) && !(be && f->nblocks > grid && !empty_ext && f->nempty_host > 0)) {
 				// (not with the separate empty-share kernel: its partials are plain stores of another launch -- fine -- but keep it simple)
@@ -1444,9 +1454,9 @@ static int launch_mic(const Dim& d, const int32_t* flags, float* dst, const floa
 				g_dot_tail_done = true;
 			}
 			if (vec)
-				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext, ktail);
+				hipLaunchKernelGGL((k_mic_rows<MODE, true>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, nch, xoff0, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext, ktail);
 			else
-				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, f->nchunks, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext, ktail);
+				hipLaunchKernelGGL((k_mic_rows<MODE, false>), dim3(grid), dim3(ROWS_THREADS), 0, st, d, f->nbj, f->nbk, f->jb, f->nblocks, nch, xoff0, f->border + (MODE == 2 ? f->nblocks : 0), f->ctl, f->rows_xt + (MODE == 2 ? 1 : 0), f->sxj, f->sxk, f->sgen, flags, dst, var1, Ap, Ai, Aj, Ak, sc, dotp, be, pk, f->pack_ok, empty_ext, ktail);
 			MF_LAUNCH_CHECK();
 			return 0;
 		}
@@ -1489,6 +1499,10 @@ static __global__ void __launch_bounds__(BLOCK) k_mic_fin_maxabs_live(int nb, co
 }
 
 namespace mf {
+void mic_set_trim(int xoff_cells, int nchunks) {
+	g_trim_xoff = xoff_cells;
+	g_trim_chunks = nchunks;
+}
 int mic_launch(int mode, const Dim& d, const int32_t* flags, float* dst, const float* var1, const float* Ap, const float* Ai,
                const float* Aj, const float* Ak, const CgScalars* sc, hipStream_t st) {
 	if (mode == 0) return launch_mic<0>(d, flags, dst, var1, Ap, Ai, Aj, Ak, sc, st);

@@ -55,6 +55,10 @@ int mic_pack_query(const Dim& d, const int32_t* flags, const float* A0, const fl
 // packed bytes built by mf_pack_matrix for exactly these grids, or nullptr (no synchronisation); *a0_packed: they carry this A0
 const unsigned char* mic_pack_user(const int32_t* flags, const float* A0, const float* Ai, const float* Aj, const float* Ak, bool* a0_packed);
 int mic_mode();          // the requested sweep mode: 0 levels, 2 rows
+// until reset with (0, 0): the apply sweeps of the registered system (on its packed bytes) cover the cells [xoff, xoff + 8 nchunks) of
+// every row only.  The caller guarantees that every cell outside has a zero packed byte (non-fluid, no couplings) and the value +0 in
+// the swept grid, and accounts for nothing of them in the fused dot (their products are +0).
+void mic_set_trim(int xoff_cells, int nchunks);
 // matrix-free set-up of mf_solve_pressure_fused: buffers of the system handle (empty-bundle map preset to 1 = empty), then the MIC
 // factor from the packed bytes and the registration of (flags, Aprecond) as a system without coefficient arrays
 int mic_fused_begin(const Dim& d, hipStream_t st, unsigned char** pack, int** bempty, int* nbj);

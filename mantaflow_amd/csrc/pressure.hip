@@ -1360,15 +1360,43 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
 // outside the fluid and the work grids are fresh zero grids, so every PCG vector is zero in those bundles and stays zero (ApplyMatrix copies
 // src, the sweeps leave them out, the vector updates combine zeros) -- the kernels of an iteration then skip them altogether.  This kernel
 // is what establishes the premise, on the device, once per solve: bad[0] counts the quads of empty bundles in which rhs or tmp is not +0.
+// x-range of the packed system (bytes of k_mic_pack / k_setup_fused; sx % 8 == 0): xr[0] = first cell with a non-zero byte, xr[1] = one
+// past the last one, plus one (a set "Ai is -1" bit couples the cell behind it).  Cells outside are non-fluid cells without couplings.
+__global__ void __launch_bounds__(BLOCK)
+k_pack_xrange(int64_t n, int sx, const unsigned char* __restrict__ pack, int* __restrict__ xr) {
+	int lo = 0x7fffffff, hi = 0;
+	const int64_t n8 = n >> 3;
+	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n8; q += (int64_t)gridDim.x * BLOCK) {
+		const unsigned long long w = ((const unsigned long long*)pack)[q];
+		if (w == 0ull) continue;
+		const int x0 = (int)((8 * q) % sx);
+		const int a = x0 + (__ffsll((long long)w) - 1) / 8, b = x0 + (63 - __clzll((long long)w)) / 8 + 2;
+		lo = a < lo ? a : lo;
+		hi = b > hi ? b : hi;
+	}
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) {
+		const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+		lo = l2 < lo ? l2 : lo;
+		hi = h2 > hi ? h2 : hi;
+	}
+	if ((threadIdx.x & 63) == 0 && hi > 0) {
+		atomicMin(&xr[0], lo);
+		atomicMax(&xr[1], hi);
+	}
+}
 __global__ void __launch_bounds__(BLOCK)
 k_cg_outside_zero(int64_t n, int sx, int sy, const int* __restrict__ bempty, int nbj, const float* __restrict__ rhs, const float* __restrict__ tmp,
-                  const float* __restrict__ search, int* __restrict__ bad) {
+                  const float* __restrict__ search, int* __restrict__ bad, const int* __restrict__ xr) {
 	const int64_t n4 = n >> 2;
 	int found = 0;
+	// (xr: also the cells outside the x-range of the packed system, rounded outwards to chunks of 8 -- what the trimmed sweeps leave out)
+	const int xlo = xr ? (xr[0] & ~7) : 0, xhi = xr ? ((xr[1] + 7) & ~7) : sx;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
 		const int64_t row = (4 * q) / sx;
 		const int j = (int)(row % sy), k = (int)(row / sy);
-		if (!bempty[(k >> 3) * nbj + (j >> 3)]) continue;
+		const int x = (int)(4 * q - row * sx);
+		if (!bempty[(k >> 3) * nbj + (j >> 3)] && x >= xlo && x < xhi) continue;
 		const uint4 a = ((const uint4*)rhs)[q], b = ((const uint4*)tmp)[q], c = ((const uint4*)search)[q];
 		if ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w | c.x | c.y | c.z | c.w) != 0u) found = 1;
 	}
@@ -1428,11 +1456,28 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	const int* sk_map = be_map;
 	int sk_nbj = be_nbj;
 	if (!sk_map && pc == MF_PC_MICP && (sx % 4) == 0) MF_TRY(mic_empty_map(d, flags, Aprecond, Aj, Ak, &sk_map, &sk_nbj, st, true));
+	// ... and the sweeps keep to the x-range of the fluid (the packed bytes tell it), if the host may know that everything outside is +0
+	struct TrimGuard {
+		~TrimGuard() { mic_set_trim(0, 0); }
+	} trim_guard;
 	if (sk_map) {
 		// (n % 4 == 0 here: sx % 4 == 0.)  residual = rhs and dst = 0 were set above; tmp and search are the caller's
-		MF_HIP(hipMemsetAsync(p_bad, 0, sizeof(int), st));
-		hipLaunchKernelGGL(k_cg_outside_zero, dim3(nbs), dim3(BLOCK), 0, st, n, sx, sy, sk_map, sk_nbj, rhs, tmp, search, p_bad);
+		int* p_xr = p_bad + 1;
+		const bool ranged = am_pack != nullptr && (sx % 8) == 0;
+		const int init3[3] = {0, 0x7fffffff, 0};
+		MF_HIP(hipMemcpyAsync(p_bad, init3, sizeof init3, hipMemcpyHostToDevice, st));
+		if (ranged) hipLaunchKernelGGL(k_pack_xrange, dim3(blocks_for(n >> 3, BLOCK, 2048)), dim3(BLOCK), 0, st, n, sx, am_pack, p_xr);
+		hipLaunchKernelGGL(k_cg_outside_zero, dim3(nbs), dim3(BLOCK), 0, st, n, sx, sy, sk_map, sk_nbj, rhs, tmp, search, p_bad, ranged ? p_xr : nullptr);
 		MF_LAUNCH_CHECK();
+		static const bool notrim = getenv("MF_MIC_NOTRIM") != nullptr;
+		if (ranged && !notrim) {
+			int h3[3] = {1, 0, 0};
+			MF_HIP(hipMemcpyAsync(h3, p_bad, sizeof h3, hipMemcpyDeviceToHost, st));
+			MF_HIP(hipStreamSynchronize(st));
+			int c0 = h3[1] >> 3, c1 = (h3[2] + 7) >> 3;
+			if (c1 > sx / 8) c1 = sx / 8;
+			if (h3[0] == 0 && h3[2] > 0 && c1 > c0) mic_set_trim(8 * c0, c1 - c0);
+		}
 	}
 	const int batch = (pc == MF_PC_MICP && mic_mode() == 0) ? 1 : 4;
 	CgScalars h;
