@@ -123,7 +123,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
                   const float* __restrict__ A0, const float* __restrict__ Ai, const float* __restrict__ Aj,
                   const float* __restrict__ Ak, double* __restrict__ partials, const CgScalars* __restrict__ sc, int jgroups, int tpb,
                   const unsigned char* __restrict__ pack, int dk0, int dk1, int a0p, const int* __restrict__ bempty = nullptr, int nbj = 0,
-                  const int* __restrict__ outside_bad = nullptr) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
+                  const int* __restrict__ outside_bad = nullptr, const int* __restrict__ xr = nullptr) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
 	// bempty (mf_cg_solve, liquid scenes): 8 x 8 bundles of rows without a fluid cell in which src is known to be zero (k_cg_outside_zero found
 	// rhs and the work grids zero there, and every kernel of the iteration keeps it so): dst = src = 0 is there already, nothing to do
 	// a0p (PACKED only): bits 4-7 of the packed bytes hold the diagonal (k_mic_pack) -- A0 is not read at all, 9 instead of 13 B per cell
@@ -142,7 +142,16 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	const int j0 = (int)(rg % jgroups) * R;
 	const int k = (int)(rg / jgroups);
 	// (R divides 8: the rows of a thread lie in one bundle; the lanes this thread exchanges +-X neighbours with work on the same rows)
-	if (IS3D && bempty && outside_bad[0] == 0 && bempty[(k >> 3) * nbj + (j0 >> 3)]) continue;
+	// (xr: the x-range of the system's non-zero packed bytes, k_pack_xrange -- the quads outside it are as empty as the empty bundles;
+	// the first / last quad inside fetch their outer x-neighbour themselves, the lane next to them has left)
+	int q_lo = 0, q_hi = qx;
+	if (IS3D && bempty && outside_bad[0] == 0) {
+		if (xr) {
+			q_lo = (xr[0] & ~7) >> 2;
+			q_hi = ((xr[1] + 7) & ~7) >> 2;
+		}
+		if (bempty[(k >> 3) * nbj + (j0 >> 3)] || qi < q_lo || qi >= q_hi) continue;
+	}
 	const int lane = threadIdx.x & 63;
 	const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 	const int64_t Y = d.Y, Z = d.Z;
@@ -193,7 +202,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 		sv[R + 1] = *(const float4*)(src + row0 + jr * Y);
 	}
 	// ---- +-X neighbours: adjacent lanes hold the adjacent quads of the same row, except at row / wave edges ----
-	const bool edge_l = (lane == 0) || (qi == 0), edge_r = (lane == 63) || (qi == qx - 1);
+	const bool edge_l = (lane == 0) || (qi == 0) || (qi == q_lo), edge_r = (lane == 63) || (qi == qx - 1) || (qi == q_hi - 1);
 #pragma unroll
 	for (int r = 0; r < R; r++) {
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
@@ -307,7 +316,7 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
                                const float* Ai, const float* Aj, const float* Ak, double* partials,
                                const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr,
                                int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr, bool a0p = false, const int* bempty = nullptr,
-                               int nbj = 0, const int* outside_bad = nullptr) {
+                               int nbj = 0, const int* outside_bad = nullptr, const int* xr = nullptr) {
 	if (ranged) *ranged = false;
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
@@ -323,11 +332,11 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
 		nb = (int)((vblocks + tpb - 1) / tpb);
 #define AM5(RR)                                                                                                                                   \
 	if (d.is3d && pack)                                                                                                                           \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad, xr); \
 	else if (d.is3d)                                                                                                                              \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad, xr); \
 	else                                                                                                                                          \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad);
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad, xr);
 		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
 #undef AM5
 		if (ranged) *ranged = true;
@@ -662,11 +671,12 @@ template <bool COPY_TMP, bool EDOT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart,
             double* __restrict__ dpart, const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0,
-            double* __restrict__ epart = nullptr, const int* __restrict__ outside_bad = nullptr) {
+            double* __restrict__ epart = nullptr, const int* __restrict__ outside_bad = nullptr, const int* __restrict__ xr = nullptr) {
 	if (sc->done) return;
 	// outside_bad[0] == 0 (k_cg_outside_zero): residual and tmp are zero in the bundles the sweeps leave out and stay so -- their quads
 	// are neither read nor written, they enter the min / max as the zeros they are and add nothing to the sums
 	const bool zero_outside = EDOT && outside_bad[0] == 0;
+	const int xlo = (EDOT && xr) ? (xr[0] & ~7) : 0, xhi = (EDOT && xr) ? ((xr[1] + 7) & ~7) : 0x7fffffff;
 	const float nalpha = sc->nalpha;
 	const bool l2 = sc->useL2 != 0;
 	float lo = FLT_MAX, hi = -FLT_MAX;
@@ -678,7 +688,8 @@ k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ res
 			const int64_t row = (4 * q) / sx;
 			const int j = (int)(row % sy), k = (int)(row / sy);
 			in_empty = bempty[(k >> 3) * nbj + (j >> 3)] != 0;
-			if (in_empty && zero_outside) {
+			const int x = (int)(4 * q - row * sx);
+			if (zero_outside && (in_empty || x < xlo || x >= xhi)) {
 				lo = fminf(lo, 0.f);
 				hi = fmaxf(hi, 0.f);
 				continue;
@@ -876,9 +887,11 @@ k_cg_update_search(int64_t n, CgScalars* __restrict__ sc, float* __restrict__ se
 template <bool SKIP>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp,
-                     const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0, const int* __restrict__ outside_bad = nullptr) {
+                     const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0, const int* __restrict__ outside_bad = nullptr,
+                     const int* __restrict__ xr = nullptr) {
 	if (!sc->xpending) return;
 	const bool upd = !sc->done;
+	const int xlo = (SKIP && xr) ? (xr[0] & ~7) : 0, xhi = (SKIP && xr) ? ((xr[1] + 7) & ~7) : 0x7fffffff;
 	const float alpha = sc->alpha, beta = sc->beta;
 	const int64_t n4 = n >> 2;
 	const bool zero_outside = SKIP && outside_bad[0] == 0;
@@ -886,7 +899,8 @@ k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restr
 		if (SKIP && zero_outside) {
 			const int64_t row = (4 * q) / sx;
 			const int j = (int)(row % sy), k = (int)(row / sy);
-			if (bempty[(k >> 3) * nbj + (j >> 3)]) continue;
+			const int xc = (int)(4 * q - row * sx);
+			if (bempty[(k >> 3) * nbj + (j >> 3)] || xc < xlo || xc >= xhi) continue;
 		}
 		float4 s = ((float4*)search)[q];
 		float4 x = ((float4*)dst)[q];
@@ -1460,10 +1474,12 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	struct TrimGuard {
 		~TrimGuard() { mic_set_trim(0, 0); }
 	} trim_guard;
+	const int* xr_dev = nullptr;      // device x-range of the packed system, for the kernels that skip by it
 	if (sk_map) {
 		// (n % 4 == 0 here: sx % 4 == 0.)  residual = rhs and dst = 0 were set above; tmp and search are the caller's
 		int* p_xr = p_bad + 1;
 		const bool ranged = am_pack != nullptr && (sx % 8) == 0;
+		if (ranged) xr_dev = p_xr;
 		const int init3[3] = {0, 0x7fffffff, 0};
 		MF_HIP(hipMemcpyAsync(p_bad, init3, sizeof init3, hipMemcpyHostToDevice, st));
 		if (ranged) hipLaunchKernelGGL(k_pack_xrange, dim3(blocks_for(n >> 3, BLOCK, 2048)), dim3(BLOCK), 0, st, n, sx, am_pack, p_xr);
@@ -1500,11 +1516,11 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 			int nba = 0, nsig = 0;
 			bool beta_done = false;
 			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p, sk_map,
-			                                 sk_nbj, sk_map ? p_bad : nullptr));
+			                                 sk_nbj, sk_map ? p_bad : nullptr, xr_dev));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
 				if (sk_map)      // (without be_map the shares it writes behind the sweep's partials are not summed: the sweep has them)
-					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, sk_map, sk_nbj, sx, sy, p_sig + be_nb, p_bad);
+					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, sk_map, sk_nbj, sx, sy, p_sig + be_nb, p_bad, xr_dev);
 				else
 					hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
@@ -1526,7 +1542,7 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 			}
 			if (!beta_done) hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
 			if (sk_map)
-				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, sk_map, sk_nbj, sx, sy, p_bad);
+				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, sk_map, sk_nbj, sx, sy, p_bad, xr_dev);
 			else
 				hipLaunchKernelGGL((k_cg_update_search_x<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
 		}
