@@ -196,6 +196,9 @@ int mf_mic_apply_dot_dev(int sx, int sy, int sz, const int32_t* flags, float* ds
  *   Aprecond after the call are unspecified: with the MIC preconditioner and a row length that is not a multiple of 8 the loop
  *   runs on an internal copy of the system whose rows are padded with obstacle cells -- same iterates, 16-byte rows)
  *   pc = MF_PC_NONE | MF_PC_MICP; Aprecond: grid for the MIC factor (pca0), unused for PC_NONE
+ *   Liquid scenes (MIC-PCG): where 8 x 8 bundles of x-rows hold no fluid cell, or the fluid keeps to a part of the x-range, and rhs
+ *   and the incoming work grids are +0 there -- checked on the device, once per call -- the kernels of an iteration leave those
+ *   cells out: they stay +0, as they do in the reference.  A rhs that is not zero there is solved without the shortcut.
  *   out_host[0] = iterations done, out_host[1] = final residual norm (mResNorm), out_host[2] = mSigma
  * returns non-zero with message "The CG solver diverged" when resNorm !< 1e35 (conjugategrad.cpp:288-295). */
 int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual,
