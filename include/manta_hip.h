@@ -205,6 +205,10 @@ int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const 
                 float* search, float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak,
                 float* Aprecond, int pc, float accuracy, int maxIter, int useL2Norm,
                 float* out_host, void* stream);
+/* What the last mf_cg_solve / mf_solve_pressure_fused of this thread did with a liquid scene (see above): out[0] = 1 when its streaming
+ * kernels were allowed to leave the fluid-free bundles out, out[1] / out[2] = first cell and number of cells of the x-range its MIC
+ * sweeps kept to (0 / 0: whole rows).  For tests and diagnostics; the oracle reports zeros (it has no shortcut). */
+int mf_cg_last_shortcut(int32_t* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Advection (plugin/advection.cpp)

@@ -10,6 +10,8 @@
 
 using namespace mf;
 
+static thread_local int g_last_shortcut[3] = {0, 0, 0};      // what mf_cg_last_shortcut reports
+
 // =========================================================================================================
 // ApplyMatrix, conjugategrad.h:118-151
 //   non-fluid: dst = src ; fluid: left-to-right fp32 sum of the 7 products.  28 B/cell of compulsory traffic
@@ -1308,6 +1310,12 @@ int mf_diffusion_matrix(int sx, int sy, int sz, const int32_t* flags, float* A0,
 	return 0;
 }
 
+int mf_cg_last_shortcut(int32_t* out) {
+	out[0] = g_last_shortcut[0];
+	out[1] = g_last_shortcut[1];
+	out[2] = g_last_shortcut[2];
+	return 0;
+}
 int mf_cg_solve(int sx, int sy, int sz, const int32_t* flags, float* dst, const float* rhs, float* residual, float* search,
                 float* tmp, const float* A0, const float* Ai, const float* Aj, const float* Ak, float* Aprecond, int pc,
                 float accuracy, int maxIter, int useL2Norm, float* out_host, void* stream) {
@@ -1474,6 +1482,7 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	struct TrimGuard {
 		~TrimGuard() { mic_set_trim(0, 0); }
 	} trim_guard;
+	g_last_shortcut[0] = g_last_shortcut[1] = g_last_shortcut[2] = 0;
 	const int* xr_dev = nullptr;      // device x-range of the packed system, for the kernels that skip by it
 	if (sk_map) {
 		// (n % 4 == 0 here: sx % 4 == 0.)  residual = rhs and dst = 0 were set above; tmp and search are the caller's
@@ -1492,7 +1501,14 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 			MF_HIP(hipStreamSynchronize(st));
 			int c0 = h3[1] >> 3, c1 = (h3[2] + 7) >> 3;
 			if (c1 > sx / 8) c1 = sx / 8;
-			if (h3[0] == 0 && h3[2] > 0 && c1 > c0) mic_set_trim(8 * c0, c1 - c0);
+			if (h3[0] == 0 && h3[2] > 0 && c1 > c0) {
+				mic_set_trim(8 * c0, c1 - c0);
+				g_last_shortcut[0] = 1;
+				if (c1 - c0 < sx / 8) {
+					g_last_shortcut[1] = 8 * c0;
+					g_last_shortcut[2] = 8 * (c1 - c0);
+				}
+			}
 		}
 	}
 	const int batch = (pc == MF_PC_MICP && mic_mode() == 0) ? 1 : 4;

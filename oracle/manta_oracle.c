@@ -32,6 +32,11 @@ static int fail(const char* msg) {
 const char* mf_last_error(void) { return g_err; }
 const char* mf_backend(void) { return "oracle"; }
 int mf_abi_version(void) { return MF_ABI_VERSION; }
+/* the restatement has no liquid-scene shortcut: it sweeps and streams every cell (include/manta_hip.h: mf_cg_last_shortcut) */
+int mf_cg_last_shortcut(int32_t* out) {
+	out[0] = out[1] = out[2] = 0;
+	return 0;
+}
 
 typedef struct {
 	int sx, sy, sz;

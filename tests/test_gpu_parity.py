@@ -361,6 +361,47 @@ def test_solve_pressure_plain_system_paths(hip, hip_backend):
         _close(got["vel"], b["vel"], "vel")
 
 
+@pytest.mark.parametrize("dims,box", [((64, 40, 24), (19, 45, 1, 22, 1, 23)), ((64, 40, 24), (1, 30, 1, 17, 1, 23)), ((64, 40, 24), (40, 63, 9, 31, 1, 23)),
+                                      ((61, 40, 24), (21, 44, 1, 22, 1, 23))])
+def test_solve_pressure_liquid_shortcuts(hip_backend, dims, box):
+    """A body of liquid strictly inside the box, away from the x walls or against one of them: most 8 x 8 bundles of rows hold no fluid
+    and the fluid keeps to a part of the x-range, so mf_cg_solve skips the empty bundles in its streaming kernels and trims the MIC sweeps
+    to the fluid's x-range (chunks of 8 cells; 61 cells per row: on the padded internal system).  Against the oracle, which does neither:
+    rhs bit-exact, the same iteration count, fields within 1e-5 -- with and without the ghost-fluid boundary (phi)."""
+    from mantaflow_amd import _lib, plugins
+    sx, sy, sz = dims
+    x0, x1, y0, y1, z0, z1 = box
+    flags = np.full((sz, sy, sx), 4, np.int32)                 # empty
+    flags[:, :, 0] = flags[:, :, -1] = flags[:, 0, :] = flags[:, -1, :] = 2
+    flags[0] = flags[-1] = 2
+    flags[z0:z1, y0:y1, x0:x1] = 1                              # fluid
+    flags[3:7, 3:9, x0 + 2:x0 + 6] = 2                          # an obstacle inside the liquid
+    vel = util.rand_vel(sx, sy, sz, 31, 0.5)
+    zz, yy, xx = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+    inside = (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1) & (zz >= z0) & (zz < z1)
+    phi = np.where(inside, -0.6, 0.7).astype(np.float32) + (0.05 * np.sin(xx * 0.9 + yy * 0.4)).astype(np.float32)
+    import ctypes
+    for ph in (None, phi):
+        a = cases.run_solve_pressure_pkg(dims, flags, vel, ph)
+        it_a = plugins.lastCgStats()["iterations"]
+        # the shortcut was taken: bundles skipped, sweeps trimmed to the chunks of 8 cells around [x0, x1] (one cell more behind the last
+        # fluid cell: its Ai bit couples it)
+        sc = (ctypes.c_int32 * 3)()
+        assert _lib.get().cdll.mf_cg_last_shortcut(sc) == 0
+        assert sc[0] == 1 and sc[1] == (x0 // 8) * 8 and sc[1] + sc[2] == min(((x1 + 1 + 7) // 8) * 8, ((sx + 7) // 8) * 8), list(sc)
+        _lib.use_library(util.build_oracle(), "cpu")
+        b = cases.run_solve_pressure_pkg(dims, flags, vel, ph)
+        it_b = plugins.lastCgStats()["iterations"]
+        _lib.reset()
+        assert it_a == it_b and it_b > 3, (it_a, it_b)
+        assert_bitexact(a["rhs"], b["rhs"], "rhs")
+        _close(a["pressure"], b["pressure"], "pressure")
+        _close(a["vel"], b["vel"], "vel")
+        # outside the liquid the pressure is exactly what the reference leaves there
+        assert_bitexact(np.where(flags == 1, 0, a["pressure"]).astype(np.float32), np.where(flags == 1, 0, b["pressure"]).astype(np.float32),
+                        "pressure outside the fluid")
+
+
 @pytest.mark.parametrize("terms,liquid", cases.PRESSURE_OPTIONAL_CASES)
 @pytest.mark.parametrize("dims", [(24, 20, 16), cases.SIZE_2D])
 def test_solve_pressure_optional_terms(hip_backend, dims, terms, liquid):
