@@ -437,6 +437,9 @@ __device__ __forceinline__ void clamp_cell(const Dim& d, const int32_t* __restri
 	}
 }
 
+#ifndef ADV_NT
+#define ADV_NT 1
+#endif
 // MacCormackCorrect<T> + MacCormackClamp<T> (advection.cpp:82-92, 145-187, 242-268) in one pass over the grid
 template <int NCOMP>
 __global__ void __launch_bounds__(BLOCK)
@@ -450,10 +453,10 @@ k_mc_correct_clamp(Dim d, const int32_t* __restrict__ flags, const float* __rest
 #pragma unroll
 	for (int c = 0; c < NCOMP; c++) {
 		const int64_t q = c * d.n + idx;
-		fw[c] = fwd[q];
+		fw[c] = ADV_NT ? __builtin_nontemporal_load(fwd + q) : fwd[q];      // fwd / bwd: read here once and never again
 		float v = fw[c];
 		if (fl) {
-			const float df = orig[q] - bwd[q];
+			const float df = orig[q] - (ADV_NT ? __builtin_nontemporal_load(bwd + q) : bwd[q]);
 			if (NCOMP == 1) v = (float)((double)v + sh * (double)df);
 			else v = v + (float)(sh * (double)df);
 		}
@@ -465,7 +468,10 @@ k_mc_correct_clamp(Dim d, const int32_t* __restrict__ flags, const float* __rest
 		clamp_cell<NCOMP>(d, flags, orig, i, j, k, vx * dt, vy * dt, vz * dt, dv, fw, clampMode);
 	}
 #pragma unroll
-	for (int c = 0; c < NCOMP; c++) dst[c * d.n + idx] = dv[c];
+	for (int c = 0; c < NCOMP; c++) {
+		if (ADV_NT) __builtin_nontemporal_store(dv[c], dst + c * d.n + idx);
+		else dst[c * d.n + idx] = dv[c];
+	}
 }
 
 // MacCormackCorrectMAC + MacCormackClampMAC (advection.cpp:95-116, 192-236, 271-288) in one pass
@@ -485,8 +491,8 @@ k_mc_correct_clamp_mac(Dim d, const int32_t* __restrict__ flags, const float* __
 #pragma unroll
 	for (int c = 0; c < 3; c++) {
 		const int64_t q = c * d.n + idx;
-		fw[c] = fwd[q];
-		dv[c] = skip[c] ? fw[c] : (float)((double)fw[c] + sh * (double)(orig[q] - bwd[q]));
+		fw[c] = ADV_NT ? __builtin_nontemporal_load(fwd + q) : fwd[q];
+		dv[c] = skip[c] ? fw[c] : (float)((double)fw[c] + sh * (double)(orig[q] - (ADV_NT ? __builtin_nontemporal_load(bwd + q) : bwd[q])));
 	}
 	if (INTERIOR(d)) {
 		float vx, vy, vz;
@@ -500,7 +506,10 @@ k_mc_correct_clamp_mac(Dim d, const int32_t* __restrict__ flags, const float* __
 		}
 	}
 #pragma unroll
-	for (int c = 0; c < 3; c++) dst[c * d.n + idx] = dv[c];
+	for (int c = 0; c < 3; c++) {
+		if (ADV_NT) __builtin_nontemporal_store(dv[c], dst + c * d.n + idx);
+		else dst[c * d.n + idx] = dv[c];
+	}
 }
 
 // extrapolateVelConvectiveBC + getBulkVel, advection.cpp:327-382 (KERNEL(): every cell; work only in outflow cells)

@@ -248,6 +248,26 @@ __device__ __forceinline__ double strided_sum(const double* __restrict__ p, int 
 	return acc;
 }
 
+// Non-temporal 16-byte accesses for data a kernel touches exactly once (streams that nothing re-reads from the caches): on gfx950 they
+// leave L2 / MALL to the operands that are re-read (stencil neighbours) -- ApplyMatrix 91 -> 69 us at 256^3 with A0 / Ai / flags loaded
+// and dst stored this way.
+__device__ __forceinline__ float4 ld_nt4(const float* p) {
+	typedef float v4 __attribute__((ext_vector_type(4)));
+	const v4 v = __builtin_nontemporal_load((const v4*)p);
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int4 ld_nt4i(const int32_t* p) {
+	typedef int v4 __attribute__((ext_vector_type(4)));
+	const v4 v = __builtin_nontemporal_load((const v4*)p);
+	return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt4(float* p, float4 a) {
+	typedef float v4 __attribute__((ext_vector_type(4)));
+	v4 o;
+	o.x = a.x; o.y = a.y; o.z = a.z; o.w = a.w;
+	__builtin_nontemporal_store(o, (v4*)p);
+}
+
 // ---- interpolation primitives, reference util/interpol.h -------------------------------------------------
 struct Bi {
 	int xi, yi, zi;

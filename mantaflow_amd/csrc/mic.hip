@@ -629,6 +629,8 @@ k_mic_rows(Dim d, int nbj, int nbk, int jb, int nstreams, int nchunks, int xoff0
 						if (MODE == 2 && with_dot) dacc += (double)(res * sR[slot]);
 					}
 					__hip_atomic_store(&s_flushed, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					// (non-temporal loads of Aprecond / var1 / dst or stores of dst make the sweeps slower -- 66.9-68.4 vs 63.7 ms per step: their
+					// hand-offs want the operands in L2 / MALL)
 					if (VEC) {
 						if (nv > 0) *(float4*)(dst + rowidx) = make_float4(w[0], w[1], w[2], w[3]);
 						if (nv > 4) *(float4*)(dst + rowidx + 4) = make_float4(w[4], w[5], w[6], w[7]);

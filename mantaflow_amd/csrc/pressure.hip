@@ -119,6 +119,9 @@ template <unsigned BIT>
 __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 	return make_float4((w & BIT) ? -1.f : 0.f, (w & (BIT << 8)) ? -1.f : 0.f, (w & (BIT << 16)) ? -1.f : 0.f, (w & (BIT << 24)) ? -1.f : 0.f);
 }
+#ifndef AM_NT
+#define AM_NT 2
+#endif
 template <bool DOT, bool IS3D, int R, bool PACKED>
 __global__ void __launch_bounds__(BLOCK)
 k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
@@ -176,15 +179,15 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 		unsigned pw = 0;
 		if (PACKED) pw = *(const unsigned*)(pack + idx);
 		if (PACKED && a0p) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
-		else a0[r] = *(const float4*)(A0 + idx);
+		else a0[r] = (AM_NT >= 1) ? ld_nt4(A0 + idx) : *(const float4*)(A0 + idx);
 		if (PACKED) {
 			f[r] = unpack_flags(pw);
 			ajv[r + 1] = unpack_coef<4u>(pw);
 			ai[r] = unpack_coef<2u>(pw);
 		} else {
-			f[r] = *(const int4*)(flags + idx);
-			ajv[r + 1] = *(const float4*)(Aj + idx);
-			ai[r] = *(const float4*)(Ai + idx);
+			f[r] = (AM_NT >= 1) ? ld_nt4i(flags + idx) : *(const int4*)(flags + idx);
+			ajv[r + 1] = (AM_NT >= 3) ? ld_nt4(Aj + idx) : *(const float4*)(Aj + idx);
+			ai[r] = (AM_NT >= 1) ? ld_nt4(Ai + idx) : *(const float4*)(Ai + idx);
 		}
 		if (IS3D) {
 			const int64_t im = (k > 0) ? idx - Z : idx, ip = (k < d.sz - 1) ? idx + Z : idx;
@@ -192,7 +195,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 				ak[r] = unpack_coef<8u>(pw);
 				akm[r] = unpack_coef<8u>(*(const unsigned*)(pack + im));
 			} else {
-				ak[r] = *(const float4*)(Ak + idx);
+				ak[r] = (AM_NT >= 3) ? ld_nt4(Ak + idx) : *(const float4*)(Ak + idx);
 				akm[r] = *(const float4*)(Ak + im);
 			}
 			szm[r] = *(const float4*)(src + im);
@@ -258,7 +261,8 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 #undef CELL5
 		}
 		if (live) {
-			*(float4*)(dst + row0 + r * Y) = res;
+			if (AM_NT >= 2 && !DOT) st_nt4(dst + row0 + r * Y, res);      // (inside the PCG -- DOT -- the next kernel reads dst back: no difference there)
+			else *(float4*)(dst + row0 + r * Y) = res;
 			if (DOT && k >= dk0 && k < dk1) {
 				const float p0 = res.x * s.x, p1 = res.y * s.y, p2 = res.z * s.z, p3 = res.w * s.w;
 				acc += (double)p0;
@@ -698,7 +702,7 @@ k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ res
 			}
 		}
 		float4 r = ((float4*)residual)[q];
-		const float4 t = ((const float4*)tmp)[q];
+		const float4 t = ((const float4*)tmp)[q];      // (non-temporal here: 64.4 vs 63.7 ms per step)
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		if (COPY_TMP) ((float4*)tmp)[q] = r;
@@ -905,11 +909,13 @@ k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restr
 			if (bempty[(k >> 3) * nbj + (j >> 3)] || xc < xlo || xc >= xhi) continue;
 		}
 		float4 s = ((float4*)search)[q];
-		float4 x = ((float4*)dst)[q];
+		// the pressure is touched here and nowhere else in an iteration, tmp for the last time before ApplyMatrix overwrites it: non-temporal,
+		// so that 128 MB per 256^3 iteration do not displace what the sweeps and the stencil re-read (63.1 vs 63.7 ms per step of tools/micro/ntv_bench.py)
+		float4 x = ld_nt4(dst + 4 * q);
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
-		((float4*)dst)[q] = x;
+		st_nt4(dst + 4 * q, x);
 		if (upd) {
-			const float4 t = ((const float4*)tmp)[q];
+			const float4 t = ld_nt4(tmp + 4 * q);
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
 			((float4*)search)[q] = s;
 		}
@@ -1056,11 +1062,11 @@ k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgSca
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
 		float4 s = ((float4*)search)[q];
-		float4 x = ((float4*)dst)[q];
+		float4 x = ld_nt4(dst + 4 * q);
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
-		((float4*)dst)[q] = x;
+		st_nt4(dst + 4 * q, x);
 		if (upd) {
-			const float4 t = ((const float4*)tmp)[q];
+			const float4 t = ld_nt4(tmp + 4 * q);
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
 			((float4*)search)[q] = s;
 		}

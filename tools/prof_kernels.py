@@ -21,6 +21,8 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n = int(os.environ.get("MF_GRID", "256"))
     dims = [int(v) for v in os.environ.get("MF_DIMS", "%d,%d,%d" % (n, n, n)).split(",")]
+    if os.environ.get("MF_LIB"):      # an experimental build of the library (tools/micro): A/B timing
+        _lib.use_library(os.path.abspath(os.environ["MF_LIB"]), "cuda")
     lib = _lib.get()
     if what in ("config3", "config4", "config5"):
         # exactly the workloads bench.py reports under other_configs (per-operator HIP-event times printed as JSON)
