@@ -122,6 +122,10 @@ __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 #ifndef AM_NT
 #define AM_NT 2
 #endif
+// AMP_NT: 1 = the thread's own src rows non-temporal as well (68.2 -> 66.2 us; the z neighbours too: 76.8 us)
+#ifndef AMP_NT
+#define AMP_NT 1
+#endif
 template <bool DOT, bool IS3D, int R, bool PACKED>
 __global__ void __launch_bounds__(BLOCK)
 k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ dst, const float* __restrict__ src,
@@ -175,7 +179,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	for (int r = 0; r < R; r++) {
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
 		const int64_t idx = row0 + jr * Y;
-		sv[r + 1] = *(const float4*)(src + idx);
+		sv[r + 1] = (AMP_NT & 1) ? ld_nt4(src + idx) : *(const float4*)(src + idx);
 		unsigned pw = 0;
 		if (PACKED) pw = *(const unsigned*)(pack + idx);
 		if (PACKED && a0p) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
@@ -198,8 +202,8 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 				ak[r] = (AM_NT >= 3) ? ld_nt4(Ak + idx) : *(const float4*)(Ak + idx);
 				akm[r] = *(const float4*)(Ak + im);
 			}
-			szm[r] = *(const float4*)(src + im);
-			szp[r] = *(const float4*)(src + ip);
+			szm[r] = (AMP_NT & 2) ? ld_nt4(src + im) : *(const float4*)(src + im);
+			szp[r] = (AMP_NT & 2) ? ld_nt4(src + ip) : *(const float4*)(src + ip);
 		}
 	}
 	{
