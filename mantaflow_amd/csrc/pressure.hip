@@ -122,6 +122,11 @@ __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 #ifndef AM_NT
 #define AM_NT 2
 #endif
+// (the z-slab search update with non-temporal pressure / tmp accesses AND non-temporal src rows in its ApplyMatrix: 74.1 vs 73.4 ms per
+// --slab step; either alone: no difference -- both off there)
+#ifndef SLAB_NT
+#define SLAB_NT 0
+#endif
 // AMP_NT: 1 = the thread's own src rows non-temporal as well (68.2 -> 66.2 us; the z neighbours too: 76.8 us)
 #ifndef AMP_NT
 #define AMP_NT 1
@@ -179,7 +184,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	for (int r = 0; r < R; r++) {
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
 		const int64_t idx = row0 + jr * Y;
-		sv[r + 1] = (AMP_NT & 1) ? ld_nt4(src + idx) : *(const float4*)(src + idx);
+		sv[r + 1] = ((AMP_NT & 1) && !DOT) ? ld_nt4(src + idx) : *(const float4*)(src + idx);      // (not inside the PCG: its neighbours re-read src)
 		unsigned pw = 0;
 		if (PACKED) pw = *(const unsigned*)(pack + idx);
 		if (PACKED && a0p) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
@@ -1066,11 +1071,12 @@ k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgSca
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
 		float4 s = ((float4*)search)[q];
-		float4 x = ld_nt4(dst + 4 * q);
+		float4 x = SLAB_NT ? ld_nt4(dst + 4 * q) : ((float4*)dst)[q];
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
-		st_nt4(dst + 4 * q, x);
+		if (SLAB_NT) st_nt4(dst + 4 * q, x);
+		else ((float4*)dst)[q] = x;
 		if (upd) {
-			const float4 t = ld_nt4(tmp + 4 * q);
+			const float4 t = SLAB_NT ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
 			((float4*)search)[q] = s;
 		}
