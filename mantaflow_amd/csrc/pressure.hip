@@ -122,10 +122,17 @@ __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 #ifndef AM_NT
 #define AM_NT 2
 #endif
-// (the z-slab search update with non-temporal pressure / tmp accesses AND non-temporal src rows in its ApplyMatrix: 74.1 vs 73.4 ms per
-// --slab step; either alone: no difference -- both off there)
+// SLAB_NT: the same in the z-slab kernels (k_slab_axpy_r, k_slab_update_search_x; their ApplyMatrix is the PCG one).  Only the complete set
+// pays: with the pressure / tmp accesses alone, or ApplyMatrix alone, `bench.py --slab` was 74.1-74.6 ms per step, with all of them 72.0-72.6
 #ifndef SLAB_NT
-#define SLAB_NT 0
+#define SLAB_NT 1
+#endif
+// PCG_NT_ALL: inside the PCG every vector stream EXCEPT the residual is non-temporal -- search and tmp in ApplyMatrix (own rows, result),
+// the residual update (tmp) and the search update (search, tmp, pressure) -- so that what the MIC sweeps read (residual, Aprecond, packed
+// bytes, tmp between the two sweeps) stays in L2 / the memory-side cache across the iteration: 72.3 -> 70.8 ms per 256^3 step.  Any one
+// of these changes alone: no difference or slower.
+#ifndef PCG_NT_ALL
+#define PCG_NT_ALL 1
 #endif
 // AMP_NT: 1 = the thread's own src rows non-temporal as well (68.2 -> 66.2 us; the z neighbours too: 76.8 us)
 #ifndef AMP_NT
@@ -184,7 +191,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	for (int r = 0; r < R; r++) {
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
 		const int64_t idx = row0 + jr * Y;
-		sv[r + 1] = ((AMP_NT & 1) && !DOT) ? ld_nt4(src + idx) : *(const float4*)(src + idx);      // (not inside the PCG: its neighbours re-read src)
+		sv[r + 1] = ((AMP_NT & 1) && (!DOT || PCG_NT_ALL)) ? ld_nt4(src + idx) : *(const float4*)(src + idx);      // (not inside the PCG: its neighbours re-read src)
 		unsigned pw = 0;
 		if (PACKED) pw = *(const unsigned*)(pack + idx);
 		if (PACKED && a0p) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
@@ -270,7 +277,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 #undef CELL5
 		}
 		if (live) {
-			if (AM_NT >= 2 && !DOT) st_nt4(dst + row0 + r * Y, res);      // (inside the PCG -- DOT -- the next kernel reads dst back: no difference there)
+			if (AM_NT >= 2 && (!DOT || PCG_NT_ALL)) st_nt4(dst + row0 + r * Y, res);      // (inside the PCG -- DOT -- the next kernel reads dst back: no difference there)
 			else *(float4*)(dst + row0 + r * Y) = res;
 			if (DOT && k >= dk0 && k < dk1) {
 				const float p0 = res.x * s.x, p1 = res.y * s.y, p2 = res.z * s.z, p3 = res.w * s.w;
@@ -711,7 +718,7 @@ k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ res
 			}
 		}
 		float4 r = ((float4*)residual)[q];
-		const float4 t = ((const float4*)tmp)[q];      // (non-temporal here: 64.4 vs 63.7 ms per step)
+		const float4 t = PCG_NT_ALL ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];      // (non-temporal here: 64.4 vs 63.7 ms per step)
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		if (COPY_TMP) ((float4*)tmp)[q] = r;
@@ -917,7 +924,7 @@ k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restr
 			const int xc = (int)(4 * q - row * sx);
 			if (bempty[(k >> 3) * nbj + (j >> 3)] || xc < xlo || xc >= xhi) continue;
 		}
-		float4 s = ((float4*)search)[q];
+		float4 s = PCG_NT_ALL ? ld_nt4(search + 4 * q) : ((float4*)search)[q];
 		// the pressure is touched here and nowhere else in an iteration, tmp for the last time before ApplyMatrix overwrites it: non-temporal,
 		// so that 128 MB per 256^3 iteration do not displace what the sweeps and the stencil re-read (63.1 vs 63.7 ms per step of tools/micro/ntv_bench.py)
 		float4 x = ld_nt4(dst + 4 * q);
@@ -926,7 +933,8 @@ k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restr
 		if (upd) {
 			const float4 t = ld_nt4(tmp + 4 * q);
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
-			((float4*)search)[q] = s;
+			if (PCG_NT_ALL) st_nt4(search + 4 * q, s);
+			else ((float4*)search)[q] = s;
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -997,7 +1005,7 @@ k_slab_axpy_r(int64_t n, const double* __restrict__ g, int world, CgScalars* __r
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
 		float4 r = ((float4*)residual)[q];
-		const float4 t = ((const float4*)tmp)[q];
+		const float4 t = (PCG_NT_ALL && SLAB_NT) ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		lo = fminf(fminf(lo, r.x), fminf(r.y, fminf(r.z, r.w)));
@@ -1070,7 +1078,7 @@ k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgSca
 	const float alpha = sc->alpha;
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
-		float4 s = ((float4*)search)[q];
+		float4 s = (PCG_NT_ALL && SLAB_NT) ? ld_nt4(search + 4 * q) : ((float4*)search)[q];
 		float4 x = SLAB_NT ? ld_nt4(dst + 4 * q) : ((float4*)dst)[q];
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
 		if (SLAB_NT) st_nt4(dst + 4 * q, x);
@@ -1078,7 +1086,8 @@ k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgSca
 		if (upd) {
 			const float4 t = SLAB_NT ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
-			((float4*)search)[q] = s;
+			if (PCG_NT_ALL && SLAB_NT) st_nt4(search + 4 * q, s);
+			else ((float4*)search)[q] = s;
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
