@@ -122,18 +122,13 @@ __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 #ifndef AM_NT
 #define AM_NT 2
 #endif
-// SLAB_NT: the same in the z-slab kernels (k_slab_axpy_r, k_slab_update_search_x; their ApplyMatrix is the PCG one).  Only the complete set
-// pays: with the pressure / tmp accesses alone, or ApplyMatrix alone, `bench.py --slab` was 74.1-74.6 ms per step, with all of them 72.0-72.6
-#ifndef SLAB_NT
-#define SLAB_NT 1
-#endif
-// PCG_NT_ALL: inside the PCG every vector stream EXCEPT the residual is non-temporal -- search and tmp in ApplyMatrix (own rows, result),
-// the residual update (tmp) and the search update (search, tmp, pressure) -- so that what the MIC sweeps read (residual, Aprecond, packed
-// bytes, tmp between the two sweeps) stays in L2 / the memory-side cache across the iteration: 72.3 -> 70.8 ms per 256^3 step.  Any one
-// of these changes alone: no difference or slower.
-#ifndef PCG_NT_ALL
-#define PCG_NT_ALL 1
-#endif
+// Inside the PCG every vector stream EXCEPT the residual is non-temporal -- search and tmp in ApplyMatrix (own rows, result), tmp in the
+// residual update, search / tmp / pressure in the search update; the same in the z-slab kernels -- so that what the MIC sweeps read
+// (residual, Aprecond, packed bytes, tmp between the two sweeps) stays in L2 / the memory-side cache across the iteration: 72.3 -> 70.8 ms
+// per 256^3 step, --slab 74.6 -> 72.3 ms.  Only the complete set pays (any one of these alone: no difference or slower), and only where
+// the vectors do not fit the caches anyway: a run-time flag of the kernels (`nt`), set for systems of more than PCG_NT_CELLS cells that
+// are swept whole (a liquid scene whose kernels skip most bundles touches a fraction: 23.5 ms per dam-break step cached, 23.9 non-temporal).
+constexpr int64_t PCG_NT_CELLS = (int64_t)8 << 20;
 // AMP_NT: 1 = the thread's own src rows non-temporal as well (68.2 -> 66.2 us; the z neighbours too: 76.8 us)
 #ifndef AMP_NT
 #define AMP_NT 1
@@ -147,7 +142,8 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
                   const int* __restrict__ outside_bad = nullptr, const int* __restrict__ xr = nullptr) {   // DOT covers the planes [dk0, dk1) (a z-slab's own)
 	// bempty (mf_cg_solve, liquid scenes): 8 x 8 bundles of rows without a fluid cell in which src is known to be zero (k_cg_outside_zero found
 	// rhs and the work grids zero there, and every kernel of the iteration keeps it so): dst = src = 0 is there already, nothing to do
-	// a0p (PACKED only): bits 4-7 of the packed bytes hold the diagonal (k_mic_pack) -- A0 is not read at all, 9 instead of 13 B per cell
+	// a0p bit 0 (PACKED only): bits 4-7 of the packed bytes hold the diagonal (k_mic_pack) -- A0 is not read at all, 9 instead of 13 B per cell;
+	// bit 1 (DOT, the PCG): src rows and dst non-temporal (PCG_NT_CELLS)
 	if (DOT && sc->done) return;
 	const int qx = d.sx >> 2;
 	const int64_t nthr = (int64_t)qx * jgroups * d.sz;
@@ -191,10 +187,10 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 	for (int r = 0; r < R; r++) {
 		const int jr = (j0 + r < d.sy) ? r : (d.sy - 1 - j0);
 		const int64_t idx = row0 + jr * Y;
-		sv[r + 1] = ((AMP_NT & 1) && (!DOT || PCG_NT_ALL)) ? ld_nt4(src + idx) : *(const float4*)(src + idx);      // (not inside the PCG: its neighbours re-read src)
+		sv[r + 1] = ((AMP_NT & 1) && (!DOT || (a0p & 2))) ? ld_nt4(src + idx) : *(const float4*)(src + idx);      // (inside the PCG -- DOT -- only as part of the complete set)
 		unsigned pw = 0;
 		if (PACKED) pw = *(const unsigned*)(pack + idx);
-		if (PACKED && a0p) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
+		if (PACKED && (a0p & 1)) a0[r] = make_float4((float)((pw >> 4) & 15u), (float)((pw >> 12) & 15u), (float)((pw >> 20) & 15u), (float)((pw >> 28) & 15u));
 		else a0[r] = (AM_NT >= 1) ? ld_nt4(A0 + idx) : *(const float4*)(A0 + idx);
 		if (PACKED) {
 			f[r] = unpack_flags(pw);
@@ -277,7 +273,7 @@ k_apply_matrix_v5(Dim d, const int32_t* __restrict__ flags, float* __restrict__ 
 #undef CELL5
 		}
 		if (live) {
-			if (AM_NT >= 2 && (!DOT || PCG_NT_ALL)) st_nt4(dst + row0 + r * Y, res);      // (inside the PCG -- DOT -- the next kernel reads dst back: no difference there)
+			if (AM_NT >= 2 && (!DOT || (a0p & 2))) st_nt4(dst + row0 + r * Y, res);
 			else *(float4*)(dst + row0 + r * Y) = res;
 			if (DOT && k >= dk0 && k < dk1) {
 				const float p0 = res.x * s.x, p1 = res.y * s.y, p2 = res.z * s.z, p3 = res.w * s.w;
@@ -338,8 +334,9 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
                                const float* Ai, const float* Aj, const float* Ak, double* partials,
                                const CgScalars* sc, hipStream_t st, int* nblocks, const unsigned char* pack = nullptr,
                                int dk0 = 0, int dk1 = 0x7fffffff, bool* ranged = nullptr, bool a0p = false, const int* bempty = nullptr,
-                               int nbj = 0, const int* outside_bad = nullptr, const int* xr = nullptr) {
+                               int nbj = 0, const int* outside_bad = nullptr, const int* xr = nullptr, int nt = -1) {
 	if (ranged) *ranged = false;
+	const int a0pn = (a0p ? 1 : 0) | ((DOT && (nt < 0 ? d.n > PCG_NT_CELLS : nt != 0)) ? 2 : 0);
 	const bool vec = (d.sx % 4 == 0) && al16(flags) && al16(dst) && al16(src) && al16(A0) && al16(Ai) && al16(Aj) && al16(Ak);
 	int nb;
 	static const int am_rows = [] {
@@ -354,11 +351,11 @@ static int launch_apply_matrix(const Dim& d, const int32_t* flags, float* dst, c
 		nb = (int)((vblocks + tpb - 1) / tpb);
 #define AM5(RR)                                                                                                                                   \
 	if (d.is3d && pack)                                                                                                                           \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad, xr); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, true>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0pn, bempty, nbj, outside_bad, xr); \
 	else if (d.is3d)                                                                                                                              \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad, xr); \
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, true, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0pn, bempty, nbj, outside_bad, xr); \
 	else                                                                                                                                          \
-		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0p ? 1 : 0, bempty, nbj, outside_bad, xr);
+		hipLaunchKernelGGL((k_apply_matrix_v5<DOT, false, RR, false>), dim3(nb), dim3(BLOCK), 0, st, d, flags, dst, src, A0, Ai, Aj, Ak, partials, sc, jgroups, tpb, pack, dk0, dk1, a0pn, bempty, nbj, outside_bad, xr);
 		if (R == 4) { AM5(4) } else if (R == 2) { AM5(2) } else { AM5(1) }
 #undef AM5
 		if (ranged) *ranged = true;
@@ -693,7 +690,7 @@ template <bool COPY_TMP, bool EDOT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ residual, float* __restrict__ tmp, float* __restrict__ fpart,
             double* __restrict__ dpart, const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0,
-            double* __restrict__ epart = nullptr, const int* __restrict__ outside_bad = nullptr, const int* __restrict__ xr = nullptr) {
+            double* __restrict__ epart = nullptr, const int* __restrict__ outside_bad = nullptr, const int* __restrict__ xr = nullptr, int nt = 0) {
 	if (sc->done) return;
 	// outside_bad[0] == 0 (k_cg_outside_zero): residual and tmp are zero in the bundles the sweeps leave out and stay so -- their quads
 	// are neither read nor written, they enter the min / max as the zeros they are and add nothing to the sums
@@ -718,7 +715,7 @@ k_cg_axpy_r(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ res
 			}
 		}
 		float4 r = ((float4*)residual)[q];
-		const float4 t = PCG_NT_ALL ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];      // (non-temporal here: 64.4 vs 63.7 ms per step)
+		const float4 t = nt ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];      // (non-temporal here alone: 64.4 vs 63.7 ms per step)
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		if (COPY_TMP) ((float4*)tmp)[q] = r;
@@ -910,7 +907,7 @@ template <bool SKIP>
 __global__ void __launch_bounds__(BLOCK)
 k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp,
                      const int* __restrict__ bempty = nullptr, int nbj = 0, int sx = 0, int sy = 0, const int* __restrict__ outside_bad = nullptr,
-                     const int* __restrict__ xr = nullptr) {
+                     const int* __restrict__ xr = nullptr, int nt = 0) {
 	if (!sc->xpending) return;
 	const bool upd = !sc->done;
 	const int xlo = (SKIP && xr) ? (xr[0] & ~7) : 0, xhi = (SKIP && xr) ? ((xr[1] + 7) & ~7) : 0x7fffffff;
@@ -924,16 +921,17 @@ k_cg_update_search_x(int64_t n, const CgScalars* __restrict__ sc, float* __restr
 			const int xc = (int)(4 * q - row * sx);
 			if (bempty[(k >> 3) * nbj + (j >> 3)] || xc < xlo || xc >= xhi) continue;
 		}
-		float4 s = PCG_NT_ALL ? ld_nt4(search + 4 * q) : ((float4*)search)[q];
+		float4 s = nt ? ld_nt4(search + 4 * q) : ((float4*)search)[q];
 		// the pressure is touched here and nowhere else in an iteration, tmp for the last time before ApplyMatrix overwrites it: non-temporal,
 		// so that 128 MB per 256^3 iteration do not displace what the sweeps and the stencil re-read (63.1 vs 63.7 ms per step of tools/micro/ntv_bench.py)
-		float4 x = ld_nt4(dst + 4 * q);
+		float4 x = nt ? ld_nt4(dst + 4 * q) : ((float4*)dst)[q];
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
-		st_nt4(dst + 4 * q, x);
+		if (nt) st_nt4(dst + 4 * q, x);
+		else ((float4*)dst)[q] = x;
 		if (upd) {
-			const float4 t = ld_nt4(tmp + 4 * q);
+			const float4 t = nt ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
-			if (PCG_NT_ALL) st_nt4(search + 4 * q, s);
+			if (nt) st_nt4(search + 4 * q, s);
 			else ((float4*)search)[q] = s;
 		}
 	}
@@ -983,7 +981,7 @@ __global__ void k_slab_alpha_x(const double* __restrict__ g, int world, CgScalar
 // another block of it (sigma and the stop state are written by the search update's kernel only).
 __global__ void __launch_bounds__(BLOCK)
 k_slab_axpy_r(int64_t n, const double* __restrict__ g, int world, CgScalars* __restrict__ sc, const int32_t* __restrict__ state,
-              float* __restrict__ residual, const float* __restrict__ tmp, float* __restrict__ fpart) {
+              float* __restrict__ residual, const float* __restrict__ tmp, float* __restrict__ fpart, int nt) {
 	const bool stopped = state[0] != 0;
 	float a = 0.f;
 	if (!stopped) {
@@ -1005,7 +1003,7 @@ k_slab_axpy_r(int64_t n, const double* __restrict__ g, int world, CgScalars* __r
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
 		float4 r = ((float4*)residual)[q];
-		const float4 t = (PCG_NT_ALL && SLAB_NT) ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
+		const float4 t = nt ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
 		r.x = r.x + nalpha * t.x; r.y = r.y + nalpha * t.y; r.z = r.z + nalpha * t.z; r.w = r.w + nalpha * t.w;
 		((float4*)residual)[q] = r;
 		lo = fminf(fminf(lo, r.x), fminf(r.y, fminf(r.z, r.w)));
@@ -1053,7 +1051,7 @@ __global__ void k_slab_beta_x(const double* __restrict__ g, int world, CgScalars
 // kernel wrote
 __global__ void __launch_bounds__(BLOCK)
 k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgScalars* __restrict__ sc, float accuracy, int iter,
-                       int32_t* __restrict__ state, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp) {
+                       int32_t* __restrict__ state, float* __restrict__ dst, float* __restrict__ search, const float* __restrict__ tmp, int nt) {
 	if (!sc->xpending) return;          // stopped before this iteration
 	double acc = 0.0, mx = 0.0;
 	for (int r = 0; r < world; r++) {
@@ -1078,15 +1076,15 @@ k_slab_update_search_x(int64_t n, const double* __restrict__ g, int world, CgSca
 	const float alpha = sc->alpha;
 	const int64_t n4 = n >> 2;
 	for (int64_t q = blockIdx.x * (int64_t)BLOCK + threadIdx.x; q < n4; q += (int64_t)gridDim.x * BLOCK) {
-		float4 s = (PCG_NT_ALL && SLAB_NT) ? ld_nt4(search + 4 * q) : ((float4*)search)[q];
-		float4 x = SLAB_NT ? ld_nt4(dst + 4 * q) : ((float4*)dst)[q];
+		float4 s = nt ? ld_nt4(search + 4 * q) : ((float4*)search)[q];
+		float4 x = nt ? ld_nt4(dst + 4 * q) : ((float4*)dst)[q];
 		x.x = x.x + alpha * s.x; x.y = x.y + alpha * s.y; x.z = x.z + alpha * s.z; x.w = x.w + alpha * s.w;
-		if (SLAB_NT) st_nt4(dst + 4 * q, x);
+		if (nt) st_nt4(dst + 4 * q, x);
 		else ((float4*)dst)[q] = x;
 		if (upd) {
-			const float4 t = SLAB_NT ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
+			const float4 t = nt ? ld_nt4(tmp + 4 * q) : ((const float4*)tmp)[q];
 			s.x = t.x + beta * s.x; s.y = t.y + beta * s.y; s.z = t.z + beta * s.z; s.w = t.w + beta * s.w;
-			if (PCG_NT_ALL && SLAB_NT) st_nt4(search + 4 * q, s);
+			if (nt) st_nt4(search + 4 * q, s);
 			else ((float4*)search)[q] = s;
 		}
 	}
@@ -1509,6 +1507,7 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	} trim_guard;
 	g_last_shortcut[0] = g_last_shortcut[1] = g_last_shortcut[2] = 0;
 	const int* xr_dev = nullptr;      // device x-range of the packed system, for the kernels that skip by it
+	const int pcg_nt = (!sk_map && n > PCG_NT_CELLS) ? 1 : 0;      // the vector streams around the sweeps non-temporal (see PCG_NT_CELLS)
 	if (sk_map) {
 		// (n % 4 == 0 here: sx % 4 == 0.)  residual = rhs and dst = 0 were set above; tmp and search are the caller's
 		int* p_xr = p_bad + 1;
@@ -1557,13 +1556,14 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 			int nba = 0, nsig = 0;
 			bool beta_done = false;
 			MF_TRY(launch_apply_matrix<true>(d, flags, tmp, search, A0, Ai, Aj, Ak, p_dot, sc, st, &nba, am_pack, 0, 0x7fffffff, nullptr, am_a0p, sk_map,
-			                                 sk_nbj, sk_map ? p_bad : nullptr, xr_dev));
+			                                 sk_nbj, sk_map ? p_bad : nullptr, xr_dev, pcg_nt));
 			hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(BLOCK), 0, st, sc, nba, p_dot);
 			if (pc == MF_PC_MICP) {
 				if (sk_map)      // (without be_map the shares it writes behind the sweep's partials are not summed: the sweep has them)
-					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, sk_map, sk_nbj, sx, sy, p_sig + be_nb, p_bad, xr_dev);
+					hipLaunchKernelGGL((k_cg_axpy_r<false, true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, sk_map, sk_nbj, sx, sy, p_sig + be_nb, p_bad, xr_dev, pcg_nt);
 				else
-					hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res);
+					hipLaunchKernelGGL((k_cg_axpy_r<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, residual, tmp, p_mm, p_res, (const int*)nullptr, 0, 0, 0,
+					                   (double*)nullptr, (const int*)nullptr, (const int*)nullptr, pcg_nt);
 				MF_TRY(mic_launch(1, d, flags, tmp, residual, Aprecond, Ai, Aj, Ak, sc, st));
 				// sigma_new = dot(tmp, residual) comes out of the backward sweep's write-back (one partial per row bundle); the shares of
 				// the bundles the sweeps leave out: from the residual update above, behind the sweep's partials
@@ -1583,9 +1583,10 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 			}
 			if (!beta_done) hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(BLOCK), 0, st, sc, nbs, p_mm, p_res, nsig, p_sig);
 			if (sk_map)
-				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, sk_map, sk_nbj, sx, sy, p_bad, xr_dev);
+				hipLaunchKernelGGL((k_cg_update_search_x<true>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, sk_map, sk_nbj, sx, sy, p_bad, xr_dev, pcg_nt);
 			else
-				hipLaunchKernelGGL((k_cg_update_search_x<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp);
+				hipLaunchKernelGGL((k_cg_update_search_x<false>), dim3(nbs), dim3(BLOCK), 0, st, n, sc, dst, search, tmp, (const int*)nullptr, 0, 0, 0, (const int*)nullptr,
+				                   (const int*)nullptr, pcg_nt);
 		}
 		MF_LAUNCH_CHECK();
 		issued += todo;
@@ -1719,7 +1720,7 @@ int mf_cg_slab_after_dp(const double* gathered, int world, void* scalars, const 
 			MF_TRY(get_workspace(&ws));
 			const int nb = blocks_for(n_own >> 2, BLOCK, 2048);
 			// the alpha step rides in the residual update (every block forms it from the gathered rows)
-			hipLaunchKernelGGL(k_slab_axpy_r, dim3(nb), dim3(BLOCK), 0, st, n_own, gathered, world, sc, state_dev, r, t, ws->fpartials);
+			hipLaunchKernelGGL(k_slab_axpy_r, dim3(nb), dim3(BLOCK), 0, st, n_own, gathered, world, sc, state_dev, r, t, ws->fpartials, n_own > PCG_NT_CELLS ? 1 : 0);
 			MF_LAUNCH_CHECK();
 			// max |r| of these partials and dot(tmp, r): folded by the last workgroup of the backward sweep (no one-block launches)
 			MF_TRY(check_dim(sx, sy, sz));
@@ -1744,7 +1745,7 @@ int mf_cg_slab_after_zr(const double* gathered, int world, void* scalars, float 
 	if (n_own > 0 && state_dev && al16(xs) && al16(s) && al16(t)) {
 		// the beta step and the stopping test ride in the search update
 		hipLaunchKernelGGL(k_slab_update_search_x, dim3(blocks_for(n_own >> 2, BLOCK, 2048)), dim3(BLOCK), 0, st, n_own, gathered, world, sc,
-		                   accuracy, iter, state_dev, xs, s, t);
+		                   accuracy, iter, state_dev, xs, s, t, n_own > PCG_NT_CELLS ? 1 : 0);
 		MF_LAUNCH_CHECK();
 		return 0;
 	}
