@@ -126,9 +126,12 @@ __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 // residual update, search / tmp / pressure in the search update; the same in the z-slab kernels -- so that what the MIC sweeps read
 // (residual, Aprecond, packed bytes, tmp between the two sweeps) stays in L2 / the memory-side cache across the iteration: 72.3 -> 70.8 ms
 // per 256^3 step, --slab 74.6 -> 72.3 ms.  Only the complete set pays (any one of these alone: no difference or slower), and only where
-// the vectors do not fit the caches anyway: a run-time flag of the kernels (`nt`), set for systems of more than PCG_NT_CELLS cells that
+// the vectors do not fit the caches anyway: a run-time flag of the kernels (`nt`), set for systems of more than PCG_NT_CELLS cells (10 Mi: the 129-plane window of one rank of two, 8.45 M cells, is 1.2 % faster cached) that
 // are swept whole (a liquid scene whose kernels skip most bundles touches a fraction: 23.5 ms per dam-break step cached, 23.9 non-temporal).
-constexpr int64_t PCG_NT_CELLS = (int64_t)8 << 20;
+#ifndef PCG_NT_MI
+#define PCG_NT_MI 10
+#endif
+constexpr int64_t PCG_NT_CELLS = (int64_t)PCG_NT_MI << 20;
 // AMP_NT: 1 = the thread's own src rows non-temporal as well (68.2 -> 66.2 us; the z neighbours too: 76.8 us)
 #ifndef AMP_NT
 #define AMP_NT 1
