@@ -119,6 +119,8 @@ template <unsigned BIT>
 __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 	return make_float4((w & BIT) ? -1.f : 0.f, (w & (BIT << 8)) ? -1.f : 0.f, (w & (BIT << 16)) ? -1.f : 0.f, (w & (BIT << 24)) ? -1.f : 0.f);
 }
+// AM_NT: non-temporal accesses (common.h: ld_nt4 / st_nt4) for what ApplyMatrix touches once -- 1: A0 / Ai / flags loads, 2: the dst
+// store as well -- 91 -> 69 us at 256^3 (3: Aj / Ak too: 78 us, they are re-read as the j-1 / k-1 coefficients)
 #ifndef AM_NT
 #define AM_NT 2
 #endif
@@ -126,8 +128,9 @@ __device__ __forceinline__ float4 unpack_coef(unsigned w) {
 // residual update, search / tmp / pressure in the search update; the same in the z-slab kernels -- so that what the MIC sweeps read
 // (residual, Aprecond, packed bytes, tmp between the two sweeps) stays in L2 / the memory-side cache across the iteration: 72.3 -> 70.8 ms
 // per 256^3 step, --slab 74.6 -> 72.3 ms.  Only the complete set pays (any one of these alone: no difference or slower), and only where
-// the vectors do not fit the caches anyway: a run-time flag of the kernels (`nt`), set for systems of more than PCG_NT_CELLS cells (10 Mi: the 129-plane window of one rank of two, 8.45 M cells, is 1.2 % faster cached) that
-// are swept whole (a liquid scene whose kernels skip most bundles touches a fraction: 23.5 ms per dam-break step cached, 23.9 non-temporal).
+// the vectors do not fit the caches anyway: a run-time flag of the kernels (`nt`), set for systems of more than PCG_NT_CELLS cells (10 Mi:
+// the 129-plane window of one rank of two, 8.45 M cells, is 1.2 % faster cached) that are swept whole (a liquid scene whose kernels skip
+// most bundles touches a fraction: 23.5 ms per dam-break step cached, 23.9 non-temporal).
 #ifndef PCG_NT_MI
 #define PCG_NT_MI 10
 #endif
