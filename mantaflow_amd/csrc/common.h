@@ -32,11 +32,12 @@ int fail(const char* fmt, ...);
 struct Workspace {
 	double* partials;   // [MAX_BLOCKS * 4]
 	float* fpartials;   // [MAX_BLOCKS * 4]
-	void* scalars;      // device scalar block (CgScalars etc.), 4 KiB
+	void* scalars;      // device scalar block, 4 KiB: CgScalars / reduction results at 0, mf_cg_solve's liquid-scene flags at WS_PCG_FLAGS
 	void* host;         // pinned host mirror, 4 KiB
 	int* tilework;      // counters for work-queue kernels
 };
 constexpr int MAX_BLOCKS = 16384;
+constexpr int WS_PCG_FLAGS = 1024;   // byte offset in Workspace::scalars of {outside_bad, x-range lo, x-range hi} (k_cg_outside_zero, k_pack_xrange)
 int get_workspace(Workspace** ws);
 
 // ---- grid geometry ---------------------------------------------------------------------------------

@@ -1502,7 +1502,7 @@ static int cg_solve_core(const Dim& d, const int32_t* flags, float* dst, const f
 	int be_nbj = 0;
 	if (pc == MF_PC_MICP && (sx % 4) == 0) MF_TRY(mic_empty_map(d, flags, Aprecond, Aj, Ak, &be_map, &be_nbj, st));
 	const int be_nb = ((sy + 7) / 8) * ((sz + 7) / 8);      // the sweep's partials (one per bundle) come first, the nbs of the residual update behind them
-	int* p_bad = (int*)((char*)ws->scalars + 1024);
+	int* p_bad = (int*)((char*)ws->scalars + WS_PCG_FLAGS);
 	// the map the vector kernels skip by: the same one, also where the sweep sums the shares of the empty bundles itself (<= one bundle per CU)
 	const int* sk_map = be_map;
 	int sk_nbj = be_nbj;
